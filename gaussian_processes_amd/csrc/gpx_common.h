@@ -1,0 +1,72 @@
+// gpx_common.h -- shared internals of libgpx.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+
+#include "../../include/gpx.h"
+
+namespace gpx {
+
+void set_error(const char *fmt, ...);
+int  hip_fail(hipError_t e, const char *what, const char *file, int line);
+int  ensure_device();   // GPX_OK when a GPU is usable
+
+#define GPX_HIP(call)                                                        \
+    do {                                                                     \
+        hipError_t e__ = (call);                                             \
+        if (e__ != hipSuccess) return gpx::hip_fail(e__, #call, __FILE__, __LINE__); \
+    } while (0)
+
+#define GPX_TRY(call)                                                        \
+    do {                                                                     \
+        int rc__ = (call);                                                   \
+        if (rc__ != GPX_OK) return rc__;                                     \
+    } while (0)
+
+#define GPX_ARG(cond, msg)                                                   \
+    do {                                                                     \
+        if (!(cond)) { gpx::set_error("%s: %s", __func__, msg); return GPX_ERR_ARG; } \
+    } while (0)
+
+#define GPX_LAUNCH_CHECK()                                                   \
+    do {                                                                     \
+        hipError_t e__ = hipGetLastError();                                  \
+        if (e__ != hipSuccess) return gpx::hip_fail(e__, "kernel launch", __FILE__, __LINE__); \
+    } while (0)
+
+static inline hipStream_t S(void *s) { return (hipStream_t)s; }
+static inline size_t esize(int dtype) { return dtype == GPX_F64 ? 8 : 4; }
+static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// parameters of a kernel-matrix member, precomputed on the host in f64
+struct KParams {
+    double c[6];     // member-specific constants (see gpx_kmat.hip)
+    double diag_add;
+    int kernel;
+    int member;
+};
+int make_kparams(int kernel, int member, const double *params, double diag_add, KParams *out);
+
+// internal (non-ABI) helpers shared between translation units
+int gemm_nt(int dtype, int64_t M, int64_t N, int64_t K, const void *A, int64_t lda, const void *B,
+            int64_t ldb, void *C, int64_t ldc, double alpha, int tri, int64_t row0, int64_t col0,
+            hipStream_t st);
+// X[r, 0:jb] <- X[r, 0:jb] * Ljj^-T for rows r in [0, rows); Ljj = jb x jb lower block
+int trsm_rows(int dtype, void *X, int64_t ldx, int64_t rows, const void *Ljj, int64_t ldl, int jb,
+              hipStream_t st);
+int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t st);
+int trsv_lower(int dtype, const void *L, int64_t n, int64_t ldl, void *b, void *x, int transpose,
+               hipStream_t st);
+int trsm_right_lt(int dtype, const void *L, int64_t n, int64_t ldl, void *X, int64_t m, int64_t ldx,
+                  hipStream_t st);
+int logdet_chol(int dtype, const void *L, int64_t n, int64_t ldl, double *out_dev, hipStream_t st);
+int dot(int dtype, const void *a, const void *b, int64_t n, double *out_dev, hipStream_t st);
+int tril(int dtype, void *A, int64_t n, int64_t lda, hipStream_t st);
+int kmat(int dtype, int kernel, int member, const void *x1, int64_t n, const void *x2, int64_t m,
+         int d, const double *params, double diag_add, int tri, void *out, int64_t ld, hipStream_t st);
+
+}  // namespace gpx

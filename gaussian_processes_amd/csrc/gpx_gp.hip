@@ -1,0 +1,622 @@
+// gpx_gp.hip -- the fitted-GP device handle and the host-pointer drop-in entry points.
+//
+// gpx_gp_t keeps one GP resident in HBM and mirrors the memoised properties of
+// the reference's gp.GP (gp/gp.py:242-396): Kxx (built lower, + s^2 on the
+// diagonal) -> Lxx (in place) -> inv_Kxx_y -> logdet / y^T alpha -> log_lh, then
+// posterior mean / covariance (gp/gp.py:574-625).  Data layout in HBM:
+//   x      (n, d)  row-major, dtype T
+//   y      (n,)
+//   A      (n, lda) row-major, lda = round_up(n, 16): lower triangle holds K, then L
+//   alpha  (n,)    K^-1 y
+//   t0,t1  (n,)    solve scratch
+//   scal   3 doubles (logdet, y^T alpha, spare) + 1 int (potrf info)
+#include "gpx_common.h"
+#include <vector>
+
+struct gpx_gp {
+    int dtype, kernel, d, nparams;
+    int64_t n, lda;
+    void *x, *y, *A, *alpha, *t0, *t1;
+    double *scal;      // device: [0] logdet [1] y^T alpha [2] spare ; int info at scal + 3
+    hipStream_t st;
+    hipEvent_t ev[6];
+    double params[3];
+    double s;
+    bool have_data, have_params, fitted, have_K;
+    float ms[5];
+};
+
+namespace gpx {
+
+template <typename T>
+__global__ void cvt_from_f64(const double *__restrict__ src, T *__restrict__ dst, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (T)src[i];
+}
+
+template <typename T>
+__global__ void cvt_to_f64_2d(const T *__restrict__ src, int64_t lds, double *__restrict__ dst,
+                              int64_t ldd, int64_t rows, int64_t cols, int lower_only)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
+        const double v = (double)src[r * lds + c];
+        dst[r * ldd + c] = (lower_only && c > r) ? 0.0 : v;
+    }
+}
+
+template <typename T>
+__global__ void eye_kernel(T *__restrict__ X, int64_t n, int64_t ld)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ld) return;
+    for (int64_t r = blockIdx.y; r < n; r += gridDim.y) X[r * ld + c] = (c == r) ? (T)1 : (T)0;
+}
+
+// upload a host f64 array into a device buffer of dtype (via a temporary when f32)
+static int upload_f64(int dtype, void *dst, const double *src, int64_t count, hipStream_t st)
+{
+    if (count <= 0) return GPX_OK;
+    if (dtype == GPX_F64) {
+        GPX_HIP(hipMemcpyAsync(dst, src, count * 8, hipMemcpyHostToDevice, st));
+        GPX_HIP(hipStreamSynchronize(st));
+        return GPX_OK;
+    }
+    double *tmp = nullptr;
+    GPX_HIP(hipMalloc((void **)&tmp, count * 8));
+    hipError_t e = hipMemcpyAsync(tmp, src, count * 8, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL((cvt_from_f64<float>), dim3((unsigned)cdiv(count, 256)), dim3(256), 0, st,
+                           tmp, (float *)dst, count);
+        e = hipStreamSynchronize(st);
+    }
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return hip_fail(e, "upload_f64", __FILE__, __LINE__);
+    return GPX_OK;
+}
+
+// download a device (rows x cols, lds) matrix of dtype into host f64 (ldh)
+static int download_f64(int dtype, double *dst, int64_t ldh, const void *src, int64_t lds, int64_t rows,
+                        int64_t cols, int lower_only, hipStream_t st)
+{
+    if (rows <= 0 || cols <= 0) return GPX_OK;
+    if (cols == 1 && lds == 1 && ldh == 1) { cols = rows; rows = 1; lds = cols; ldh = cols; }   // vector
+    double *tmp = nullptr;
+    GPX_HIP(hipMalloc((void **)&tmp, (size_t)rows * cols * 8));
+    dim3 grid((unsigned)cdiv(cols, 256), (unsigned)std::min<int64_t>(rows, 32768)), block(256);
+    if (dtype == GPX_F64)
+        hipLaunchKernelGGL((cvt_to_f64_2d<double>), grid, block, 0, st, (const double *)src, lds, tmp,
+                           cols, rows, cols, lower_only);
+    else
+        hipLaunchKernelGGL((cvt_to_f64_2d<float>), grid, block, 0, st, (const float *)src, lds, tmp, cols,
+                           rows, cols, lower_only);
+    hipError_t e = hipMemcpy2DAsync(dst, (size_t)ldh * 8, tmp, (size_t)cols * 8, (size_t)cols * 8,
+                                    (size_t)rows, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return hip_fail(e, "download_f64", __FILE__, __LINE__);
+    return GPX_OK;
+}
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes)
+    {
+        hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+        if (e != hipSuccess) { p = nullptr; return hip_fail(e, "hipMalloc", __FILE__, __LINE__); }
+        return GPX_OK;
+    }
+};
+
+int kmat(int dtype, int kernel, int member, const void *x1, int64_t n, const void *x2, int64_t m,
+         int d, const double *params, double diag_add, int tri, void *out, int64_t ld, hipStream_t st)
+{
+    return gpx_d_kmat(dtype, kernel, member, x1, n, x2, m, d, params, diag_add, tri, out, ld, (void *)st);
+}
+
+static int nparams_of(int kernel) { return kernel == GPX_KERNEL_PERIODIC ? 3 : 2; }
+
+}  // namespace gpx
+
+using namespace gpx;
+
+extern "C" {
+
+// ------------------------------------------------------------- the handle --
+int gpx_gp_create(gpx_gp_t **out, int dtype, int kernel, int64_t n, int d)
+{
+    GPX_TRY(ensure_device());
+    GPX_ARG(out, "gp is NULL");
+    *out = nullptr;
+    GPX_ARG(dtype == GPX_F64 || dtype == GPX_F32, "dtype must be GPX_F64 or GPX_F32");
+    GPX_ARG(kernel == GPX_KERNEL_GAUSSIAN || kernel == GPX_KERNEL_PERIODIC, "unknown kernel family");
+    GPX_ARG(n >= 1 && d >= 1, "need n >= 1 and d >= 1");
+    gpx_gp *g = new gpx_gp();
+    memset(g, 0, sizeof(*g));
+    g->dtype = dtype; g->kernel = kernel; g->n = n; g->d = d;
+    g->nparams = nparams_of(kernel);
+    g->lda = round_up(n, 16);
+    const size_t es = esize(dtype);
+    int rc = GPX_OK;
+    hipError_t e;
+#define GP_ALLOC(field, bytes)                                                        \
+    if (rc == GPX_OK) {                                                               \
+        e = hipMalloc((void **)&g->field, (bytes));                                   \
+        if (e != hipSuccess) rc = hip_fail(e, "hipMalloc " #field, __FILE__, __LINE__); \
+    }
+    GP_ALLOC(x, (size_t)n * d * es);
+    GP_ALLOC(y, (size_t)n * es);
+    GP_ALLOC(A, (size_t)n * g->lda * es);
+    GP_ALLOC(alpha, (size_t)n * es);
+    GP_ALLOC(t0, (size_t)n * es);
+    GP_ALLOC(t1, (size_t)n * es);
+    GP_ALLOC(scal, 4 * sizeof(double));
+#undef GP_ALLOC
+    if (rc == GPX_OK) {
+        e = hipStreamCreateWithFlags(&g->st, hipStreamNonBlocking);
+        if (e != hipSuccess) rc = hip_fail(e, "hipStreamCreate", __FILE__, __LINE__);
+    }
+    for (int i = 0; i < 6 && rc == GPX_OK; ++i) {
+        e = hipEventCreate(&g->ev[i]);
+        if (e != hipSuccess) rc = hip_fail(e, "hipEventCreate", __FILE__, __LINE__);
+    }
+    if (rc != GPX_OK) { gpx_gp_destroy(g); return rc; }
+    *out = g;
+    return GPX_OK;
+}
+
+int gpx_gp_destroy(gpx_gp_t *g)
+{
+    if (!g) return GPX_OK;
+    if (g->st) (void)hipStreamSynchronize(g->st);
+    void *bufs[] = {g->x, g->y, g->A, g->alpha, g->t0, g->t1, g->scal};
+    for (void *b : bufs) if (b) (void)hipFree(b);
+    for (int i = 0; i < 6; ++i) if (g->ev[i]) (void)hipEventDestroy(g->ev[i]);
+    if (g->st) (void)hipStreamDestroy(g->st);
+    delete g;
+    return GPX_OK;
+}
+
+int gpx_gp_set_data(gpx_gp_t *g, const double *x, const double *y)
+{
+    GPX_ARG(g && x && y, "NULL argument");
+    GPX_TRY(upload_f64(g->dtype, g->x, x, g->n * g->d, g->st));
+    GPX_TRY(upload_f64(g->dtype, g->y, y, g->n, g->st));
+    g->have_data = true; g->fitted = false;
+    return GPX_OK;
+}
+
+int gpx_gp_set_data_device(gpx_gp_t *g, const void *x_dev, const void *y_dev)
+{
+    GPX_ARG(g && x_dev && y_dev, "NULL argument");
+    const size_t es = esize(g->dtype);
+    GPX_HIP(hipMemcpyAsync(g->x, x_dev, (size_t)g->n * g->d * es, hipMemcpyDeviceToDevice, g->st));
+    GPX_HIP(hipMemcpyAsync(g->y, y_dev, (size_t)g->n * es, hipMemcpyDeviceToDevice, g->st));
+    g->have_data = true; g->fitted = false;
+    return GPX_OK;
+}
+
+int gpx_gp_set_params(gpx_gp_t *g, const double *params, double s)
+{
+    GPX_ARG(g && params, "NULL argument");
+    GPX_ARG(s >= 0, "invalid value for s");                    // gp/gp.py:192-193
+    for (int i = 0; i < g->nparams; ++i) g->params[i] = params[i];
+    g->s = s;
+    g->have_params = true; g->fitted = false; g->have_K = false;
+    return GPX_OK;
+}
+
+int gpx_gp_set_K(gpx_gp_t *g, const double *Kxx, int64_t ld)
+{
+    GPX_ARG(g && Kxx && ld >= g->n, "bad arguments");
+    const int64_t n = g->n;
+    if (g->dtype == GPX_F64) {
+        GPX_HIP(hipMemcpy2DAsync(g->A, (size_t)g->lda * 8, Kxx, (size_t)ld * 8, (size_t)n * 8, (size_t)n,
+                                 hipMemcpyHostToDevice, g->st));
+        GPX_HIP(hipStreamSynchronize(g->st));
+    } else {
+        // stage as f64, convert row by row into the padded f32 matrix
+        DevBuf tmp;
+        GPX_TRY(tmp.alloc((size_t)n * n * 8));
+        GPX_HIP(hipMemcpy2DAsync(tmp.p, (size_t)n * 8, Kxx, (size_t)ld * 8, (size_t)n * 8, (size_t)n,
+                                 hipMemcpyHostToDevice, g->st));
+        for (int64_t r = 0; r < n; ++r)
+            hipLaunchKernelGGL((cvt_from_f64<float>), dim3((unsigned)cdiv(n, 256)), dim3(256), 0, g->st,
+                               (const double *)tmp.p + r * n, (float *)g->A + r * g->lda, n);
+        GPX_HIP(hipStreamSynchronize(g->st));
+    }
+    g->have_K = true; g->fitted = false;
+    return GPX_OK;
+}
+
+int gpx_gp_fit(gpx_gp_t *g, int *info)
+{
+    GPX_ARG(g, "gp is NULL");
+    GPX_ARG(g->have_data && (g->have_params || g->have_K),
+            "set_data and set_params (or set_K) must be called before fit");
+    const size_t es = esize(g->dtype);
+    int *info_dev = (int *)(g->scal + 3);
+    hipStream_t st = g->st;
+    GPX_HIP(hipEventRecord(g->ev[0], st));
+    // Kxx = K(x, x) + s^2 I, lower triangle only (gp/gp.py:263-266)
+    if (!g->have_K)
+        GPX_TRY(kmat(g->dtype, g->kernel, GPX_K, g->x, g->n, g->x, g->n, g->d, g->params, g->s * g->s,
+                     GPX_LOWER, g->A, g->lda, st));
+    g->have_K = false;   // the factor overwrites it
+    GPX_HIP(hipEventRecord(g->ev[1], st));
+    // Lxx (gp/gp.py:294), in place
+    GPX_TRY(potrf(g->dtype, g->A, g->n, g->lda, info_dev, st));
+    GPX_HIP(hipEventRecord(g->ev[2], st));
+    // inv_Kxx_y = cho_solve((L, True), y) (gp/gp.py:332-334)
+    GPX_HIP(hipMemcpyAsync(g->t0, g->y, (size_t)g->n * es, hipMemcpyDeviceToDevice, st));
+    GPX_TRY(trsv_lower(g->dtype, g->A, g->n, g->lda, g->t0, g->t1, 0, st));
+    GPX_TRY(trsv_lower(g->dtype, g->A, g->n, g->lda, g->t1, g->alpha, 1, st));
+    GPX_HIP(hipEventRecord(g->ev[3], st));
+    // logdet (replaces slogdet(K), gp_c.pyx:21) and y^T alpha (gp_c.pyx:26)
+    GPX_TRY(logdet_chol(g->dtype, g->A, g->n, g->lda, g->scal + 0, st));
+    GPX_TRY(dot(g->dtype, g->y, g->alpha, g->n, g->scal + 1, st));
+    GPX_HIP(hipEventRecord(g->ev[4], st));
+    g->fitted = true;
+    if (info) {
+        GPX_HIP(hipMemcpyAsync(info, info_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+        GPX_HIP(hipStreamSynchronize(st));
+    }
+    return GPX_OK;
+}
+
+static int gp_scalars(gpx_gp_t *g, double *logdet, double *yta, int *info)
+{
+    GPX_ARG(g && g->fitted, "gp is not fitted");
+    double h[4];
+    GPX_HIP(hipMemcpyAsync(h, g->scal, sizeof(h), hipMemcpyDeviceToHost, g->st));
+    GPX_HIP(hipStreamSynchronize(g->st));
+    if (logdet) *logdet = h[0];
+    if (yta) *yta = h[1];
+    if (info) memcpy(info, &h[3], sizeof(int));
+    return GPX_OK;
+}
+
+int gpx_gp_log_lh(gpx_gp_t *g, double *log_lh)
+{
+    GPX_ARG(log_lh, "log_lh is NULL");
+    double logdet, yta; int info;
+    GPX_TRY(gp_scalars(g, &logdet, &yta, &info));
+    // gp/gp.py:362-365 (LinAlgError -> -inf) and gp_c.pyx:22-29 (sign / MIN clamp)
+    if (info != 0 || !(logdet >= GPX_MIN_LOG)) { *log_lh = -INFINITY; return GPX_OK; }
+    const double data_fit = -0.5 * yta;
+    const double complexity_penalty = -0.5 * logdet;
+    const double constant = -0.5 * (double)g->n * log(2 * M_PI);
+    *log_lh = data_fit + complexity_penalty + constant;
+    return GPX_OK;
+}
+
+int gpx_gp_logdet(gpx_gp_t *g, double *logdet)
+{
+    GPX_ARG(logdet, "logdet is NULL");
+    return gp_scalars(g, logdet, nullptr, nullptr);
+}
+
+int gpx_gp_info(gpx_gp_t *g, int *info)
+{
+    GPX_ARG(info, "info is NULL");
+    return gp_scalars(g, nullptr, nullptr, info);
+}
+
+int gpx_gp_mean(gpx_gp_t *g, const double *xo, int64_t m, double *out)
+{
+    GPX_ARG(g && g->fitted, "gp is not fitted");
+    GPX_ARG(m >= 0 && (m == 0 || (xo && out)), "bad arguments");
+    if (m == 0) return GPX_OK;
+    const size_t es = esize(g->dtype);
+    DevBuf dxo, dout;
+    GPX_TRY(dxo.alloc((size_t)m * g->d * es));
+    GPX_TRY(dout.alloc((size_t)m * es));
+    GPX_TRY(upload_f64(g->dtype, dxo.p, xo, m * g->d, g->st));
+    GPX_TRY(gpx_d_mean(g->dtype, g->kernel, dxo.p, m, g->x, g->n, g->d, g->params, g->alpha, dout.p,
+                       (void *)g->st));
+    return download_f64(g->dtype, out, 1, dout.p, 1, m, 1, 0, g->st);
+}
+
+int gpx_gp_cov(gpx_gp_t *g, const double *xo, int64_t m, double *out)
+{
+    GPX_ARG(g && g->fitted, "gp is not fitted");
+    GPX_ARG(m >= 0 && (m == 0 || (xo && out)), "bad arguments");
+    if (m == 0) return GPX_OK;
+    const size_t es = esize(g->dtype);
+    const int64_t ldx = g->lda, ldc = round_up(m, 16);
+    DevBuf dxo, X, C;
+    GPX_TRY(dxo.alloc((size_t)m * g->d * es));
+    GPX_TRY(X.alloc((size_t)m * ldx * es));
+    GPX_TRY(C.alloc((size_t)m * ldc * es));
+    GPX_TRY(upload_f64(g->dtype, dxo.p, xo, m * g->d, g->st));
+    // X = Kxox (m x n); V^T = X L^-T; cov = Kxoxo - V^T V   (gp/gp.py:622-625 without K^-1)
+    GPX_TRY(kmat(g->dtype, g->kernel, GPX_K, dxo.p, m, g->x, g->n, g->d, g->params, 0.0, GPX_FULL, X.p,
+                 ldx, g->st));
+    GPX_TRY(trsm_right_lt(g->dtype, g->A, g->n, g->lda, X.p, m, ldx, g->st));
+    GPX_TRY(kmat(g->dtype, g->kernel, GPX_K, dxo.p, m, dxo.p, m, g->d, g->params, 0.0, GPX_FULL, C.p,
+                 ldc, g->st));
+    GPX_TRY(gemm_nt(g->dtype, m, m, g->n, X.p, ldx, X.p, ldx, C.p, ldc, -1.0, GPX_FULL, 0, 0, g->st));
+    return download_f64(g->dtype, out, m, C.p, ldc, m, m, 0, g->st);
+}
+
+int gpx_gp_mean_from_K(gpx_gp_t *g, const double *Kxox, int64_t m, double *out)
+{
+    GPX_ARG(g && g->fitted, "gp is not fitted");
+    GPX_ARG(m >= 0 && (m == 0 || (Kxox && out)), "bad arguments");
+    if (m == 0) return GPX_OK;
+    const size_t es = esize(g->dtype);
+    const int64_t n = g->n, ldx = g->lda;
+    DevBuf X, o;
+    GPX_TRY(X.alloc((size_t)m * ldx * es));
+    GPX_TRY(o.alloc((size_t)m * es));
+    GPX_HIP(hipMemsetAsync(o.p, 0, (size_t)m * es, g->st));
+    if (g->dtype == GPX_F64) {
+        GPX_HIP(hipMemcpy2DAsync(X.p, (size_t)ldx * 8, Kxox, (size_t)n * 8, (size_t)n * 8, (size_t)m,
+                                 hipMemcpyHostToDevice, g->st));
+    } else {
+        for (int64_t r = 0; r < m; ++r)
+            GPX_TRY(upload_f64(g->dtype, (float *)X.p + r * ldx, Kxox + r * n, n, g->st));
+    }
+    GPX_TRY(gemm_nt(g->dtype, m, 1, n, X.p, ldx, g->alpha, ldx, o.p, 1, 1.0, GPX_FULL, 0, 0, g->st));
+    return download_f64(g->dtype, out, 1, o.p, 1, m, 1, 0, g->st);
+}
+
+int gpx_gp_cov_from_K(gpx_gp_t *g, const double *Kxox, const double *Kxoxo, int64_t m, double *out)
+{
+    GPX_ARG(g && g->fitted, "gp is not fitted");
+    GPX_ARG(m >= 0 && (m == 0 || (Kxox && Kxoxo && out)), "bad arguments");
+    if (m == 0) return GPX_OK;
+    const size_t es = esize(g->dtype);
+    const int64_t n = g->n, ldx = g->lda, ldc = round_up(m, 16);
+    DevBuf X, C;
+    GPX_TRY(X.alloc((size_t)m * ldx * es));
+    GPX_TRY(C.alloc((size_t)m * ldc * es));
+    if (g->dtype == GPX_F64) {
+        GPX_HIP(hipMemcpy2DAsync(X.p, (size_t)ldx * 8, Kxox, (size_t)n * 8, (size_t)n * 8, (size_t)m,
+                                 hipMemcpyHostToDevice, g->st));
+        GPX_HIP(hipMemcpy2DAsync(C.p, (size_t)ldc * 8, Kxoxo, (size_t)m * 8, (size_t)m * 8, (size_t)m,
+                                 hipMemcpyHostToDevice, g->st));
+    } else {
+        for (int64_t r = 0; r < m; ++r) {
+            GPX_TRY(upload_f64(g->dtype, (float *)X.p + r * ldx, Kxox + r * n, n, g->st));
+            GPX_TRY(upload_f64(g->dtype, (float *)C.p + r * ldc, Kxoxo + r * m, m, g->st));
+        }
+    }
+    GPX_TRY(trsm_right_lt(g->dtype, g->A, n, g->lda, X.p, m, ldx, g->st));
+    GPX_TRY(gemm_nt(g->dtype, m, m, n, X.p, ldx, X.p, ldx, C.p, ldc, -1.0, GPX_FULL, 0, 0, g->st));
+    return download_f64(g->dtype, out, m, C.p, ldc, m, m, 0, g->st);
+}
+
+int gpx_gp_get_Kxx(gpx_gp_t *g, double *out, int64_t ld)
+{
+    GPX_ARG(g && g->have_data && g->have_params && out && ld >= g->n, "bad arguments");
+    const size_t es = esize(g->dtype);
+    DevBuf K;
+    GPX_TRY(K.alloc((size_t)g->n * g->lda * es));
+    GPX_TRY(kmat(g->dtype, g->kernel, GPX_K, g->x, g->n, g->x, g->n, g->d, g->params, g->s * g->s,
+                 GPX_FULL, K.p, g->lda, g->st));
+    return download_f64(g->dtype, out, ld, K.p, g->lda, g->n, g->n, 0, g->st);
+}
+
+int gpx_gp_get_Lxx(gpx_gp_t *g, double *out, int64_t ld)
+{
+    GPX_ARG(g && g->fitted && out && ld >= g->n, "bad arguments");
+    return download_f64(g->dtype, out, ld, g->A, g->lda, g->n, g->n, 1, g->st);
+}
+
+int gpx_gp_get_alpha(gpx_gp_t *g, double *out)
+{
+    GPX_ARG(g && g->fitted && out, "bad arguments");
+    return download_f64(g->dtype, out, 1, g->alpha, 1, g->n, 1, 0, g->st);
+}
+
+int gpx_gp_get_inv_Kxx(gpx_gp_t *g, double *out, int64_t ld)
+{
+    GPX_ARG(g && g->fitted && out && ld >= g->n, "bad arguments");
+    const size_t es = esize(g->dtype);
+    const int64_t n = g->n, lda = g->lda;
+    DevBuf X, C;
+    GPX_TRY(X.alloc((size_t)n * lda * es));
+    GPX_TRY(C.alloc((size_t)n * lda * es));
+    dim3 grid((unsigned)cdiv(lda, 256), (unsigned)std::min<int64_t>(n, 32768)), block(256);
+    if (g->dtype == GPX_F64) hipLaunchKernelGGL((eye_kernel<double>), grid, block, 0, g->st, (double *)X.p, n, lda);
+    else hipLaunchKernelGGL((eye_kernel<float>), grid, block, 0, g->st, (float *)X.p, n, lda);
+    GPX_LAUNCH_CHECK();
+    GPX_HIP(hipMemsetAsync(C.p, 0, (size_t)n * lda * es, g->st));
+    // X = I L^-T = L^-T ; K^-1 = L^-T L^-1 = X X^T   (gp/gp.py:311-312)
+    GPX_TRY(trsm_right_lt(g->dtype, g->A, n, lda, X.p, n, lda, g->st));
+    GPX_TRY(gemm_nt(g->dtype, n, n, n, X.p, lda, X.p, lda, C.p, lda, 1.0, GPX_FULL, 0, 0, g->st));
+    return download_f64(g->dtype, out, ld, C.p, lda, n, n, 0, g->st);
+}
+
+int gpx_gp_last_timing(gpx_gp_t *g, float *ms5)
+{
+    GPX_ARG(g && g->fitted && ms5, "bad arguments");
+    GPX_HIP(hipEventSynchronize(g->ev[4]));
+    for (int i = 0; i < 4; ++i) GPX_HIP(hipEventElapsedTime(&ms5[i], g->ev[i], g->ev[i + 1]));
+    GPX_HIP(hipEventElapsedTime(&ms5[4], g->ev[0], g->ev[4]));
+    return GPX_OK;
+}
+
+int gpx_gp_device_ptrs(gpx_gp_t *g, void **A, int64_t *lda, void **x, void **y, void **alpha,
+                       void **stream)
+{
+    GPX_ARG(g, "gp is NULL");
+    if (A) *A = g->A;
+    if (lda) *lda = g->lda;
+    if (x) *x = g->x;
+    if (y) *y = g->y;
+    if (alpha) *alpha = g->alpha;
+    if (stream) *stream = (void *)g->st;
+    return GPX_OK;
+}
+
+// ----------------------------------------------- host-pointer drop-ins --
+int gpx_kmat_host(int kernel, int member, double *out, const double *x1, int64_t n, const double *x2,
+                  int64_t m, int d, const double *params, double diag_add)
+{
+    GPX_TRY(ensure_device());
+    GPX_ARG(n >= 0 && m >= 0 && d >= 1, "bad dimensions");
+    if (n == 0 || m == 0) return GPX_OK;
+    GPX_ARG(out && x1 && x2 && params, "NULL pointer");
+    const int64_t ld = round_up(m, 16);
+    DevBuf a, b, o;
+    GPX_TRY(a.alloc((size_t)n * d * 8));
+    GPX_TRY(o.alloc((size_t)n * ld * 8));
+    GPX_HIP(hipMemcpy(a.p, x1, (size_t)n * d * 8, hipMemcpyHostToDevice));
+    const void *bp = a.p;
+    if (!(x2 == x1 && m == n)) {
+        GPX_TRY(b.alloc((size_t)m * d * 8));
+        GPX_HIP(hipMemcpy(b.p, x2, (size_t)m * d * 8, hipMemcpyHostToDevice));
+        bp = b.p;
+    }
+    GPX_TRY(gpx_d_kmat(GPX_F64, kernel, member, a.p, n, bp, m, d, params, diag_add, GPX_FULL, o.p, ld,
+                       nullptr));
+    GPX_HIP(hipMemcpy2D(out, (size_t)m * 8, o.p, (size_t)ld * 8, (size_t)m * 8, (size_t)n,
+                        hipMemcpyDeviceToHost));
+    return GPX_OK;
+}
+
+int gpx_gaussian_c(int member, double *out, const double *x1, int64_t n, const double *x2, int64_t m,
+                   double h, double w)
+{
+    const double p[2] = {h, w};
+    return gpx_kmat_host(GPX_KERNEL_GAUSSIAN, member, out, x1, n, x2, m, 1, p, 0.0);
+}
+
+int gpx_gaussian_c_jacobian(double *out, const double *x1, int64_t n, const double *x2, int64_t m,
+                            double h, double w)
+{
+    // gaussian_c.pyx:39-41
+    GPX_TRY(gpx_gaussian_c(GPX_DK_DH, out, x1, n, x2, m, h, w));
+    return gpx_gaussian_c(GPX_DK_DW, out + n * m, x1, n, x2, m, h, w);
+}
+
+int gpx_gaussian_c_hessian(double *out, const double *x1, int64_t n, const double *x2, int64_t m,
+                           double h, double w)
+{
+    // gaussian_c.pyx:44-48
+    const int mem[4] = {GPX_D2K_DHDH, GPX_D2K_DHDW, GPX_D2K_DHDW, GPX_D2K_DWDW};
+    for (int i = 0; i < 4; ++i) GPX_TRY(gpx_gaussian_c(mem[i], out + (int64_t)i * n * m, x1, n, x2, m, h, w));
+    return GPX_OK;
+}
+
+int gpx_periodic_c(int member, double *out, const double *x1, int64_t n, const double *x2, int64_t m,
+                   double h, double w, double p)
+{
+    const double prm[3] = {h, w, p};
+    return gpx_kmat_host(GPX_KERNEL_PERIODIC, member, out, x1, n, x2, m, 1, prm, 0.0);
+}
+
+int gpx_periodic_c_jacobian(double *out, const double *x1, int64_t n, const double *x2, int64_t m,
+                            double h, double w, double p)
+{
+    // periodic_c.pyx:33-36
+    const int mem[3] = {GPX_DK_DH, GPX_DK_DW, GPX_DK_DP};
+    for (int i = 0; i < 3; ++i) GPX_TRY(gpx_periodic_c(mem[i], out + (int64_t)i * n * m, x1, n, x2, m, h, w, p));
+    return GPX_OK;
+}
+
+int gpx_periodic_c_hessian(double *out, const double *x1, int64_t n, const double *x2, int64_t m,
+                           double h, double w, double p)
+{
+    // periodic_c.pyx:39-50
+    const int mem[9] = {GPX_D2K_DHDH, GPX_D2K_DHDW, GPX_D2K_DHDP, GPX_D2K_DHDW, GPX_D2K_DWDW,
+                        GPX_D2K_DWDP, GPX_D2K_DHDP, GPX_D2K_DWDP, GPX_D2K_DPDP};
+    for (int i = 0; i < 9; ++i) GPX_TRY(gpx_periodic_c(mem[i], out + (int64_t)i * n * m, x1, n, x2, m, h, w, p));
+    return GPX_OK;
+}
+
+int gpx_gemm_nt_host(double *C, const double *A, const double *B, int64_t M, int64_t N, int64_t K)
+{
+    GPX_TRY(ensure_device());
+    GPX_ARG(M >= 0 && N >= 0 && K >= 0, "negative dimension");
+    if (M == 0 || N == 0) return GPX_OK;
+    GPX_ARG(C && (K == 0 || (A && B)), "NULL pointer");
+    const int64_t ldk = round_up(std::max<int64_t>(K, 1), 16), ldc = round_up(N, 16);
+    DevBuf a, b, c;
+    GPX_TRY(a.alloc((size_t)M * ldk * 8));
+    GPX_TRY(c.alloc((size_t)M * ldc * 8));
+    GPX_HIP(hipMemset(c.p, 0, (size_t)M * ldc * 8));
+    if (K > 0) {
+        GPX_HIP(hipMemcpy2D(a.p, (size_t)ldk * 8, A, (size_t)K * 8, (size_t)K * 8, (size_t)M, hipMemcpyHostToDevice));
+        const void *bp = a.p;
+        if (!(B == A && N == M)) {
+            GPX_TRY(b.alloc((size_t)N * ldk * 8));
+            GPX_HIP(hipMemcpy2D(b.p, (size_t)ldk * 8, B, (size_t)K * 8, (size_t)K * 8, (size_t)N, hipMemcpyHostToDevice));
+            bp = b.p;
+        }
+        GPX_TRY(gemm_nt(GPX_F64, M, N, K, a.p, ldk, bp, ldk, c.p, ldc, 1.0, GPX_FULL, 0, 0, nullptr));
+    }
+    GPX_HIP(hipMemcpy2D(C, (size_t)N * 8, c.p, (size_t)ldc * 8, (size_t)N * 8, (size_t)M, hipMemcpyDeviceToHost));
+    return GPX_OK;
+}
+
+int gpx_cholesky(double *L, const double *A, int64_t n, int *info)
+{
+    GPX_TRY(ensure_device());
+    GPX_ARG(n >= 0 && info, "bad arguments");
+    *info = 0;
+    if (n == 0) return GPX_OK;
+    GPX_ARG(L && A, "NULL pointer");
+    const int64_t lda = round_up(n, 16);
+    DevBuf a, inf;
+    GPX_TRY(a.alloc((size_t)n * lda * 8));
+    GPX_TRY(inf.alloc(sizeof(int)));
+    GPX_HIP(hipMemcpy2D(a.p, (size_t)lda * 8, A, (size_t)n * 8, (size_t)n * 8, (size_t)n, hipMemcpyHostToDevice));
+    GPX_TRY(potrf(GPX_F64, a.p, n, lda, (int *)inf.p, nullptr));
+    GPX_TRY(tril(GPX_F64, a.p, n, lda, nullptr));
+    GPX_HIP(hipMemcpy(info, inf.p, sizeof(int), hipMemcpyDeviceToHost));
+    GPX_HIP(hipMemcpy2D(L, (size_t)n * 8, a.p, (size_t)lda * 8, (size_t)n * 8, (size_t)n, hipMemcpyDeviceToHost));
+    return GPX_OK;
+}
+
+int gpx_cho_solve(const double *L, int64_t n, double *b)
+{
+    GPX_TRY(ensure_device());
+    GPX_ARG(n >= 0, "n < 0");
+    if (n == 0) return GPX_OK;
+    GPX_ARG(L && b, "NULL pointer");
+    const int64_t ldl = round_up(n, 16);
+    DevBuf l, v0, v1;
+    GPX_TRY(l.alloc((size_t)n * ldl * 8));
+    GPX_TRY(v0.alloc((size_t)n * 8));
+    GPX_TRY(v1.alloc((size_t)n * 8));
+    GPX_HIP(hipMemcpy2D(l.p, (size_t)ldl * 8, L, (size_t)n * 8, (size_t)n * 8, (size_t)n, hipMemcpyHostToDevice));
+    GPX_HIP(hipMemcpy(v0.p, b, (size_t)n * 8, hipMemcpyHostToDevice));
+    GPX_TRY(trsv_lower(GPX_F64, l.p, n, ldl, v0.p, v1.p, 0, nullptr));
+    GPX_TRY(trsv_lower(GPX_F64, l.p, n, ldl, v1.p, v0.p, 1, nullptr));
+    GPX_HIP(hipMemcpy(b, v0.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+    return GPX_OK;
+}
+
+int gpx_gp_c_log_lh(const double *y, const double *L, const double *Kiy, int64_t n, double *log_lh)
+{
+    GPX_TRY(ensure_device());
+    GPX_ARG(n >= 0 && log_lh, "bad arguments");
+    GPX_ARG(n == 0 || (y && L && Kiy), "NULL pointer");
+    double h[2] = {0.0, 0.0};
+    if (n > 0) {
+        // only the diagonal of L is needed: gather it on the host side of the copy
+        DevBuf dg, a, b, sc;
+        GPX_TRY(dg.alloc((size_t)n * 8));
+        GPX_TRY(a.alloc((size_t)n * 8));
+        GPX_TRY(b.alloc((size_t)n * 8));
+        GPX_TRY(sc.alloc(2 * sizeof(double)));
+        GPX_HIP(hipMemcpy2D(dg.p, 8, L, (size_t)(n + 1) * 8, 8, (size_t)n, hipMemcpyHostToDevice));
+        GPX_HIP(hipMemcpy(a.p, y, (size_t)n * 8, hipMemcpyHostToDevice));
+        GPX_HIP(hipMemcpy(b.p, Kiy, (size_t)n * 8, hipMemcpyHostToDevice));
+        GPX_TRY(logdet_chol(GPX_F64, dg.p, n, 0, (double *)sc.p, nullptr));   // stride = ldl + 1 = 1
+        GPX_TRY(dot(GPX_F64, a.p, b.p, n, (double *)sc.p + 1, nullptr));
+        GPX_HIP(hipMemcpy(h, sc.p, sizeof(h), hipMemcpyDeviceToHost));
+    }
+    const double logdet = h[0];
+    if (!(logdet >= GPX_MIN_LOG)) { *log_lh = -INFINITY; return GPX_OK; }        // gp_c.pyx:22-23
+    *log_lh = -0.5 * h[1] + -0.5 * logdet + -0.5 * (double)n * log(2 * M_PI);     // gp_c.pyx:26-29
+    return GPX_OK;
+}
+
+}  // extern "C"

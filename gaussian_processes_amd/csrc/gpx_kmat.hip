@@ -1,0 +1,412 @@
+// gpx_kmat.hip -- pairwise kernel-matrix build and fused posterior mean (gfx950).
+//
+// Replaces the O(n*m) double loops of gp/ext/gaussian_c.pyx:18-164 and
+// gp/ext/periodic_c.pyx:18-235 (one exp per entry, single CPU thread) and the
+// `K += eye(n) * s**2` temporaries of gp/gp.py:265.
+//
+// Roofline: HBM write bandwidth.  Algorithmic bytes per launch = n*m*sizeof(T)
+// written (+ (n+m)*d*sizeof(T) read, negligible).  One workgroup owns a
+// 64 x (64*VEC) output tile; both point sets of the tile are staged in LDS once,
+// every lane owns VEC consecutive columns so that a wave stores 1 KiB contiguous
+// per row (16 B per lane), and the squared distance is accumulated directly as
+// sum_k (a_k - b_k)^2 (never |a|^2+|b|^2-2ab: that loses the digits near r = 0
+// that the reference keeps).
+#include "gpx_common.h"
+
+namespace gpx {
+
+// ---------------------------------------------------------------------------
+// member constants, precomputed in f64 exactly as the reference spells them
+// gaussian (gaussian_c.pyx): c[0]=c1  c[1]=c2  c[2]=c3  c[3]=c4  c[4]=form
+// periodic (periodic_c.pyx): c[0]=h  c[1]=w  c[2]=p
+// ---------------------------------------------------------------------------
+int make_kparams(int kernel, int member, const double *params, double diag_add, KParams *out)
+{
+    memset(out, 0, sizeof(*out));
+    out->kernel = kernel;
+    out->member = member;
+    out->diag_add = diag_add;
+    if (!params) { set_error("params is NULL"); return GPX_ERR_ARG; }
+    if (kernel == GPX_KERNEL_GAUSSIAN) {
+        const double h = params[0], w = params[1];
+        const double S = sqrt(2.0 / M_PI);          // gaussian_c.pyx:14
+        const double h2 = h * h, w2 = w * w;
+        out->c[0] = -0.5 / w2;                      // c1
+        switch (member) {
+        case GPX_K:        out->c[1] = 0.5 * S * h2 / w; out->c[4] = 0; break;            // :28
+        case GPX_DK_DH:    out->c[1] = S * h / w; out->c[4] = 0; break;                   // :61
+        case GPX_DK_DW:    out->c[1] = 0.5 * S * h2 / w2;                                  // :82-83
+                           out->c[2] = 0.5 * S * h2 / pow(w, 4); out->c[4] = 1; break;
+        case GPX_D2K_DHDH: out->c[1] = S / w; out->c[4] = 0; break;                        // :105
+        case GPX_D2K_DHDW: out->c[1] = S * h / w2;                                          // :126-127
+                           out->c[2] = S * h / pow(w, 4); out->c[4] = 1; break;
+        case GPX_D2K_DWDW: out->c[1] = S * h2 / pow(w, 3);                                  // :153-155
+                           out->c[2] = 2.5 * S * h2 / pow(w, 5);
+                           out->c[3] = 0.5 * S * h2 / pow(w, 7); out->c[4] = 2; break;
+        default: set_error("gaussian kernel has no member %d", member); return GPX_ERR_ARG;
+        }
+    } else if (kernel == GPX_KERNEL_PERIODIC) {
+        if (member < GPX_K || member > GPX_D2K_DPDP) {
+            set_error("periodic kernel has no member %d", member);
+            return GPX_ERR_ARG;
+        }
+        out->c[0] = params[0];
+        out->c[1] = params[1];
+        out->c[2] = params[2];
+    } else {
+        set_error("unknown kernel family %d", kernel);
+        return GPX_ERR_ARG;
+    }
+    return GPX_OK;
+}
+
+template <typename T> struct Vec;
+template <> struct Vec<double> { static constexpr int N = 2; typedef double2 type; };
+template <> struct Vec<float>  { static constexpr int N = 4; typedef float4 type; };
+
+template <typename T> __device__ __forceinline__ T dev_exp(T x);
+template <> __device__ __forceinline__ double dev_exp<double>(double x) { return exp(x); }
+template <> __device__ __forceinline__ float  dev_exp<float>(float x)  { return expf(x); }
+
+// one kernel-matrix entry from the accumulated squared distance (gaussian) --
+// FORM 0: c2*exp(e)   1: exp(e)*(c3*d2 - c2)   2: exp(e)*(c4*d2^2 - c3*d2 + c2)
+// with the reference's underflow clamp  e < MIN -> 0  (gaussian_c.pyx:31-34)
+template <typename T, int FORM>
+__device__ __forceinline__ T gaussian_entry(T d2, T c1, T c2, T c3, T c4)
+{
+    const T e = c1 * d2;
+    T v;
+    if (FORM == 0)      v = c2 * dev_exp<T>(e);
+    else if (FORM == 1) v = dev_exp<T>(e) * (c3 * d2 - c2);
+    else                v = dev_exp<T>(e) * (c4 * (d2 * d2) - c3 * d2 + c2);
+    return (e < (T)GPX_MIN_LOG) ? (T)0 : v;
+}
+
+// periodic members for d == 1 (periodic_c.pyx), dd = x1[i] - x2[j]
+template <typename T>
+__device__ __forceinline__ T periodic_entry(int member, T dd, T h, T w, T p)
+{
+    const T h2 = h * h, w2 = w * w, p2 = p * p;
+    const T arg = (T)0.5 * dd / p;
+    const T sn = sin(arg), cs = cos(arg);
+    const T ex = dev_exp<T>((T)-2.0 * (sn * sn) / w2);
+    const T w3 = w2 * w, w4 = w2 * w2, p4 = p2 * p2;
+    switch (member) {
+    case GPX_K:        return h2 * ex;                                                    // :30
+    case GPX_DK_DH:    return (T)2.0 * h * ex;                                            // :65
+    case GPX_DK_DW:    return (T)4.0 * h2 * ex * (sn * sn) / w3;                          // :80
+    case GPX_DK_DP:    return (T)2.0 * dd * h2 * ex * sn * cs / (p2 * w2);                // :96
+    case GPX_D2K_DHDH: return (T)2.0 * ex;                                                // :111
+    case GPX_D2K_DHDW: return (T)8.0 * h * ex * (sn * sn) / w3;                           // :126
+    case GPX_D2K_DHDP: return (T)4.0 * dd * h * ex * sn * cs / (p2 * w2);                 // :142
+    case GPX_D2K_DWDW: return (T)-12.0 * h2 * ex * (sn * sn) / w4                         // :172
+                              + (T)16.0 * h2 * ex * (sn * sn) * (sn * sn) / (w4 * w2);
+    case GPX_D2K_DWDP: return (T)-4.0 * dd * h2 * ex * sn * cs / (p2 * w3)                // :188
+                              + (T)8.0 * dd * h2 * ex * (sn * sn * sn) * cs / (p2 * w3 * w2);
+    default:           return (dd * dd) * h2 * ex * (sn * sn) / (p4 * w2)                 // :235
+                              - (dd * dd) * h2 * ex * (cs * cs) / (p4 * w2)
+                              + (T)4.0 * (dd * dd) * h2 * ex * (sn * sn) * (cs * cs) / (p4 * w4)
+                              - (T)4.0 * dd * h2 * ex * sn * cs / (p2 * p * w2);
+    }
+}
+
+struct KP32 { float c[6]; };
+
+constexpr int KM_ROWS = 64;        // tile rows
+constexpr int KM_RB = 4;           // rows register-blocked per lane
+
+// MODE 0..2: gaussian FORM 0..2 ; MODE 3: periodic K, any d ; MODE 4: periodic member, d == 1
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void kmat_kernel(const T *__restrict__ x1, int64_t n,
+                                                   const T *__restrict__ x2, int64_t m, int d,
+                                                   KParams kp, int tri, int aligned,
+                                                   T *__restrict__ out, int64_t ld)
+{
+    constexpr int VEC = Vec<T>::N;
+    constexpr int TN = 64 * VEC;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *s1 = reinterpret_cast<T *>(smem_raw);          // [KM_ROWS][d]
+    T *s2 = s1 + (size_t)KM_ROWS * d;                 // [d][TN]   (transposed: lanes contiguous)
+
+    const int64_t row0 = (int64_t)blockIdx.y * KM_ROWS;
+    const int64_t col0 = (int64_t)blockIdx.x * TN;
+    if (tri == GPX_LOWER && col0 > row0 + KM_ROWS - 1) return;   // strictly above the diagonal
+
+    const int tid = threadIdx.x;
+    // stage the two point sets (coalesced: consecutive threads -> consecutive elements)
+    for (int idx = tid; idx < KM_ROWS * d; idx += 256) {
+        const int r = idx / d;
+        s1[idx] = (row0 + r < n) ? x1[(row0 + r) * d + (idx - r * d)] : (T)0;
+    }
+    for (int idx = tid; idx < TN * d; idx += 256) {
+        const int c = idx / d, k = idx - c * d;
+        s2[(size_t)k * TN + c] = (col0 + c < m) ? x2[(col0 + c) * d + k] : (T)0;
+    }
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int cbase = lane * VEC;
+    const T c1 = (T)kp.c[0], c2 = (T)kp.c[1], c3 = (T)kp.c[2], c4 = (T)kp.c[3];
+    const T dadd = (T)kp.diag_add;
+
+#pragma unroll 1
+    for (int rb = 0; rb < 16; rb += KM_RB) {
+        const int rloc = wave * 16 + rb;
+        T acc[KM_RB][VEC];
+#pragma unroll
+        for (int r = 0; r < KM_RB; ++r)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[r][v] = (T)0;
+
+        if (MODE == 4) {
+            // d == 1: acc holds the signed difference
+#pragma unroll
+            for (int r = 0; r < KM_RB; ++r)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) acc[r][v] = s1[rloc + r] - s2[cbase + v];
+        } else {
+            for (int k = 0; k < d; ++k) {
+                T b[VEC];
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) b[v] = s2[(size_t)k * TN + cbase + v];
+#pragma unroll
+                for (int r = 0; r < KM_RB; ++r) {
+                    const T a = s1[(rloc + r) * d + k];
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        if (MODE == 3) {
+                            const T sn = sin((T)0.5 * (a - b[v]) / (T)kp.c[2]);
+                            acc[r][v] = fma(sn, sn, acc[r][v]);
+                        } else {
+                            const T t = a - b[v];
+                            acc[r][v] = fma(t, t, acc[r][v]);
+                        }
+                    }
+                }
+            }
+        }
+
+#pragma unroll
+        for (int r = 0; r < KM_RB; ++r) {
+            const int64_t gi = row0 + rloc + r;
+            if (gi >= n) continue;
+            T val[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                T x;
+                if (MODE <= 2) {
+                    x = gaussian_entry<T, MODE>(acc[r][v], c1, c2, c3, c4);
+                } else if (MODE == 3) {
+                    const T h = (T)kp.c[0], w = (T)kp.c[1];
+                    x = (h * h) * dev_exp<T>((T)-2.0 * acc[r][v] / (w * w));
+                } else {
+                    x = periodic_entry<T>(kp.member, acc[r][v], (T)kp.c[0], (T)kp.c[1], (T)kp.c[2]);
+                }
+                if (gi == col0 + cbase + v) x += dadd;
+                val[v] = x;
+            }
+            T *dst = out + gi * ld + col0 + cbase;
+            if (aligned && col0 + cbase + VEC <= m) {
+                typename Vec<T>::type pk;
+                memcpy(&pk, val, sizeof(pk));
+                *reinterpret_cast<typename Vec<T>::type *>(dst) = pk;
+            } else {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v)
+                    if (col0 + cbase + v < m) dst[v] = val[v];
+            }
+        }
+    }
+}
+
+template <typename T>
+static int launch_kmat(const void *x1, int64_t n, const void *x2, int64_t m, int d,
+                       const KParams &kp, int tri, void *out, int64_t ld, hipStream_t st)
+{
+    constexpr int VEC = Vec<T>::N;
+    constexpr int TN = 64 * VEC;
+    int mode;
+    if (kp.kernel == GPX_KERNEL_GAUSSIAN) mode = (int)kp.c[4];
+    else mode = (kp.member == GPX_K) ? 3 : 4;
+    if (mode == 4 && d != 1) {
+        set_error("periodic derivative members need d == 1 (got %d)", d);
+        return GPX_ERR_UNSUPPORTED;
+    }
+    const size_t smem = ((size_t)KM_ROWS * d + (size_t)d * TN) * sizeof(T);
+    if (smem > 96 * 1024) {
+        set_error("kmat: d = %d too large for the LDS-staged tile (max 64 for f64)", d);
+        return GPX_ERR_UNSUPPORTED;
+    }
+    const int aligned = (ld % VEC == 0) && (((uintptr_t)out) % 16 == 0);
+    dim3 grid((unsigned)cdiv(m, TN), (unsigned)cdiv(n, KM_ROWS));
+    dim3 block(256);
+    const T *a = (const T *)x1;
+    const T *b = (const T *)x2;
+    T *o = (T *)out;
+#define GPX_KM_LAUNCH(MODE)                                                                   \
+    do {                                                                                      \
+        if (smem > 48 * 1024)                                                                 \
+            GPX_HIP(hipFuncSetAttribute((const void *)kmat_kernel<T, MODE>,                   \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        hipLaunchKernelGGL((kmat_kernel<T, MODE>), grid, block, smem, st, a, n, b, m, d, kp,  \
+                           tri, aligned, o, ld);                                              \
+    } while (0)
+    switch (mode) {
+    case 0: GPX_KM_LAUNCH(0); break;
+    case 1: GPX_KM_LAUNCH(1); break;
+    case 2: GPX_KM_LAUNCH(2); break;
+    case 3: GPX_KM_LAUNCH(3); break;
+    default: GPX_KM_LAUNCH(4); break;
+    }
+#undef GPX_KM_LAUNCH
+    GPX_LAUNCH_CHECK();
+    return GPX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// fused posterior mean: out[i] = sum_j K(xo[i], x[j]) * alpha[j]   (gp/gp.py:597)
+// One workgroup owns MP test points; the training set streams through LDS in
+// chunks of 256 points; sums are kept in f64 and reduced in a fixed order
+// (deterministic: no atomics).
+// ---------------------------------------------------------------------------
+constexpr int MP = 4;
+
+template <typename T, int KIND>
+__global__ __launch_bounds__(256) void mean_kernel(const T *__restrict__ xo, int64_t m,
+                                                   const T *__restrict__ x, int64_t n, int d,
+                                                   KParams kp, const T *__restrict__ alpha,
+                                                   T *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *sx = reinterpret_cast<T *>(smem_raw);            // [d][256] chunk of x, transposed
+    T *so = sx + (size_t)d * 256;                       // [MP][d] test points
+    __shared__ double red[4][MP];
+
+    const int tid = threadIdx.x;
+    const int64_t p0 = (int64_t)blockIdx.x * MP;
+    for (int idx = tid; idx < MP * d; idx += 256) {
+        const int pp = idx / d;
+        so[idx] = (p0 + pp < m) ? xo[(p0 + pp) * d + (idx - pp * d)] : (T)0;
+    }
+    double acc[MP];
+#pragma unroll
+    for (int pp = 0; pp < MP; ++pp) acc[pp] = 0.0;
+
+    const T c1 = (T)kp.c[0], c2 = (T)kp.c[1];
+    for (int64_t j0 = 0; j0 < n; j0 += 256) {
+        __syncthreads();
+        for (int idx = tid; idx < 256 * d; idx += 256) {
+            const int c = idx / d, k = idx - c * d;
+            sx[(size_t)k * 256 + c] = (j0 + c < n) ? x[(j0 + c) * d + k] : (T)0;
+        }
+        __syncthreads();
+        const int64_t j = j0 + tid;
+        if (j < n) {
+            const T aj = alpha[j];
+            T r[MP];
+#pragma unroll
+            for (int pp = 0; pp < MP; ++pp) r[pp] = (T)0;
+            for (int k = 0; k < d; ++k) {
+                const T b = sx[(size_t)k * 256 + tid];
+#pragma unroll
+                for (int pp = 0; pp < MP; ++pp) {
+                    if (KIND == GPX_KERNEL_GAUSSIAN) {
+                        const T t = so[pp * d + k] - b;
+                        r[pp] = fma(t, t, r[pp]);
+                    } else {
+                        const T sn = sin((T)0.5 * (so[pp * d + k] - b) / (T)kp.c[2]);
+                        r[pp] = fma(sn, sn, r[pp]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int pp = 0; pp < MP; ++pp) {
+                T kv;
+                if (KIND == GPX_KERNEL_GAUSSIAN) {
+                    kv = gaussian_entry<T, 0>(r[pp], c1, c2, (T)0, (T)0);
+                } else {
+                    const T h = (T)kp.c[0], w = (T)kp.c[1];
+                    kv = (h * h) * dev_exp<T>((T)-2.0 * r[pp] / (w * w));
+                }
+                acc[pp] += (double)kv * (double)aj;
+            }
+        }
+    }
+    // wave reduction (64 lanes), then across the 4 waves in a fixed order
+#pragma unroll
+    for (int pp = 0; pp < MP; ++pp) {
+        double v = acc[pp];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((tid & 63) == 0) red[tid >> 6][pp] = v;
+    }
+    __syncthreads();
+    if (tid < MP && p0 + tid < m) {
+        out[p0 + tid] = (T)(((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid]);
+    }
+}
+
+template <typename T>
+static int launch_mean(int kernel, const void *xo, int64_t m, const void *x, int64_t n, int d,
+                       const KParams &kp, const void *alpha, void *out, hipStream_t st)
+{
+    const size_t smem = ((size_t)d * 256 + (size_t)MP * d) * sizeof(T);
+    if (smem > 96 * 1024) {
+        set_error("mean: d = %d too large", d);
+        return GPX_ERR_UNSUPPORTED;
+    }
+    dim3 grid((unsigned)cdiv(m, MP)), block(256);
+    if (kernel == GPX_KERNEL_GAUSSIAN) {
+        if (smem > 48 * 1024)
+            GPX_HIP(hipFuncSetAttribute((const void *)mean_kernel<T, GPX_KERNEL_GAUSSIAN>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL((mean_kernel<T, GPX_KERNEL_GAUSSIAN>), grid, block, smem, st,
+                           (const T *)xo, m, (const T *)x, n, d, kp, (const T *)alpha, (T *)out);
+    } else {
+        if (smem > 48 * 1024)
+            GPX_HIP(hipFuncSetAttribute((const void *)mean_kernel<T, GPX_KERNEL_PERIODIC>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL((mean_kernel<T, GPX_KERNEL_PERIODIC>), grid, block, smem, st,
+                           (const T *)xo, m, (const T *)x, n, d, kp, (const T *)alpha, (T *)out);
+    }
+    GPX_LAUNCH_CHECK();
+    return GPX_OK;
+}
+
+}  // namespace gpx
+
+using namespace gpx;
+
+extern "C" {
+
+int gpx_d_kmat(int dtype, int kernel, int member, const void *x1, int64_t n, const void *x2,
+               int64_t m, int d, const double *params, double diag_add, int tri, void *out,
+               int64_t ld, void *stream)
+{
+    GPX_TRY(ensure_device());
+    GPX_ARG(dtype == GPX_F64 || dtype == GPX_F32, "dtype must be GPX_F64 or GPX_F32");
+    GPX_ARG(n >= 0 && m >= 0 && d >= 1, "need n, m >= 0 and d >= 1");
+    GPX_ARG(ld >= m, "ld < m");
+    GPX_ARG(tri == GPX_FULL || tri == GPX_LOWER, "tri must be GPX_FULL or GPX_LOWER");
+    if (n == 0 || m == 0) return GPX_OK;
+    GPX_ARG(x1 && x2 && out, "NULL pointer");
+    KParams kp;
+    GPX_TRY(make_kparams(kernel, member, params, diag_add, &kp));
+    if (dtype == GPX_F64) return launch_kmat<double>(x1, n, x2, m, d, kp, tri, out, ld, S(stream));
+    return launch_kmat<float>(x1, n, x2, m, d, kp, tri, out, ld, S(stream));
+}
+
+int gpx_d_mean(int dtype, int kernel, const void *xo, int64_t m, const void *x, int64_t n, int d,
+               const double *params, const void *alpha, void *out, void *stream)
+{
+    GPX_TRY(ensure_device());
+    GPX_ARG(dtype == GPX_F64 || dtype == GPX_F32, "dtype must be GPX_F64 or GPX_F32");
+    GPX_ARG(n >= 0 && m >= 0 && d >= 1, "need n, m >= 0 and d >= 1");
+    if (m == 0) return GPX_OK;
+    GPX_ARG(xo && out && (n == 0 || (x && alpha)), "NULL pointer");
+    KParams kp;
+    GPX_TRY(make_kparams(kernel, GPX_K, params, 0.0, &kp));
+    if (dtype == GPX_F64) return launch_mean<double>(kernel, xo, m, x, n, d, kp, alpha, out, S(stream));
+    return launch_mean<float>(kernel, xo, m, x, n, d, kp, alpha, out, S(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,235 @@
+// gpx_runtime.hip -- device / memory / stream / event plumbing of the C ABI.
+#include "gpx_common.h"
+#include <stdarg.h>
+
+namespace gpx {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char *what, const char *file, int line)
+{
+    set_error("HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+    if (e == hipErrorOutOfMemory) return GPX_ERR_NOMEM;
+    if (e == hipErrorNoDevice || e == hipErrorInvalidDevice) return GPX_ERR_NO_DEVICE;
+    return GPX_ERR_HIP;
+}
+
+int ensure_device()
+{
+    static thread_local int ok = 0;
+    if (ok) return GPX_OK;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        set_error("no usable HIP device (hipGetDeviceCount -> %d, count %d): libgpx has no CPU fallback",
+                  (int)e, n);
+        return GPX_ERR_NO_DEVICE;
+    }
+    ok = 1;
+    return GPX_OK;
+}
+
+}  // namespace gpx
+
+using namespace gpx;
+
+extern "C" {
+
+int gpx_version(void) { return GPX_VERSION; }
+
+const char *gpx_last_error(void) { return g_err; }
+
+int gpx_device_count(int *count)
+{
+    GPX_ARG(count, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    *count = n;
+    return GPX_OK;
+}
+
+int gpx_set_device(int device)
+{
+    GPX_TRY(ensure_device());
+    GPX_HIP(hipSetDevice(device));
+    return GPX_OK;
+}
+
+int gpx_get_device(int *device)
+{
+    GPX_ARG(device, "device is NULL");
+    GPX_TRY(ensure_device());
+    GPX_HIP(hipGetDevice(device));
+    return GPX_OK;
+}
+
+int gpx_device_info(int device, char *name, size_t name_len, int *cus, int *clock_mhz,
+                    uint64_t *hbm_bytes)
+{
+    GPX_TRY(ensure_device());
+    hipDeviceProp_t p;
+    GPX_HIP(hipGetDeviceProperties(&p, device));
+    if (name && name_len) {
+        snprintf(name, name_len, "%s (%s)", p.name, p.gcnArchName);
+    }
+    if (cus) *cus = p.multiProcessorCount;
+    if (clock_mhz) *clock_mhz = p.clockRate / 1000;
+    if (hbm_bytes) *hbm_bytes = (uint64_t)p.totalGlobalMem;
+    return GPX_OK;
+}
+
+int gpx_malloc(void **dptr, size_t bytes)
+{
+    GPX_ARG(dptr, "dptr is NULL");
+    GPX_TRY(ensure_device());
+    *dptr = nullptr;
+    if (bytes == 0) bytes = 16;
+    GPX_HIP(hipMalloc(dptr, bytes));
+    return GPX_OK;
+}
+
+int gpx_free(void *dptr)
+{
+    if (!dptr) return GPX_OK;
+    GPX_HIP(hipFree(dptr));
+    return GPX_OK;
+}
+
+int gpx_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream)
+{
+    GPX_TRY(ensure_device());
+    if (bytes == 0) return GPX_OK;
+    GPX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, S(stream)));
+    GPX_HIP(hipStreamSynchronize(S(stream)));
+    return GPX_OK;
+}
+
+int gpx_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream)
+{
+    GPX_TRY(ensure_device());
+    if (bytes == 0) return GPX_OK;
+    GPX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, S(stream)));
+    GPX_HIP(hipStreamSynchronize(S(stream)));
+    return GPX_OK;
+}
+
+int gpx_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream)
+{
+    GPX_TRY(ensure_device());
+    if (bytes == 0) return GPX_OK;
+    GPX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, S(stream)));
+    return GPX_OK;
+}
+
+int gpx_memcpy2d_h2d(void *dst, size_t dpitch, const void *src, size_t spitch,
+                     size_t row_bytes, size_t rows, void *stream)
+{
+    GPX_TRY(ensure_device());
+    if (row_bytes == 0 || rows == 0) return GPX_OK;
+    GPX_HIP(hipMemcpy2DAsync(dst, dpitch, src, spitch, row_bytes, rows, hipMemcpyHostToDevice, S(stream)));
+    GPX_HIP(hipStreamSynchronize(S(stream)));
+    return GPX_OK;
+}
+
+int gpx_memcpy2d_d2h(void *dst, size_t dpitch, const void *src, size_t spitch,
+                     size_t row_bytes, size_t rows, void *stream)
+{
+    GPX_TRY(ensure_device());
+    if (row_bytes == 0 || rows == 0) return GPX_OK;
+    GPX_HIP(hipMemcpy2DAsync(dst, dpitch, src, spitch, row_bytes, rows, hipMemcpyDeviceToHost, S(stream)));
+    GPX_HIP(hipStreamSynchronize(S(stream)));
+    return GPX_OK;
+}
+
+int gpx_memset(void *dst, int value, size_t bytes, void *stream)
+{
+    GPX_TRY(ensure_device());
+    if (bytes == 0) return GPX_OK;
+    GPX_HIP(hipMemsetAsync(dst, value, bytes, S(stream)));
+    return GPX_OK;
+}
+
+int gpx_stream_create(void **stream)
+{
+    GPX_ARG(stream, "stream is NULL");
+    GPX_TRY(ensure_device());
+    hipStream_t s;
+    GPX_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = (void *)s;
+    return GPX_OK;
+}
+
+int gpx_stream_destroy(void *stream)
+{
+    if (!stream) return GPX_OK;
+    GPX_HIP(hipStreamDestroy(S(stream)));
+    return GPX_OK;
+}
+
+int gpx_stream_sync(void *stream)
+{
+    GPX_TRY(ensure_device());
+    GPX_HIP(hipStreamSynchronize(S(stream)));
+    return GPX_OK;
+}
+
+int gpx_device_sync(void)
+{
+    GPX_TRY(ensure_device());
+    GPX_HIP(hipDeviceSynchronize());
+    return GPX_OK;
+}
+
+int gpx_event_create(void **event)
+{
+    GPX_ARG(event, "event is NULL");
+    GPX_TRY(ensure_device());
+    hipEvent_t e;
+    GPX_HIP(hipEventCreate(&e));
+    *event = (void *)e;
+    return GPX_OK;
+}
+
+int gpx_event_destroy(void *event)
+{
+    if (!event) return GPX_OK;
+    GPX_HIP(hipEventDestroy((hipEvent_t)event));
+    return GPX_OK;
+}
+
+int gpx_event_record(void *event, void *stream)
+{
+    GPX_HIP(hipEventRecord((hipEvent_t)event, S(stream)));
+    return GPX_OK;
+}
+
+int gpx_event_sync(void *event)
+{
+    GPX_HIP(hipEventSynchronize((hipEvent_t)event));
+    return GPX_OK;
+}
+
+int gpx_event_elapsed_ms(void *start, void *stop, float *ms)
+{
+    GPX_ARG(ms, "ms is NULL");
+    GPX_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return GPX_OK;
+}
+
+int gpx_stream_wait_event(void *stream, void *event)
+{
+    GPX_HIP(hipStreamWaitEvent(S(stream), (hipEvent_t)event, 0));
+    return GPX_OK;
+}
+
+}  // extern "C"

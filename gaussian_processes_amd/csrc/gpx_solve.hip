@@ -1,0 +1,258 @@
+// gpx_solve.hip -- triangular solves and O(n) reductions on the factor (gfx950).
+//
+// Replaces scipy.linalg.cho_solve((L, True), y) of gp/gp.py:332-334 (LAPACK
+// dpotrs), np.linalg.slogdet(K) of gp/ext/gp_c.pyx:21 (a second, redundant LU in
+// the reference; here 2*sum(log diag L)), np.dot(y, Kiy) of gp_c.pyx:26, and the
+// explicit-inverse route to the posterior covariance (gp/gp.py:311-312,622-625).
+//
+// Roofline: HBM read bandwidth -- a single-right-hand-side solve reads the
+// lower triangle of L once per direction (n^2/2 * sizeof(T) bytes, 2 n^2 flop for
+// both directions together).  Each 64-wide block step is ONE launch: every
+// workgroup re-solves the 64 x 64 diagonal system in its first wave (register
+// resident, lane-broadcast substitution, no barriers) and then streams its own
+// slice of the panel below (forward) / to the left (backward) in coalesced rows.
+#include "gpx_common.h"
+
+namespace gpx {
+
+constexpr int SB = 64;
+constexpr int SBP = SB + 1;
+
+template <typename T>
+__device__ __forceinline__ void load_diag_block(T *sL, T *sRinv, const T *__restrict__ L, int64_t ldl,
+                                                int64_t k0, int jb, int tid)
+{
+    const T *blk = L + k0 * ldl + k0;
+    for (int idx = tid; idx < jb * SB; idx += 256) {
+        const int i = idx >> 6, c = idx & 63;
+        sL[i * SBP + c] = (c <= i && c < jb) ? blk[(int64_t)i * ldl + c] : (T)0;
+    }
+    if (tid < SB) sRinv[tid] = (tid < jb) ? (T)1 / blk[(int64_t)tid * ldl + tid] : (T)0;
+}
+
+// forward: solves L[k0:k0+jb, k0:k0+jb] z = b[k0:k0+jb], writes x[k0:k0+jb] = z and
+// b[r] -= L[r, k0:k0+jb] . z for all r >= k0 + jb.
+template <typename T>
+__global__ __launch_bounds__(256) void trsv_fwd_step(const T *__restrict__ L, int64_t ldl,
+                                                     T *__restrict__ b, T *__restrict__ x, int64_t k0,
+                                                     int jb, int64_t n)
+{
+    __shared__ T sL[SB * SBP];
+    __shared__ T sTile[SB * SBP];
+    __shared__ T sz[SB];
+    __shared__ T sRinv[SB];
+    const int tid = threadIdx.x;
+    load_diag_block<T>(sL, sRinv, L, ldl, k0, jb, tid);
+    // this workgroup's slice of the panel below: 64 rows x jb columns, coalesced along the row
+    const int64_t r0 = k0 + jb + (int64_t)blockIdx.x * SB;
+    for (int idx = tid; idx < SB * SB; idx += 256) {
+        const int i = idx >> 6, c = idx & 63;
+        sTile[i * SBP + c] = (r0 + i < n && c < jb) ? L[(r0 + i) * ldl + k0 + c] : (T)0;
+    }
+    __syncthreads();
+    if (tid < SB) {
+        T v = (tid < jb) ? b[k0 + tid] : (T)0;
+        for (int j = 0; j < jb; ++j) {
+            const T zj = __shfl(v, j, 64) * sRinv[j];
+            if (tid == j) v = zj;
+            else if (tid > j) v = fma(-sL[tid * SBP + j], zj, v);
+        }
+        sz[tid] = v;
+        if (blockIdx.x == 0 && tid < jb) x[k0 + tid] = v;
+    }
+    __syncthreads();
+    // 4 lanes per row, 16 columns each
+    const int row = tid >> 2, part = tid & 3;
+    T acc = (T)0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc = fma(sTile[row * SBP + part * 16 + c], sz[part * 16 + c], acc);
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    if (part == 0 && r0 + row < n) b[r0 + row] -= acc;
+}
+
+// backward: solves L[k0:k0+jb, k0:k0+jb]^T a = b[k0:k0+jb], writes x[k0:k0+jb] = a and
+// b[c] -= sum_i L[k0+i, c] * a_i for all c < k0.
+template <typename T>
+__global__ __launch_bounds__(256) void trsv_bwd_step(const T *__restrict__ L, int64_t ldl,
+                                                     T *__restrict__ b, T *__restrict__ x, int64_t k0,
+                                                     int jb)
+{
+    __shared__ T sL[SB * SBP];
+    __shared__ T sz[SB];
+    __shared__ T sRinv[SB];
+    const int tid = threadIdx.x;
+    load_diag_block<T>(sL, sRinv, L, ldl, k0, jb, tid);
+    __syncthreads();
+    if (tid < SB) {
+        T v = (tid < jb) ? b[k0 + tid] : (T)0;
+        for (int j = jb - 1; j >= 0; --j) {
+            const T aj = __shfl(v, j, 64) * sRinv[j];
+            if (tid == j) v = aj;
+            else if (tid < j) v = fma(-sL[j * SBP + tid], aj, v);
+        }
+        sz[tid] = v;
+        if (blockIdx.x == 0 && tid < jb) x[k0 + tid] = v;
+    }
+    __syncthreads();
+    const int64_t c = (int64_t)blockIdx.x * 256 + tid;
+    if (c < k0) {
+        const T *col = L + k0 * ldl + c;
+        T acc = (T)0;
+#pragma unroll 8
+        for (int i = 0; i < jb; ++i) acc = fma(col[(int64_t)i * ldl], sz[i], acc);
+        b[c] -= acc;
+    }
+}
+
+template <typename T>
+static int trsv_t(const T *L, int64_t n, int64_t ldl, T *b, T *x, int transpose, hipStream_t st)
+{
+    if (!transpose) {
+        for (int64_t k0 = 0; k0 < n; k0 += SB) {
+            const int jb = (int)std::min<int64_t>(SB, n - k0);
+            const int64_t below = n - k0 - jb;
+            dim3 grid((unsigned)std::max<int64_t>(1, cdiv(below, SB))), block(256);
+            hipLaunchKernelGGL((trsv_fwd_step<T>), grid, block, 0, st, L, ldl, b, x, k0, jb, n);
+        }
+    } else {
+        const int64_t nblk = cdiv(n, SB);
+        for (int64_t kb = nblk - 1; kb >= 0; --kb) {
+            const int64_t k0 = kb * SB;
+            const int jb = (int)std::min<int64_t>(SB, n - k0);
+            dim3 grid((unsigned)std::max<int64_t>(1, cdiv(k0, 256))), block(256);
+            hipLaunchKernelGGL((trsv_bwd_step<T>), grid, block, 0, st, L, ldl, b, x, k0, jb);
+        }
+    }
+    GPX_LAUNCH_CHECK();
+    return GPX_OK;
+}
+
+int trsv_lower(int dtype, const void *L, int64_t n, int64_t ldl, void *b, void *x, int transpose,
+               hipStream_t st)
+{
+    if (n <= 0) return GPX_OK;
+    if (dtype == GPX_F64) return trsv_t<double>((const double *)L, n, ldl, (double *)b, (double *)x, transpose, st);
+    return trsv_t<float>((const float *)L, n, ldl, (float *)b, (float *)x, transpose, st);
+}
+
+// X (m x n) <- X * L^-T, blocked: level-3 updates on the MFMA gemm_nt, 64-wide
+// substitutions by trsm_rows (shared with the Cholesky panel).
+int trsm_right_lt(int dtype, const void *L, int64_t n, int64_t ldl, void *X, int64_t m, int64_t ldx,
+                  hipStream_t st)
+{
+    if (n <= 0 || m <= 0) return GPX_OK;
+    const size_t es = esize(dtype);
+    const int64_t NB = 256;
+    auto Lp = [&](int64_t r, int64_t c) { return (const char *)L + (r * ldl + c) * es; };
+    auto Xp = [&](int64_t c) { return (char *)X + c * es; };
+    for (int64_t k0 = 0; k0 < n; k0 += NB) {
+        const int64_t kb = std::min(NB, n - k0);
+        if (k0 > 0)
+            GPX_TRY(gemm_nt(dtype, m, kb, k0, X, ldx, Lp(k0, 0), ldl, Xp(k0), ldx, -1.0, GPX_FULL, 0, 0, st));
+        for (int64_t j0 = k0; j0 < k0 + kb; j0 += SB) {
+            const int jb = (int)std::min<int64_t>(SB, k0 + kb - j0);
+            if (j0 > k0)
+                GPX_TRY(gemm_nt(dtype, m, jb, j0 - k0, Xp(k0), ldx, Lp(j0, k0), ldl, Xp(j0), ldx, -1.0,
+                                GPX_FULL, 0, 0, st));
+            GPX_TRY(trsm_rows(dtype, Xp(j0), ldx, m, Lp(j0, j0), ldl, jb, st));
+        }
+    }
+    return GPX_OK;
+}
+
+// ---- reductions (single workgroup, fixed order => deterministic) ----------
+template <typename T, int MODE>   // MODE 0: sum a[i]*b[i]   1: 2*sum log a[i*stride]
+__global__ __launch_bounds__(1024) void reduce_kernel(const T *__restrict__ a, const T *__restrict__ b,
+                                                      int64_t n, int64_t stride, double *__restrict__ out)
+{
+    __shared__ double red[16];
+    const int tid = threadIdx.x;
+    double acc = 0.0;
+    for (int64_t i = tid; i < n; i += 1024) {
+        if (MODE == 0) acc = fma((double)a[i], (double)b[i], acc);
+        else acc += log((double)a[i * stride]);
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        double s = 0.0;
+        for (int w = 0; w < 16; ++w) s += red[w];
+        out[0] = (MODE == 0) ? s : 2.0 * s;
+    }
+}
+
+int logdet_chol(int dtype, const void *L, int64_t n, int64_t ldl, double *out_dev, hipStream_t st)
+{
+    if (dtype == GPX_F64)
+        hipLaunchKernelGGL((reduce_kernel<double, 1>), dim3(1), dim3(1024), 0, st, (const double *)L,
+                           (const double *)nullptr, n, ldl + 1, out_dev);
+    else
+        hipLaunchKernelGGL((reduce_kernel<float, 1>), dim3(1), dim3(1024), 0, st, (const float *)L,
+                           (const float *)nullptr, n, ldl + 1, out_dev);
+    GPX_LAUNCH_CHECK();
+    return GPX_OK;
+}
+
+int dot(int dtype, const void *a, const void *b, int64_t n, double *out_dev, hipStream_t st)
+{
+    if (dtype == GPX_F64)
+        hipLaunchKernelGGL((reduce_kernel<double, 0>), dim3(1), dim3(1024), 0, st, (const double *)a,
+                           (const double *)b, n, 1, out_dev);
+    else
+        hipLaunchKernelGGL((reduce_kernel<float, 0>), dim3(1), dim3(1024), 0, st, (const float *)a,
+                           (const float *)b, n, 1, out_dev);
+    GPX_LAUNCH_CHECK();
+    return GPX_OK;
+}
+
+}  // namespace gpx
+
+using namespace gpx;
+
+extern "C" {
+
+int gpx_d_trsv_lower(int dtype, const void *L, int64_t n, int64_t ldl, void *b, void *x,
+                     int transpose, void *stream)
+{
+    GPX_TRY(ensure_device());
+    GPX_ARG(dtype == GPX_F64 || dtype == GPX_F32, "dtype must be GPX_F64 or GPX_F32");
+    GPX_ARG(n >= 0, "n < 0");
+    if (n == 0) return GPX_OK;
+    GPX_ARG(L && b && x && b != x, "NULL pointer or b == x");
+    GPX_ARG(ldl >= n, "ldl < n");
+    return trsv_lower(dtype, L, n, ldl, b, x, transpose, S(stream));
+}
+
+int gpx_d_trsm_right_lt(int dtype, const void *L, int64_t n, int64_t ldl, void *X, int64_t m,
+                        int64_t ldx, void *stream)
+{
+    GPX_TRY(ensure_device());
+    GPX_ARG(dtype == GPX_F64 || dtype == GPX_F32, "dtype must be GPX_F64 or GPX_F32");
+    GPX_ARG(n >= 0 && m >= 0, "negative dimension");
+    if (n == 0 || m == 0) return GPX_OK;
+    GPX_ARG(L && X, "NULL pointer");
+    GPX_ARG(ldl >= n && ldx >= n, "leading dimension too small");
+    GPX_ARG(ldl % 16 == 0 && ldx % 16 == 0, "ldl/ldx must be multiples of 16 elements");
+    GPX_ARG(((uintptr_t)L) % 16 == 0 && ((uintptr_t)X) % 16 == 0, "L/X must be 16-byte aligned");
+    return trsm_right_lt(dtype, L, n, ldl, X, m, ldx, S(stream));
+}
+
+int gpx_d_logdet_chol(int dtype, const void *L, int64_t n, int64_t ldl, double *out_dev, void *stream)
+{
+    GPX_TRY(ensure_device());
+    GPX_ARG(dtype == GPX_F64 || dtype == GPX_F32, "dtype must be GPX_F64 or GPX_F32");
+    GPX_ARG(n >= 0 && out_dev && (n == 0 || L), "bad arguments");
+    return logdet_chol(dtype, L, n, ldl, out_dev, S(stream));
+}
+
+int gpx_d_dot(int dtype, const void *a, const void *b, int64_t n, double *out_dev, void *stream)
+{
+    GPX_TRY(ensure_device());
+    GPX_ARG(dtype == GPX_F64 || dtype == GPX_F32, "dtype must be GPX_F64 or GPX_F32");
+    GPX_ARG(n >= 0 && out_dev && (n == 0 || (a && b)), "bad arguments");
+    return dot(dtype, a, b, n, out_dev, S(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,267 @@
+/*
+ * gpx.h -- C ABI of libgpx.so: the MI355X (gfx950) GP regression core.
+ *
+ * This is the drop-in boundary for the GP fit/predict hot path of
+ * jhamrick/gaussian_processes.  Every entry point names the reference interface
+ * it replaces (paths relative to the reference tree):
+ *
+ *   gp/ext/gaussian_c.pyx   K, jacobian, hessian, dK_*, d2K_*      (Cython -> C)
+ *   gp/ext/periodic_c.pyx   K, jacobian, hessian, dK_*, d2K_*
+ *   gp/ext/gp_c.pyx         log_lh
+ *   gp/gp.py:294            scipy.linalg.cholesky(Kxx, lower=True)     (LAPACK dpotrf)
+ *   gp/gp.py:332-334        scipy.linalg.cho_solve((L, True), y)       (LAPACK dpotrs)
+ *   gp/gp.py:311-312        inv(L).T @ inv(L)
+ *   gp/gp.py:597, 622-625   posterior mean / covariance
+ *
+ * Conventions
+ *   - plain C: pointers, sizes, scalars.  No torch / numpy types.
+ *   - all matrices are ROW-MAJOR (numpy C order, as the reference's
+ *     np.ndarray[float64, mode='c']); `ld` = elements between consecutive rows.
+ *   - every function returns an int status: GPX_OK (0) or a negative GPX_ERR_*;
+ *     gpx_last_error() gives the message (thread-local).  Factorisations report
+ *     LAPACK-style `info` (> 0: that leading minor is not positive definite)
+ *     through an out-parameter, not through the status.
+ *   - "device" entry points (gpx_d_*) take DEVICE pointers and a hipStream_t
+ *     passed as void* (NULL = the null stream); they enqueue work and return.
+ *     Device matrices must have ld % 16 == 0 and 16-byte aligned bases.
+ *   - "host" entry points (gpx_gaussian_c_*, gpx_periodic_c_*, gpx_gp_c_*,
+ *     gpx_cholesky, gpx_cho_solve ...) take HOST pointers with the reference's
+ *     exact argument meaning, run on the current device and return when the
+ *     result is in the caller's buffer.
+ *   - no CPU fallback exists: without a usable GPU every compute entry point
+ *     returns GPX_ERR_NO_DEVICE.
+ */
+#ifndef GPX_H
+#define GPX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPX_VERSION 100
+
+/* status codes */
+#define GPX_OK              0
+#define GPX_ERR_ARG        -1   /* bad argument (maps to ValueError)              */
+#define GPX_ERR_HIP        -2   /* HIP runtime failure (maps to RuntimeError)     */
+#define GPX_ERR_NO_DEVICE  -3   /* no usable GPU                                  */
+#define GPX_ERR_NOMEM      -4   /* device allocation failed                       */
+#define GPX_ERR_UNSUPPORTED -5  /* combination not implemented                    */
+
+/* dtype */
+#define GPX_F64 0
+#define GPX_F32 1
+
+/* kernel families (gp/kernels/gaussian.py, gp/kernels/periodic.py) */
+#define GPX_KERNEL_GAUSSIAN 0   /* params = (h, w)    */
+#define GPX_KERNEL_PERIODIC 1   /* params = (h, w, p) */
+
+/* members of a kernel family: the function and its parameter derivatives.
+ * Gaussian: gaussian_c.pyx:18-164.  Periodic: periodic_c.pyx:18-235. */
+#define GPX_K          0
+#define GPX_DK_DH      1
+#define GPX_DK_DW      2
+#define GPX_DK_DP      3   /* periodic only */
+#define GPX_D2K_DHDH   4
+#define GPX_D2K_DHDW   5   /* == d2K_dwdh */
+#define GPX_D2K_DHDP   6   /* periodic only; == d2K_dpdh */
+#define GPX_D2K_DWDW   7
+#define GPX_D2K_DWDP   8   /* periodic only; == d2K_dpdw */
+#define GPX_D2K_DPDP   9   /* periodic only */
+
+/* triangle selector for symmetric builds */
+#define GPX_FULL  0
+#define GPX_LOWER 1   /* only tiles touching the lower triangle are written */
+
+/* MIN = log(2^-1018): gp/gp.py:17, gaussian_c.pyx:15, gp_c.pyx:14 */
+#define GPX_MIN_LOG (-705.6238298100243)
+
+/* ---------------------------------------------------------------- runtime -- */
+int         gpx_version(void);
+const char *gpx_last_error(void);
+int gpx_device_count(int *count);
+int gpx_set_device(int device);
+int gpx_get_device(int *device);
+/* name: caller buffer; cus / clock_mhz / hbm_bytes may be NULL */
+int gpx_device_info(int device, char *name, size_t name_len, int *cus,
+                    int *clock_mhz, uint64_t *hbm_bytes);
+
+int gpx_malloc(void **dptr, size_t bytes);
+int gpx_free(void *dptr);
+int gpx_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream);
+int gpx_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream);
+int gpx_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream);
+/* strided copies: `rows` rows of `row_bytes`, pitches in bytes */
+int gpx_memcpy2d_h2d(void *dst, size_t dpitch, const void *src, size_t spitch,
+                     size_t row_bytes, size_t rows, void *stream);
+int gpx_memcpy2d_d2h(void *dst, size_t dpitch, const void *src, size_t spitch,
+                     size_t row_bytes, size_t rows, void *stream);
+int gpx_memset(void *dst, int value, size_t bytes, void *stream);
+
+int gpx_stream_create(void **stream);
+int gpx_stream_destroy(void *stream);
+int gpx_stream_sync(void *stream);
+int gpx_device_sync(void);
+int gpx_event_create(void **event);
+int gpx_event_destroy(void *event);
+int gpx_event_record(void *event, void *stream);
+int gpx_event_sync(void *event);
+int gpx_event_elapsed_ms(void *start, void *stop, float *ms);
+int gpx_stream_wait_event(void *stream, void *event);
+
+/* ------------------------------------------------- device-level hot path -- */
+
+/* Kernel-matrix build: out[i, j] = member(x1[i, :], x2[j, :]) (+ diag_add if i == j).
+ * Replaces gaussian_c.K / periodic_c.K (and the d*K members) plus the
+ * `K += eye(n) * s**2` of gp/gp.py:265 (diag_add = s*s, applied where i == j).
+ * x1: (n, d), x2: (m, d) row-major, densely packed; out: (n, m) with ld.
+ * params: HOST array (h, w[, p]) as doubles.  tri = GPX_LOWER skips tiles that
+ * lie strictly above the diagonal (only meaningful for x1 == x2).
+ * d > 1 (an extension: the reference is 1-D) uses r2 = sum_k (x1[i,k]-x2[j,k])^2;
+ * periodic members other than GPX_K require d == 1. */
+int gpx_d_kmat(int dtype, int kernel, int member, const void *x1, int64_t n,
+               const void *x2, int64_t m, int d, const double *params,
+               double diag_add, int tri, void *out, int64_t ld, void *stream);
+
+/* Fused posterior mean  out[i] = sum_j K(xo[i], x[j]) * alpha[j]   (gp/gp.py:597
+ * without materialising Kxox).  xo: (m, d), x: (n, d), alpha: (n,), out: (m,). */
+int gpx_d_mean(int dtype, int kernel, const void *xo, int64_t m, const void *x,
+               int64_t n, int d, const double *params, const void *alpha,
+               void *out, void *stream);
+
+/* C (M x N, ldc) += alpha * A (M x K, lda) * B (N x K, ldb)^T -- the MFMA work-horse.
+ * tri = GPX_LOWER: only tiles with some row >= col are touched and elements
+ * with col > row are left unchanged (SYRK form; requires M == N geometry with
+ * row/col origins equal).  row0/col0 shift the triangle test:
+ * element (i, j) is "lower" when row0 + i >= col0 + j. */
+int gpx_d_gemm_nt(int dtype, int64_t M, int64_t N, int64_t K, double alpha,
+                  const void *A, int64_t lda, const void *B, int64_t ldb, void *C,
+                  int64_t ldc, int tri, int64_t row0, int64_t col0, void *stream);
+
+/* Blocked right-looking Cholesky, lower, in place (replaces scipy.linalg.cholesky,
+ * gp/gp.py:294 -> LAPACK dpotrf).  Only the lower triangle of A is read; the
+ * strict upper triangle is left untouched (use gpx_d_tril to zero it).
+ * info_dev: DEVICE int; 0 on success, j (1-based) if the j-th leading minor is
+ * not positive definite (pivot <= 0 or NaN), as LAPACK reports it. */
+int gpx_d_potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev,
+                void *stream);
+
+/* Zero the strict upper triangle (scipy's cholesky returns a clean L). */
+int gpx_d_tril(int dtype, void *A, int64_t n, int64_t lda, void *stream);
+
+/* x <- L^-1 b (transpose = 0, forward) or x <- L^-T b (transpose = 1, backward),
+ * single right-hand side; b is used as scratch and destroyed, x != b.
+ * Forward then backward = cho_solve((L, True), b), gp/gp.py:332-334 (dpotrs). */
+int gpx_d_trsv_lower(int dtype, const void *L, int64_t n, int64_t ldl, void *b,
+                     void *x, int transpose, void *stream);
+
+/* X (m x n, ldx) <- X * L^-T  : rows of X are right-hand sides; i.e. solves
+ * L * x_row^T = b_row^T for every row.  With X = Kxox this yields V^T where
+ * V = L^-1 Kxxo, the factor of the posterior covariance (gp/gp.py:622-625). */
+int gpx_d_trsm_right_lt(int dtype, const void *L, int64_t n, int64_t ldl, void *X,
+                        int64_t m, int64_t ldx, void *stream);
+
+/* out_dev[0] = 2 * sum_i log L[i,i]  (f64 accumulation for both dtypes).
+ * Replaces the LU-based np.linalg.slogdet(K) of gp_c.pyx:21 given L. */
+int gpx_d_logdet_chol(int dtype, const void *L, int64_t n, int64_t ldl,
+                      double *out_dev, void *stream);
+
+/* out_dev[0] = sum_i a[i] * b[i]  (f64 accumulation).  np.dot(y, Kiy), gp_c.pyx:26 */
+int gpx_d_dot(int dtype, const void *a, const void *b, int64_t n, double *out_dev,
+              void *stream);
+
+/* ------------------------------------------------ fitted-GP device handle -- */
+/* One handle = one GP resident in HBM: x, y, the kernel matrix / its factor
+ * (in place), alpha = K^-1 y, logdet, y^T alpha.  Mirrors the memoised
+ * properties of gp.GP (gp/gp.py:242-396). */
+typedef struct gpx_gp gpx_gp_t;
+
+int gpx_gp_create(gpx_gp_t **gp, int dtype, int kernel, int64_t n, int d);
+int gpx_gp_destroy(gpx_gp_t *gp);
+/* x: (n, d) HOST float64; y: (n,) HOST float64 (converted to dtype on upload) */
+int gpx_gp_set_data(gpx_gp_t *gp, const double *x, const double *y);
+/* same, from DEVICE buffers already in the handle's dtype */
+int gpx_gp_set_data_device(gpx_gp_t *gp, const void *x_dev, const void *y_dev);
+/* params = (h, w[, p]); s = noise standard deviation (gp/gp.py:190-197) */
+int gpx_gp_set_params(gpx_gp_t *gp, const double *params, double s);
+/* Plugin kernels (any gp.kernels.Kernel subclass without a native id):
+ * the host evaluates its own K(x, x) + s^2 I (gp/gp.py:263-266) and hands the
+ * full (n, n) HOST float64 matrix over; gpx_gp_fit then skips the kernel build. */
+int gpx_gp_set_K(gpx_gp_t *gp, const double *Kxx, int64_t ld);
+/* kernel build (lower) -> potrf -> alpha -> logdet, y^T alpha.  Asynchronous on
+ * the handle's stream; *info (HOST, may be NULL) is filled after a sync only
+ * when non-NULL. */
+int gpx_gp_fit(gpx_gp_t *gp, int *info);
+/* log marginal likelihood with the reference's conventions (gp/gp.py:360-367,
+ * gp_c.pyx:17-31): -inf when the factorisation failed or logdet < MIN. */
+int gpx_gp_log_lh(gpx_gp_t *gp, double *log_lh);
+int gpx_gp_logdet(gpx_gp_t *gp, double *logdet);
+/* potrf info of the last fit (0 ok, j > 0: j-th leading minor not positive definite) */
+int gpx_gp_info(gpx_gp_t *gp, int *info);
+/* posterior mean at xo (m, d) HOST float64 -> out (m,) HOST float64 */
+int gpx_gp_mean(gpx_gp_t *gp, const double *xo, int64_t m, double *out);
+/* posterior covariance at xo -> out (m, m) HOST float64, via V = L^-1 Kxxo */
+int gpx_gp_cov(gpx_gp_t *gp, const double *xo, int64_t m, double *out);
+/* plugin-kernel forms: the caller supplies Kxox (m, n) [and Kxoxo (m, m)] as HOST
+ * float64; mean = Kxox alpha, cov = Kxoxo - (Kxox L^-T)(Kxox L^-T)^T on the device */
+int gpx_gp_mean_from_K(gpx_gp_t *gp, const double *Kxox, int64_t m, double *out);
+int gpx_gp_cov_from_K(gpx_gp_t *gp, const double *Kxox, const double *Kxoxo, int64_t m,
+                      double *out);
+/* copy-outs to HOST float64: Kxx is rebuilt (full, + s^2 I); L has zero upper */
+int gpx_gp_get_Kxx(gpx_gp_t *gp, double *out, int64_t ld);
+int gpx_gp_get_Lxx(gpx_gp_t *gp, double *out, int64_t ld);
+int gpx_gp_get_alpha(gpx_gp_t *gp, double *out);
+/* K^-1 = L^-T L^-1 (gp/gp.py:311-312) -> out (n, n) HOST float64 */
+int gpx_gp_get_inv_Kxx(gpx_gp_t *gp, double *out, int64_t ld);
+/* timing of the last fit, milliseconds per stage (HIP events on the handle's
+ * stream): [0] kernel build [1] potrf [2] solve [3] logdet+dot [4] total */
+int gpx_gp_last_timing(gpx_gp_t *gp, float *ms5);
+/* raw device views for tests / multi-GPU drivers (do not free) */
+int gpx_gp_device_ptrs(gpx_gp_t *gp, void **A, int64_t *lda, void **x, void **y,
+                       void **alpha, void **stream);
+
+/* ------------------------------------------ host-level drop-in entry points -- */
+/* gaussian_c.K(out, x1, x2, h, w) -- gaussian_c.pyx:18 ; and the derivative
+ * members through `member`.  out: (n, m) C-contiguous float64. */
+int gpx_gaussian_c(int member, double *out, const double *x1, int64_t n,
+                   const double *x2, int64_t m, double h, double w);
+/* gaussian_c.jacobian(out[2,n,m], ...) :39 ; gaussian_c.hessian(out[2,2,n,m], ...) :44 */
+int gpx_gaussian_c_jacobian(double *out, const double *x1, int64_t n,
+                            const double *x2, int64_t m, double h, double w);
+int gpx_gaussian_c_hessian(double *out, const double *x1, int64_t n,
+                           const double *x2, int64_t m, double h, double w);
+/* periodic_c.K(out, x1, x2, h, w, p) -- periodic_c.pyx:18 ; members as above */
+int gpx_periodic_c(int member, double *out, const double *x1, int64_t n,
+                   const double *x2, int64_t m, double h, double w, double p);
+int gpx_periodic_c_jacobian(double *out, const double *x1, int64_t n,
+                            const double *x2, int64_t m, double h, double w, double p);
+int gpx_periodic_c_hessian(double *out, const double *x1, int64_t n,
+                           const double *x2, int64_t m, double h, double w, double p);
+/* (n, d) generalisation of the two above (BASELINE configs use d = 8/16/32) */
+int gpx_kmat_host(int kernel, int member, double *out, const double *x1, int64_t n,
+                  const double *x2, int64_t m, int d, const double *params,
+                  double diag_add);
+
+/* scipy.linalg.cholesky(A, lower=True) -- gp/gp.py:294.  A, L: (n, n) row-major
+ * HOST float64 (may alias).  *info as LAPACK dpotrf. */
+int gpx_cholesky(double *L, const double *A, int64_t n, int *info);
+/* scipy.linalg.cho_solve((L, True), b) -- gp/gp.py:332-334.  b: (n,) in/out. */
+int gpx_cho_solve(const double *L, int64_t n, double *b);
+/* gp_c.log_lh(y, K, Kiy) -- gp_c.pyx:17-31.  Given L (not K): the logdet comes
+ * from diag(L) instead of the reference's second LU factorisation of K. */
+int gpx_gp_c_log_lh(const double *y, const double *L, const double *Kiy, int64_t n,
+                    double *log_lh);
+
+/* C (M, N) = A (M, K) * B (N, K)^T, all HOST float64 C-contiguous: the np.dot
+ * calls of the derivative glue (gp/ext/gp_c.pyx:43-48,61-66,89-110,127-131) on
+ * the fp64 matrix cores. */
+int gpx_gemm_nt_host(double *C, const double *A, const double *B, int64_t M, int64_t N,
+                     int64_t K);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPX_H */

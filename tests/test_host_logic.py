@@ -1,0 +1,171 @@
+"""CPU tests (no GPU needed): host-side logic of the drop-in classes, and that
+the C-ABI library loads and exports every symbol include/gpx.h declares.
+Mirrors gp/tests/test_gp.py:245-432 and gp/tests/test_kernels.py:13-26 where no
+device compute is involved."""
+import os
+import pickle
+import re
+from copy import copy, deepcopy
+
+import numpy as np
+import pytest
+
+import gaussian_processes_amd as gp
+from gaussian_processes_amd import _lib
+from conftest import ROOT
+
+
+def make_xy():
+    x = np.linspace(-2 * np.pi, 2 * np.pi, 16)
+    return x, np.sin(x)
+
+
+def make_gp():
+    x, y = make_xy()
+    return gp.GP(gp.GaussianKernel(1, 1), x, y, s=1)
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "gpx.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(gpx_[a-z0-9_A-Z]+)\s*\(", hdr))
+    declared.discard("gpx_gp")
+    assert len(declared) > 50
+    lib = _lib.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libgpx.so does not export %s" % name
+    assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
+    assert lib.gpx_version() == 100
+
+
+def test_no_cpu_fallback_without_gpu():
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is present")
+    k = gp.GaussianKernel(1, 1)
+    with pytest.raises(_lib.GpxError):
+        k(np.zeros(3), np.zeros(3))
+    with pytest.raises(_lib.GpxError):
+        make_gp().log_lh
+
+
+def test_product_path_never_imports_oracle():
+    pkg = os.path.join(ROOT, "gaussian_processes_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("the oracle's", ""), os.path.join(dirpath, f)
+
+
+@pytest.mark.parametrize("cls,good", [(gp.GaussianKernel, (0.7, 1.3)), (gp.PeriodicKernel, (0.7, 1.3, 2.0))])
+def test_kernel_params_and_validation(cls, good):
+    k = cls(*good)
+    assert (k.params == np.array(good)).all()
+    assert k.params.dtype == np.float64
+    k.params = good
+    assert (k.params == np.array(good)).all()
+    for i in range(len(good)):
+        bad = list(good)
+        bad[i] = 0
+        with pytest.raises(ValueError):
+            cls(*bad)
+        with pytest.raises(ValueError):
+            k.params = bad
+    with pytest.raises(ValueError):
+        k.set_param("nope", 1.0)
+    assert type(k.h) is np.float64
+
+
+def test_kernel_copy_pickle():
+    k1 = gp.GaussianKernel(0.3, 0.9)
+    for k2 in (k1.copy(), copy(k1), deepcopy(k1), pickle.loads(pickle.dumps(k1))):
+        assert k1.h == k2.h and k1.w == k2.w and k1 is not k2
+    k3 = deepcopy(k1)
+    assert k1.h is not k3.h
+    p1 = gp.PeriodicKernel(0.3, 0.9, 1.7)
+    p2 = pickle.loads(pickle.dumps(p1))
+    assert (p1.params == p2.params).all()
+
+
+def test_kernel_buffer_errors():
+    from gaussian_processes_amd.ext import gaussian_c
+    x = np.linspace(0, 1, 4)
+    out = np.empty((4, 4))
+    with pytest.raises(ValueError, match="dtype mismatch"):
+        gaussian_c.K(out, x.astype(np.float32), x, 1.0, 1.0)
+    with pytest.raises(ValueError, match="not C-contiguous"):
+        gaussian_c.K(np.empty((4, 8))[:, ::2], x, x, 1.0, 1.0)
+    with pytest.raises(ValueError, match="wrong number of dimensions"):
+        gaussian_c.K(out, x[:, None], x, 1.0, 1.0)
+    with pytest.raises(ValueError, match="shape"):
+        gaussian_c.K(np.empty((4, 5)), x, x, 1.0, 1.0)
+
+
+def test_gp_inputs_are_readonly_float64_copies():
+    x, y = make_xy()
+    g = gp.GP(gp.GaussianKernel(1, 1), x, y, s=1)
+    assert g.x.dtype == np.float64 and g.y.dtype == np.float64 and type(g.s) is np.float64
+    assert g.x is not x and not g.x.flags.writeable and not g.y.flags.writeable
+    assert g.params.dtype == np.float64 and (g.params == [1, 1, 1]).all()
+
+
+def test_set_y_shape_and_negative_s():
+    g = make_gp()
+    with pytest.raises(ValueError):
+        g.y = g.y.copy()[:, None]
+    x, y = make_xy()
+    with pytest.raises(ValueError):
+        gp.GP(gp.GaussianKernel(1, 1), x, y, s=-1)
+
+
+def test_reset_memoized_on_any_setter():
+    g = make_gp()
+    for prop, val in (("x", g.x.copy() + 1), ("y", g.y.copy() + 1), ("s", g.s + 1),
+                      ("params", g.params + 1)):
+        g._memoized["sentinel"] = 1
+        setattr(g, prop, val)
+        assert g._memoized == {}
+
+
+def test_memoprop_del():
+    g = make_gp()
+    g._memoized["Kxx"] = "cached"
+    assert g.Kxx == "cached"
+    del g.Kxx
+    assert "Kxx" not in g._memoized
+
+
+def test_set_params_and_unknown_name():
+    g = make_gp()
+    g.set_param("h", 1)
+    g.set_param("w", 0.2)
+    g.set_param("s", 0.01)
+    assert g.get_param("w") == 0.2 and g.get_param("s") == 0.01
+    with pytest.raises(AttributeError):
+        g.set_param("p", 1.1)
+
+
+def test_copy_semantics():
+    g1 = make_gp()
+    for g2 in (g1.copy(deep=False), copy(g1)):
+        assert g1 is not g2 and g1._x is g2._x and g1._y is g2._y and g1._s is g2._s and g1.K is g2.K
+    for g2 in (g1.copy(deep=True), deepcopy(g1), pickle.loads(pickle.dumps(g1))):
+        assert g1 is not g2 and g1._x is not g2._x and g1._y is not g2._y and g1.K is not g2.K
+        assert g1._s is not g2._s
+        assert (g1._x == g2._x).all() and (g1._y == g2._y).all() and g1._s == g2._s
+        assert (g1.K.params == g2.K.params).all()
+
+
+def test_pickle_carries_memoized_host_arrays():
+    g1 = make_gp()
+    g1._memoized["Kxx"] = np.eye(16)
+    g2 = pickle.loads(pickle.dumps(g1))
+    assert (g2._memoized["Kxx"] == np.eye(16)).all()
+
+
+def test_nd_inputs_accepted():
+    X = np.random.RandomState(0).randn(10, 3)
+    g = gp.GP(gp.GaussianKernel(1, 1), X, np.zeros(10), s=1)
+    assert g._n == 10 and g._d == 3
+    with pytest.raises(ValueError):
+        gp.GP(gp.GaussianKernel(1, 1), X, np.zeros((10, 3)), s=1)
