@@ -58,6 +58,8 @@ _SIGNATURES = {
     "gpx_event_sync": (c_int, [c_void_p]),
     "gpx_event_elapsed_ms": (c_int, [c_void_p, c_void_p, POINTER(c_float)]),
     "gpx_stream_wait_event": (c_int, [c_void_p, c_void_p]),
+    "gpx_prof_enable": (c_int, [c_int]),
+    "gpx_prof_read": (c_int, [c_int, c_double_p, c_double_p, c_double_p]),
     "gpx_d_kmat": (c_int, [c_int, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int,
                            c_double_p, c_double, c_int, c_void_p, c_int64, c_void_p]),
     "gpx_d_mean": (c_int, [c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int, c_double_p,

@@ -42,6 +42,18 @@ static inline size_t esize(int dtype) { return dtype == GPX_F64 ? 8 : 4; }
 static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// ---- live per-kernel-class timing (HIP events around each launch; off by default) ----
+enum ProfClass { PC_KMAT = 0, PC_GEMM = 1, PC_POTRF_DIAG = 2, PC_TRSM_ROWS = 3, PC_TRSV = 4,
+                 PC_MEAN = 5, PC_REDUCE = 6, PC_COUNT = 7 };
+extern bool g_prof_on;
+void prof_begin(int cls, double work, hipStream_t st);
+void prof_end(hipStream_t st);
+struct ProfScope {
+    hipStream_t st; bool on;
+    ProfScope(int cls, double work, hipStream_t s) : st(s), on(g_prof_on) { if (on) prof_begin(cls, work, st); }
+    ~ProfScope() { if (on) prof_end(st); }
+};
+
 // parameters of a kernel-matrix member, precomputed on the host in f64
 struct KParams {
     double c[6];     // member-specific constants (see gpx_kmat.hip)

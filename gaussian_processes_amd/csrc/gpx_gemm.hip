@@ -193,6 +193,21 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(int64_t M, int64_t N, i
     }
 }
 
+// number of C elements a launch updates (all of M x N, or those with row0+i >= col0+j)
+static double updated_elements(int64_t M, int64_t N, int tri, int64_t row0, int64_t col0)
+{
+    if (tri != GPX_LOWER) return (double)M * (double)N;
+    double cnt = 0;
+    // column j is updated for rows i >= col0 + j - row0
+    const int64_t off = col0 - row0;
+    // closed form over j in [0, N): rows max(0, j + off) .. M-1
+    for (int64_t j = 0; j < N; ++j) {
+        const int64_t first = std::max<int64_t>(0, j + off);
+        if (first < M) cnt += (double)(M - first);
+    }
+    return cnt;
+}
+
 template <typename T>
 int launch_gemm_nt(int64_t M, int64_t N, int64_t K, const void *A, int64_t lda, const void *B,
                    int64_t ldb, void *C, int64_t ldc, double alpha, int tri, int64_t row0,
@@ -206,6 +221,7 @@ int launch_gemm_nt(int64_t M, int64_t N, int64_t K, const void *A, int64_t lda, 
         attr_done = true;
     }
     dim3 grid((unsigned)cdiv(N, GB_N), (unsigned)cdiv(M, GB_M)), block(256);
+    ProfScope prof(PC_GEMM, 2.0 * (double)K * updated_elements(M, N, tri, row0, col0), st);
     hipLaunchKernelGGL((gemm_nt_kernel<T>), grid, block, G_SMEM, st, M, N, K, (const T *)A, lda,
                        (const T *)B, ldb, (T *)C, ldc, (T)alpha, tri, row0, col0);
     GPX_LAUNCH_CHECK();

@@ -243,6 +243,17 @@ static int launch_kmat(const void *x1, int64_t n, const void *x2, int64_t m, int
     const T *a = (const T *)x1;
     const T *b = (const T *)x2;
     T *o = (T *)out;
+    double bytes = 0;
+    if (g_prof_on) {
+        // bytes actually written: every tile that is not strictly above the diagonal
+        for (int64_t r0 = 0; r0 < n; r0 += KM_ROWS) {
+            const int64_t rows = std::min<int64_t>(KM_ROWS, n - r0);
+            int64_t cols = m;
+            if (tri == GPX_LOWER) cols = std::min<int64_t>(m, ((r0 + KM_ROWS - 1) / TN + 1) * TN);
+            bytes += (double)rows * cols * sizeof(T);
+        }
+    }
+    ProfScope prof(PC_KMAT, bytes, st);
 #define GPX_KM_LAUNCH(MODE)                                                                   \
     do {                                                                                      \
         if (smem > 48 * 1024)                                                                 \
@@ -355,6 +366,7 @@ static int launch_mean(int kernel, const void *xo, int64_t m, const void *x, int
         return GPX_ERR_UNSUPPORTED;
     }
     dim3 grid((unsigned)cdiv(m, MP)), block(256);
+    ProfScope prof(PC_MEAN, (double)m * n, st);
     if (kernel == GPX_KERNEL_GAUSSIAN) {
         if (smem > 48 * 1024)
             GPX_HIP(hipFuncSetAttribute((const void *)mean_kernel<T, GPX_KERNEL_GAUSSIAN>,

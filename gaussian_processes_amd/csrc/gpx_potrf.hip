@@ -116,6 +116,7 @@ static int launch_trsm_rows(void *X, int64_t ldx, int64_t rows, const void *Ljj,
     if (rows <= 0 || jb <= 0) return GPX_OK;
     dim3 grid((unsigned)cdiv(rows, 256)), block(256);
     const bool vec_ok = (jb == IB) && (ldx % (16 / (int64_t)sizeof(T)) == 0) && (((uintptr_t)X) % 16 == 0);
+    ProfScope prof(PC_TRSM_ROWS, (double)rows * jb * jb, st);
     if (vec_ok)
         hipLaunchKernelGGL((trsm_rows_kernel<T, true>), grid, block, 0, st, (T *)X, ldx, rows,
                            (const T *)Ljj, ldl, jb);
@@ -177,8 +178,11 @@ static int potrf_t(T *A, int64_t n, int64_t lda, int *info_dev, hipStream_t st, 
             if (j0 > k0)
                 GPX_TRY(gemm_nt(dtype, n - j0, jb, j0 - k0, Aj + k0, lda, Aj + k0, lda, Aj + j0, lda,
                                 -1.0, GPX_LOWER, 0, 0, st));
-            hipLaunchKernelGGL((potrf_diag_kernel<T>), dim3(1), dim3(256), 0, st, A, lda, j0, jb,
-                               info_dev);
+            {
+                ProfScope prof(PC_POTRF_DIAG, (double)jb * jb * jb / 3.0, st);
+                hipLaunchKernelGGL((potrf_diag_kernel<T>), dim3(1), dim3(256), 0, st, A, lda, j0, jb,
+                                   info_dev);
+            }
             GPX_LAUNCH_CHECK();
             const int64_t below = n - (j0 + jb);
             if (below > 0)

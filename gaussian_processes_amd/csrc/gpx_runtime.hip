@@ -1,6 +1,7 @@
 // gpx_runtime.hip -- device / memory / stream / event plumbing of the C ABI.
 #include "gpx_common.h"
 #include <stdarg.h>
+#include <vector>
 
 namespace gpx {
 
@@ -36,6 +37,34 @@ int ensure_device()
     }
     ok = 1;
     return GPX_OK;
+}
+
+// ---- profiling registry -----------------------------------------------------
+bool g_prof_on = false;
+struct ProfRec { int cls; double work; hipEvent_t a, b; };
+static std::vector<ProfRec> g_prof;
+
+void prof_begin(int cls, double work, hipStream_t st)
+{
+    ProfRec r;
+    r.cls = cls; r.work = work; r.a = nullptr; r.b = nullptr;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    (void)hipEventRecord(r.a, st);
+    g_prof.push_back(r);
+}
+
+void prof_end(hipStream_t st)
+{
+    if (!g_prof.empty() && g_prof.back().b) (void)hipEventRecord(g_prof.back().b, st);
+}
+
+static void prof_clear()
+{
+    for (auto &r : g_prof) {
+        if (r.a) (void)hipEventDestroy(r.a);
+        if (r.b) (void)hipEventDestroy(r.b);
+    }
+    g_prof.clear();
 }
 
 }  // namespace gpx
@@ -223,6 +252,33 @@ int gpx_event_elapsed_ms(void *start, void *stop, float *ms)
 {
     GPX_ARG(ms, "ms is NULL");
     GPX_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return GPX_OK;
+}
+
+int gpx_prof_enable(int on)
+{
+    if (g_prof_on || on) GPX_TRY(ensure_device());
+    if (g_prof_on) (void)hipDeviceSynchronize();
+    prof_clear();
+    g_prof_on = on != 0;
+    return GPX_OK;
+}
+
+int gpx_prof_read(int cls, double *launches, double *total_ms, double *total_work)
+{
+    GPX_ARG(cls >= 0 && cls < PC_COUNT, "unknown profile class");
+    GPX_TRY(ensure_device());
+    GPX_HIP(hipDeviceSynchronize());
+    double n = 0, ms = 0, w = 0;
+    for (auto &r : g_prof) {
+        if (r.cls != cls || !r.a || !r.b) continue;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) { (void)hipGetLastError(); continue; }
+        n += 1; ms += t; w += r.work;
+    }
+    if (launches) *launches = n;
+    if (total_ms) *total_ms = ms;
+    if (total_work) *total_work = w;
     return GPX_OK;
 }
 

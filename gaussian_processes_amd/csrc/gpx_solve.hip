@@ -108,6 +108,7 @@ __global__ __launch_bounds__(256) void trsv_bwd_step(const T *__restrict__ L, in
 template <typename T>
 static int trsv_t(const T *L, int64_t n, int64_t ldl, T *b, T *x, int transpose, hipStream_t st)
 {
+    ProfScope prof(PC_TRSV, 0.5 * (double)n * (n + 1) * sizeof(T), st);
     if (!transpose) {
         for (int64_t k0 = 0; k0 < n; k0 += SB) {
             const int jb = (int)std::min<int64_t>(SB, n - k0);

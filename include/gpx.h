@@ -112,6 +112,21 @@ int gpx_event_sync(void *event);
 int gpx_event_elapsed_ms(void *start, void *stop, float *ms);
 int gpx_stream_wait_event(void *stream, void *event);
 
+/* Live per-kernel-class timing.  When enabled every launch of the hot-path
+ * kernels is bracketed by HIP events on its own stream; gpx_prof_read sums, per
+ * class, the launches, their elapsed milliseconds and their ALGORITHMIC work
+ * (flops for GPX_PROF_GEMM, bytes for the others).  bench.py derives
+ * roofline.achieved from these. */
+#define GPX_PROF_KMAT       0   /* bytes written                                  */
+#define GPX_PROF_GEMM       1   /* flops: 2*K per updated element (lower: i >= j) */
+#define GPX_PROF_POTRF_DIAG 2   /* flops jb^3/3                                   */
+#define GPX_PROF_TRSM_ROWS  3   /* flops rows*jb^2                                */
+#define GPX_PROF_TRSV       4   /* bytes of L read                                */
+#define GPX_PROF_MEAN       5   /* kernel evaluations m*n                         */
+#define GPX_PROF_REDUCE     6   /* bytes read                                     */
+int gpx_prof_enable(int on);    /* also clears the registry */
+int gpx_prof_read(int cls, double *launches, double *total_ms, double *total_work);
+
 /* ------------------------------------------------- device-level hot path -- */
 
 /* Kernel-matrix build: out[i, j] = member(x1[i, :], x2[j, :]) (+ diag_add if i == j).
