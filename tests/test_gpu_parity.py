@@ -113,7 +113,8 @@ def test_kmat_lower_only_and_diag_add_device_api():
 # ------------------------------------------------------------------ gemm (MFMA) --
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 @pytest.mark.parametrize("M,N,K", [(16, 16, 4), (128, 128, 16), (130, 70, 37), (257, 300, 129),
-                                   (64, 1, 1000), (500, 500, 64)])
+                                   (64, 1, 1000), (500, 500, 64), (300, 200, 96), (1025, 515, 160),
+                                   (2048, 1024, 512), (3, 1300, 32)])
 def test_gemm_nt_vs_numpy(dtype, M, N, K):
     npdt = np.float64 if dtype == "f64" else np.float32
     did = _lib.F64 if dtype == "f64" else _lib.F32
@@ -135,10 +136,10 @@ def test_gemm_nt_vs_numpy(dtype, M, N, K):
     np.testing.assert_allclose(got, ref, rtol=tol, atol=tol * np.sqrt(K))
 
 
-def test_gemm_nt_lower_mask():
-    M = K = 300
+@pytest.mark.parametrize("M,K", [(300, 300), (300, 320), (1500, 64), (2304, 256), (4100, 128)])
+def test_gemm_nt_lower_mask(M, K):
     rng = np.random.RandomState(3)
-    ld = 304
+    ld = ((max(M, K) + 15) // 16) * 16
     A = np.zeros((M, ld)); A[:, :K] = rng.randn(M, K)
     C = np.zeros((M, ld)); C[:, :M] = rng.randn(M, M)
     dA, dC = DeviceBuffer.from_host(A), DeviceBuffer.from_host(C)
@@ -148,8 +149,33 @@ def test_gemm_nt_lower_mask():
     got = dC.to_host()[:, :M]
     full = C[:, :M] - A[:, :K] @ A[:, :K].T
     il, iu = np.tril_indices(M), np.triu_indices(M, 1)
-    np.testing.assert_allclose(got[il], full[il], rtol=1e-12, atol=1e-11)
+    np.testing.assert_allclose(got[il], full[il], rtol=1e-12, atol=1e-10)
     assert np.array_equal(got[iu], C[:, :M][iu])           # strict upper untouched
+
+
+def test_gemm_nt_lower_with_offsets():
+    # panel-update geometry of the factorisation: tall C (M x 64) whose top 64 x 64 block is on
+    # the diagonal, and a shifted triangle (row0 != col0)
+    rng = np.random.RandomState(11)
+    M, N, K = 900, 64, 192
+    A = rng.randn(M, K); C = rng.randn(M, 64)
+    dA, dC = DeviceBuffer.from_host(A), DeviceBuffer.from_host(C)
+    _lib.check(_lib.load().gpx_d_gemm_nt(_lib.F64, M, N, K, -1.0, dA.ptr, K, dA.ptr, K, dC.ptr, 64,
+                                         _lib.LOWER, 0, 0, None))
+    sync()
+    got = dC.to_host()
+    full = C - A @ A[:N].T
+    mask = np.arange(M)[:, None] >= np.arange(N)[None, :]
+    np.testing.assert_allclose(got[mask], full[mask], rtol=1e-12, atol=1e-10)
+    assert np.array_equal(got[~mask], C[~mask])
+    dC2 = DeviceBuffer.from_host(C)
+    _lib.check(_lib.load().gpx_d_gemm_nt(_lib.F64, M, N, K, -1.0, dA.ptr, K, dA.ptr, K, dC2.ptr, 64,
+                                         _lib.LOWER, 10, 40, None))
+    sync()
+    got = dC2.to_host()
+    mask = (10 + np.arange(M))[:, None] >= (40 + np.arange(N))[None, :]
+    np.testing.assert_allclose(got[mask], full[mask], rtol=1e-12, atol=1e-10)
+    assert np.array_equal(got[~mask], C[~mask])
 
 
 # ------------------------------------------------------------ cholesky / solves --
