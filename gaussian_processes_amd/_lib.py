@@ -68,6 +68,10 @@ _SIGNATURES = {
                               c_void_p, c_int64, c_void_p, c_int64, c_int, c_int64, c_int64,
                               c_void_p]),
     "gpx_d_potrf": (c_int, [c_int, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+    "gpx_d_potrf_panel": (c_int, [c_int, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p,
+                                  c_void_p]),
+    "gpx_d_syrk_bc": (c_int, [c_int, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p,
+                              c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_void_p]),
     "gpx_d_tril": (c_int, [c_int, c_void_p, c_int64, c_int64, c_void_p]),
     "gpx_d_trsv_lower": (c_int, [c_int, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int,
                                  c_void_p]),

@@ -70,6 +70,12 @@ int gemm_nt(int dtype, int64_t M, int64_t N, int64_t K, const void *A, int64_t l
 // X[r, 0:jb] <- X[r, 0:jb] * Ljj^-T for rows r in [0, rows); Ljj = jb x jb lower block
 int trsm_rows(int dtype, void *X, int64_t ldx, int64_t rows, const void *Ljj, int64_t ldl, int jb,
               hipStream_t st);
+int syrk_bc(int dtype, int64_t n, int64_t row_begin, void *Cloc, int64_t ldc, int64_t cl0, int64_t cl1,
+            const void *Pb, int64_t ldp, int64_t k0, int64_t kb, int64_t nb, int P, int rank,
+            hipStream_t st);
+// factor rows [r0, n) x columns [c0, c0 + kb) of A whose diagonal block sits at (r0, c0)
+int potrf_panel(int dtype, void *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int64_t kb,
+                int *info_dev, hipStream_t st);
 int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t st);
 int trsv_lower(int dtype, const void *L, int64_t n, int64_t ldl, void *b, void *x, int transpose,
                hipStream_t st);

@@ -273,7 +273,19 @@ constexpr int F_SMEM = F_NST * F_STAGE;        // 147,456 B
 // 16-lane group of a ds_read_b128 fragment read hits 16 distinct 16-B slots
 __device__ __forceinline__ int f_swz(int r) { return (0x64753120u >> (4 * ((r >> 1) & 7))) & 7; }
 
-struct FastMap { int np; int pbc; int tri_enum; };
+// Tile map of one launch.
+//  * columns: local column c of C takes its B-operand row from
+//        c + boff + ((cbase + c) / nb) * pm1nb
+//    and sits at "global" column c + col0 + ((cbase + c) / nb) * pm1nb for the
+//    triangle test.  Plain GEMM: boff = pm1nb = 0.  1-D block-cyclic trailing
+//    update on rank r of P: pm1nb = (P - 1) * nb, so that consecutive local block
+//    columns map to global block columns P apart.
+//  * enumeration: 1024 x 1024 patches, column-major staircase -- patch column pc
+//    holds patch rows [b + a * pc, PBR); R = PBR - b; np patches in total.
+struct GemmMap {
+    int64_t boff, cbase, nb, pm1nb, brows;
+    int np, a, b, R;
+};
 
 typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
 #define GPX_DSR(dst, addr, off) \
@@ -285,7 +297,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_fast_kernel(int64_t M, int64_t
                                                               const T *__restrict__ B, int64_t ldb,
                                                               T *__restrict__ C, int64_t ldc, T alpha,
                                                               int tri, int64_t row0, int64_t col0,
-                                                              FastMap fm)
+                                                              GemmMap fm)
 {
     typedef typename MF<T>::acc_t acc_t;
     constexpr int EPK = MF<T>::EPK;
@@ -297,18 +309,26 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_fast_kernel(int64_t M, int64_t
     const int patch = (loc >> 5) * 8 + xcd, within = loc & 31;
     if (patch >= fm.np) return;
     int pb_r, pb_c;
-    if (fm.tri_enum) {
-        int b = (int)((sqrt(8.0 * (double)patch + 1.0) - 1.0) * 0.5);
-        while ((b + 1) * (b + 2) / 2 <= patch) ++b;
-        while (b * (b + 1) / 2 > patch) --b;
-        pb_r = b; pb_c = patch - b * (b + 1) / 2;
+    if (fm.a == 0) {
+        pb_c = patch / fm.R; pb_r = fm.b + (patch - pb_c * fm.R);
     } else {
-        pb_r = patch / fm.pbc; pb_c = patch - pb_r * fm.pbc;
+        // patches before column pc: cum(pc) = pc * R - a * pc * (pc - 1) / 2
+        auto cum = [&](int pc) { return pc * fm.R - fm.a * (pc * (pc - 1) / 2); };
+        const double rh = (double)fm.R + 0.5 * fm.a;
+        const double disc = rh * rh - 2.0 * fm.a * (double)patch;
+        int pc = (int)((rh - sqrt(disc > 0.0 ? disc : 0.0)) / fm.a);
+        if (pc < 0) pc = 0;
+        while (cum(pc + 1) <= patch) ++pc;
+        while (pc > 0 && cum(pc) > patch) --pc;
+        pb_c = pc; pb_r = fm.b + fm.a * pc + (patch - cum(pc));
     }
     const int64_t bm0 = ((int64_t)pb_r * 4 + (within >> 3)) * F_BM;
     const int64_t bn0 = ((int64_t)pb_c * 8 + (within & 7)) * F_BN;
     if (bm0 >= M || bn0 >= N) return;
+    const int64_t cshift = ((fm.cbase + bn0) / fm.nb) * fm.pm1nb;   // same for the tile's 128 columns
+    col0 += cshift;
     if (tri == GPX_LOWER && col0 + bn0 > row0 + bm0 + F_BM - 1) return;
+    const int64_t brow0 = bn0 + fm.boff + cshift;                   // B-operand row of tile column 0
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -327,7 +347,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_fast_kernel(int64_t M, int64_t
                 const int64_t r = min(bm0 + tr, M - 1);
                 gsrc[j] = reinterpret_cast<const unsigned char *>(A + r * lda) + g * 16;
             } else {
-                const int64_t r = min(bn0 + (tr - F_BM), N - 1);
+                const int64_t r = min(brow0 + (tr - F_BM), fm.brows - 1);
                 gsrc[j] = reinterpret_cast<const unsigned char *>(B + r * ldb) + g * 16;
             }
         }
@@ -416,7 +436,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_fast_kernel(int64_t M, int64_t
 template <typename T>
 static int launch_gemm_nt_fast(int64_t M, int64_t N, int64_t K, const void *A, int64_t lda,
                                const void *B, int64_t ldb, void *C, int64_t ldc, double alpha, int tri,
-                               int64_t row0, int64_t col0, hipStream_t st)
+                               int64_t row0, int64_t col0, hipStream_t st, const GemmMap *map = nullptr,
+                               double work = -1.0)
 {
     static bool attr_done = false;
     if (!attr_done) {
@@ -424,15 +445,28 @@ static int launch_gemm_nt_fast(int64_t M, int64_t N, int64_t K, const void *A, i
                                     hipFuncAttributeMaxDynamicSharedMemorySize, F_SMEM));
         attr_done = true;
     }
-    const int64_t tm = cdiv(M, F_BM), tn = cdiv(N, F_BN);
-    FastMap fm;
-    fm.tri_enum = (tri == GPX_LOWER && M == N && row0 == col0) ? 1 : 0;
-    const int64_t pbr = cdiv(tm, 4), pbc = cdiv(tn, 8);
-    fm.pbc = (int)pbc;
-    const int64_t np = fm.tri_enum ? pbr * (pbr + 1) / 2 : pbr * pbc;
-    fm.np = (int)np;
+    GemmMap fm;
+    if (map) {
+        fm = *map;
+    } else {
+        fm.boff = 0; fm.cbase = 0; fm.nb = (int64_t)1 << 40; fm.pm1nb = 0; fm.brows = N;
+        const int64_t pbr = cdiv(M, 1024), pbc = cdiv(N, 1024);
+        fm.a = 0; fm.b = 0;
+        if (tri == GPX_LOWER && col0 >= row0) { fm.a = 1; fm.b = (int)((col0 - row0) / 1024); }
+        fm.R = (int)pbr - fm.b;
+        if (fm.R <= 0) return GPX_OK;                       // nothing at or below the diagonal
+        int64_t np = 0;
+        for (int64_t pc = 0; pc < pbc; ++pc) {
+            const int64_t cnt = fm.R - (int64_t)fm.a * pc;
+            if (cnt <= 0) break;
+            np += cnt;
+        }
+        fm.np = (int)np;
+    }
+    const int64_t np = fm.np;
+    if (np <= 0) return GPX_OK;
     const int64_t blocks = cdiv(np, 8) * 8 * 32;
-    ProfScope prof(PC_GEMM, 2.0 * (double)K * updated_elements(M, N, tri, row0, col0), st);
+    ProfScope prof(PC_GEMM, work >= 0 ? work : 2.0 * (double)K * updated_elements(M, N, tri, row0, col0), st);
     hipLaunchKernelGGL((gemm_nt_fast_kernel<T>), dim3((unsigned)blocks), dim3(512), F_SMEM, st, M, N, K,
                        (const T *)A, lda, (const T *)B, ldb, (T *)C, ldc, (T)alpha, tri, row0, col0, fm);
     GPX_LAUNCH_CHECK();
@@ -458,6 +492,76 @@ int gemm_nt(int dtype, int64_t M, int64_t N, int64_t K, const void *A, int64_t l
     return launch_gemm_nt<float>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0, col0, st);
 }
 
+
+// ---------------------------------------------------------------------------
+// Trailing update of the blocked Cholesky on a 1-D block-cyclic column layout.
+//   Cloc (n x local columns, ldc): this rank's block columns; local block jl is
+//   global block jl * P + rank (width nb).  Updates rows [row_begin, n) of the
+//   local columns [cl0, cl1) with the factored panel Pb (row i of Pb = global row
+//   k0 + i, kb columns, ldp):   C[g, c] -= sum_k Pb[g - k0, k] * Pb[gcol(c) - k0, k]
+//   for global row g >= global column gcol(c).  P = 1, rank = 0 is the ordinary
+//   single-GPU SYRK.  One launch for all local block columns (staircase map).
+// ---------------------------------------------------------------------------
+int syrk_bc(int dtype, int64_t n, int64_t row_begin, void *Cloc, int64_t ldc, int64_t cl0, int64_t cl1,
+            const void *Pb, int64_t ldp, int64_t k0, int64_t kb, int64_t nb, int P, int rank,
+            hipStream_t st)
+{
+    const int64_t M = n - row_begin, Ncols = cl1 - cl0;
+    if (M <= 0 || Ncols <= 0 || kb <= 0) return GPX_OK;
+    const size_t es = esize(dtype);
+    const int64_t epk = 128 / (int64_t)es, ch = 16 / (int64_t)es;
+    auto gcol = [&](int64_t c) { return ((c / nb) * P + rank) * nb + c % nb; };   // local -> global column
+    // algorithmic flops: 2 * kb per updated element (global row >= global column)
+    double elems = 0;
+    for (int64_t c = cl0; c < cl1; c += nb) {
+        const int64_t w = std::min(nb - c % nb, cl1 - c), g = gcol(c);
+        for (int64_t j = 0; j < w; ++j) {
+            const int64_t first = std::max(row_begin, g + j);
+            if (first < n) elems += (double)(n - first);
+        }
+    }
+    const double work = 2.0 * (double)kb * elems;
+    const bool fast = kb % epk == 0 && ldp % ch == 0 && ((uintptr_t)Pb) % 16 == 0 && cl0 % 128 == 0 &&
+                      nb % 128 == 0 && (1024 % nb == 0) && getenv("GPX_GEMM_NO_FAST") == nullptr;
+    char *C = (char *)Cloc + (row_begin * ldc + cl0) * es;
+    const char *A = (const char *)Pb + (row_begin - k0) * ldp * es;
+    if (fast) {
+        GemmMap fm;
+        fm.cbase = cl0; fm.nb = nb; fm.pm1nb = (int64_t)(P - 1) * nb;
+        fm.boff = cl0 + (int64_t)rank * nb - k0;
+        fm.brows = n - k0;
+        const int64_t G0 = gcol(cl0);
+        const int64_t pbr = cdiv(M, 1024), pbc = cdiv(Ncols, 1024);
+        fm.a = P;
+        fm.b = (int)std::max<int64_t>(0, (G0 - row_begin) / 1024);
+        fm.R = (int)pbr - fm.b;
+        if (fm.R <= 0) return GPX_OK;
+        int64_t np = 0;
+        for (int64_t pc = 0; pc < pbc; ++pc) {
+            const int64_t cnt = fm.R - (int64_t)fm.a * pc;
+            if (cnt <= 0) break;
+            np += cnt;
+        }
+        fm.np = (int)np;
+        if (dtype == GPX_F64)
+            return launch_gemm_nt_fast<double>(M, Ncols, kb, A, ldp, Pb, ldp, C, ldc, -1.0, GPX_LOWER,
+                                               row_begin, cl0 + (int64_t)rank * nb, st, &fm, work);
+        return launch_gemm_nt_fast<float>(M, Ncols, kb, A, ldp, Pb, ldp, C, ldc, -1.0, GPX_LOWER,
+                                          row_begin, cl0 + (int64_t)rank * nb, st, &fm, work);
+    }
+    // generic route: one launch per local block column
+    for (int64_t c = cl0; c < cl1;) {
+        const int64_t w = std::min(nb - c % nb, cl1 - c), g = gcol(c);
+        const int64_t rb = std::max(row_begin, g);
+        if (rb < n)
+            GPX_TRY(gemm_nt(dtype, n - rb, w, kb, (const char *)Pb + (rb - k0) * ldp * es, ldp,
+                            (const char *)Pb + (g - k0) * ldp * es, ldp,
+                            (char *)Cloc + (rb * ldc + c) * es, ldc, -1.0, GPX_LOWER, rb, g, st));
+        c += w;
+    }
+    return GPX_OK;
+}
+
 }  // namespace gpx
 
 using namespace gpx;
@@ -477,4 +581,20 @@ extern "C" int gpx_d_gemm_nt(int dtype, int64_t M, int64_t N, int64_t K, double 
     GPX_ARG(((uintptr_t)A) % 16 == 0 && ((uintptr_t)B) % 16 == 0, "A/B must be 16-byte aligned");
     GPX_ARG(tri == GPX_FULL || tri == GPX_LOWER, "tri must be GPX_FULL or GPX_LOWER");
     return gemm_nt(dtype, M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0, col0, S(stream));
+}
+
+extern "C" int gpx_d_syrk_bc(int dtype, int64_t n, int64_t row_begin, void *Cloc, int64_t ldc,
+                             int64_t cl0, int64_t cl1, const void *Pb, int64_t ldp, int64_t k0,
+                             int64_t kb, int64_t nb, int P, int rank, void *stream)
+{
+    GPX_TRY(ensure_device());
+    GPX_ARG(dtype == GPX_F64 || dtype == GPX_F32, "dtype must be GPX_F64 or GPX_F32");
+    GPX_ARG(n >= 0 && row_begin >= 0 && cl0 >= 0 && cl1 >= cl0 && kb >= 0, "bad dimensions");
+    GPX_ARG(P >= 1 && rank >= 0 && rank < P && nb >= 64 && nb % 64 == 0, "bad P / rank / nb");
+    GPX_ARG(k0 + kb <= row_begin, "row_begin must lie below the panel's diagonal block");
+    if (n == 0 || cl1 == cl0 || kb == 0) return GPX_OK;
+    GPX_ARG(Cloc && Pb, "NULL pointer");
+    const int64_t ch = 16 / (int64_t)esize(dtype);
+    GPX_ARG(ldp >= kb && ldp % ch == 0 && ((uintptr_t)Pb) % 16 == 0, "panel must be 16-byte aligned");
+    return syrk_bc(dtype, n, row_begin, Cloc, ldc, cl0, cl1, Pb, ldp, k0, kb, nb, P, rank, S(stream));
 }

@@ -15,6 +15,7 @@
 //     trailing update A[k0+kb:, k0+kb:] -= P * P^T, P = A[k0+kb:, k0:k0+kb]  MFMA gemm_nt, lower
 // >= 97 % of the flops at N = 65536 are in the trailing update (K = nb deep).
 #include "gpx_common.h"
+#include <vector>
 
 namespace gpx {
 
@@ -23,13 +24,13 @@ constexpr int IBP = IB + 1;   // LDS pitch (elements): conflict-free column walk
 
 // ---- (b) diagonal block: unblocked right-looking Cholesky in LDS ----------
 template <typename T>
-__global__ __launch_bounds__(256) void potrf_diag_kernel(T *__restrict__ A, int64_t lda, int64_t j0,
+__global__ __launch_bounds__(256) void potrf_diag_kernel(T *__restrict__ blk, int64_t lda, int64_t j0,
                                                          int jb, int *__restrict__ info)
 {
+    // blk: the jb x jb diagonal block; j0: its global (0-based) index, for `info`
     __shared__ T s[IB * IBP];
     __shared__ T sdiag[IB];
     const int tid = threadIdx.x;
-    T *blk = A + j0 * lda + j0;
     for (int idx = tid; idx < jb * jb; idx += 256) {
         const int i = idx / jb, c = idx - i * jb;
         s[i * IBP + c] = (c <= i) ? blk[(int64_t)i * lda + c] : (T)0;
@@ -165,43 +166,116 @@ static int64_t outer_block(int64_t n)
     return 512;
 }
 
+// ---- panel: rows [r0, n) x columns [c0, c0 + kb), diagonal block at (r0, c0) ----
 template <typename T>
-static int potrf_t(T *A, int64_t n, int64_t lda, int *info_dev, hipStream_t st, int dtype)
+static int potrf_panel_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int64_t kb, int *info_dev,
+                         hipStream_t st, int dtype)
 {
-    GPX_HIP(hipMemsetAsync(info_dev, 0, sizeof(int), st));
-    const int64_t nb = outer_block(n);
-    for (int64_t k0 = 0; k0 < n; k0 += nb) {
-        const int64_t kb = std::min(nb, n - k0);
-        for (int64_t j0 = k0; j0 < k0 + kb; j0 += IB) {
-            const int jb = (int)std::min<int64_t>(IB, k0 + kb - j0);
-            T *Aj = A + j0 * lda;                       // row j0
-            if (j0 > k0)
-                GPX_TRY(gemm_nt(dtype, n - j0, jb, j0 - k0, Aj + k0, lda, Aj + k0, lda, Aj + j0, lda,
-                                -1.0, GPX_LOWER, 0, 0, st));
-            {
-                ProfScope prof(PC_POTRF_DIAG, (double)jb * jb * jb / 3.0, st);
-                hipLaunchKernelGGL((potrf_diag_kernel<T>), dim3(1), dim3(256), 0, st, A, lda, j0, jb,
-                                   info_dev);
-            }
-            GPX_LAUNCH_CHECK();
-            const int64_t below = n - (j0 + jb);
-            if (below > 0)
-                GPX_TRY(trsm_rows(dtype, A + (j0 + jb) * lda + j0, lda, below, Aj + j0, lda, jb, st));
+    for (int64_t j = 0; j < kb; j += IB) {
+        const int jb = (int)std::min<int64_t>(IB, kb - j);
+        T *Aj = A + (r0 + j) * lda + c0;            // row r0 + j, first panel column
+        if (j > 0)
+            GPX_TRY(gemm_nt(dtype, n - (r0 + j), jb, j, Aj, lda, Aj, lda, Aj + j, lda, -1.0, GPX_LOWER, 0,
+                            0, st));
+        {
+            ProfScope prof(PC_POTRF_DIAG, (double)jb * jb * jb / 3.0, st);
+            hipLaunchKernelGGL((potrf_diag_kernel<T>), dim3(1), dim3(256), 0, st, Aj + j, lda, r0 + j, jb,
+                               info_dev);
         }
-        const int64_t r = k0 + kb;
-        if (r < n) {
-            T *P = A + r * lda + k0;
-            GPX_TRY(gemm_nt(dtype, n - r, n - r, kb, P, lda, P, lda, A + r * lda + r, lda, -1.0,
-                            GPX_LOWER, 0, 0, st));
-        }
+        GPX_LAUNCH_CHECK();
+        const int64_t below = n - (r0 + j + jb);
+        if (below > 0)
+            GPX_TRY(trsm_rows(dtype, A + (r0 + j + jb) * lda + c0 + j, lda, below, Aj + j, lda, jb, st));
     }
     return GPX_OK;
 }
 
+int potrf_panel(int dtype, void *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int64_t kb,
+                int *info_dev, hipStream_t st)
+{
+    if (dtype == GPX_F64) return potrf_panel_t<double>((double *)A, lda, n, r0, c0, kb, info_dev, st, dtype);
+    return potrf_panel_t<float>((float *)A, lda, n, r0, c0, kb, info_dev, st, dtype);
+}
+
+// side stream + event pool for the look-ahead (one set per host thread and device)
+struct LookAhead {
+    int device = -1;
+    hipStream_t q = nullptr;
+    std::vector<hipEvent_t> ev;
+    size_t next = 0;
+    int get(hipEvent_t *e)
+    {
+        if (next == ev.size()) {
+            hipEvent_t x;
+            GPX_HIP(hipEventCreateWithFlags(&x, hipEventDisableTiming));
+            ev.push_back(x);
+        }
+        *e = ev[next++];
+        return GPX_OK;
+    }
+};
+static thread_local LookAhead g_la;
+
+static int lookahead_setup()
+{
+    int dev = 0;
+    GPX_HIP(hipGetDevice(&dev));
+    if (g_la.device != dev) {
+        g_la = LookAhead();
+        g_la.device = dev;
+        GPX_HIP(hipStreamCreateWithFlags(&g_la.q, hipStreamNonBlocking));
+    }
+    g_la.next = 0;
+    return GPX_OK;
+}
+
+// Right-looking blocked Cholesky with one-panel look-ahead: while the main stream
+// applies panel k to the block columns beyond k + 1, the side stream already
+// factors panel k + 1 (whose block column was updated first).
 int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t st)
 {
-    if (dtype == GPX_F64) return potrf_t<double>((double *)A, n, lda, info_dev, st, dtype);
-    return potrf_t<float>((float *)A, n, lda, info_dev, st, dtype);
+    GPX_HIP(hipMemsetAsync(info_dev, 0, sizeof(int), st));
+    const int64_t nb = outer_block(n);
+    const int64_t nblk = cdiv(n, nb);
+    const size_t es = esize(dtype);
+    static const bool no_la = getenv("GPX_POTRF_NO_LOOKAHEAD") != nullptr;
+    if (nblk <= 1) return potrf_panel(dtype, A, lda, n, 0, 0, n, info_dev, st);
+    auto at = [&](int64_t r, int64_t c) { return (char *)A + (r * lda + c) * es; };
+    if (no_la) {
+        for (int64_t k0 = 0; k0 < n; k0 += nb) {
+            const int64_t kb = std::min(nb, n - k0), r = k0 + kb;
+            GPX_TRY(potrf_panel(dtype, A, lda, n, k0, k0, kb, info_dev, st));
+            if (r < n) GPX_TRY(syrk_bc(dtype, n, r, A, lda, r, n, at(k0, k0), lda, k0, kb, nb, 1, 0, st));
+        }
+        return GPX_OK;
+    }
+    GPX_TRY(lookahead_setup());
+    hipStream_t q = g_la.q;
+    hipEvent_t e, ep;
+    GPX_TRY(g_la.get(&e));
+    GPX_HIP(hipEventRecord(e, st));
+    GPX_HIP(hipStreamWaitEvent(q, e, 0));
+    GPX_TRY(potrf_panel(dtype, A, lda, n, 0, 0, std::min(nb, n), info_dev, q));
+    GPX_TRY(g_la.get(&ep));
+    GPX_HIP(hipEventRecord(ep, q));
+    for (int64_t k0 = 0; k0 < n; k0 += nb) {
+        const int64_t kb = std::min(nb, n - k0), r = k0 + kb;
+        GPX_HIP(hipStreamWaitEvent(st, ep, 0));                 // panel k is factored
+        if (r >= n) break;
+        const int64_t kb1 = std::min(nb, n - r);
+        // block column k + 1 first, so that its panel can start ...
+        GPX_TRY(syrk_bc(dtype, n, r, A, lda, r, r + kb1, at(k0, k0), lda, k0, kb, nb, 1, 0, st));
+        GPX_TRY(g_la.get(&e));
+        GPX_HIP(hipEventRecord(e, st));
+        GPX_HIP(hipStreamWaitEvent(q, e, 0));
+        GPX_TRY(potrf_panel(dtype, A, lda, n, r, r, kb1, info_dev, q));
+        GPX_TRY(g_la.get(&ep));
+        GPX_HIP(hipEventRecord(ep, q));
+        // ... while the rest of the trailing matrix is updated underneath it
+        if (r + kb1 < n)
+            GPX_TRY(syrk_bc(dtype, n, r, A, lda, r + kb1, n, at(k0, k0), lda, k0, kb, nb, 1, 0, st));
+    }
+    return GPX_OK;
 }
 
 }  // namespace gpx
@@ -235,3 +309,16 @@ int gpx_d_tril(int dtype, void *A, int64_t n, int64_t lda, void *stream)
 }
 
 }  // extern "C"
+
+extern "C" int gpx_d_potrf_panel(int dtype, void *A, int64_t lda, int64_t n, int64_t r0, int64_t c0,
+                                 int64_t kb, int *info_dev, void *stream)
+{
+    GPX_TRY(ensure_device());
+    GPX_ARG(dtype == GPX_F64 || dtype == GPX_F32, "dtype must be GPX_F64 or GPX_F32");
+    GPX_ARG(n >= 0 && r0 >= 0 && c0 >= 0 && kb >= 0 && r0 + kb <= n, "bad dimensions");
+    GPX_ARG(info_dev, "info_dev is NULL");
+    if (kb == 0) return GPX_OK;
+    GPX_ARG(A, "A is NULL");
+    GPX_ARG(lda % 16 == 0 && ((uintptr_t)A) % 16 == 0 && c0 % 16 == 0, "A / lda / c0 must be 16-element aligned");
+    return potrf_panel(dtype, A, lda, n, r0, c0, kb, info_dev, S(stream));
+}

@@ -164,6 +164,22 @@ int gpx_d_gemm_nt(int dtype, int64_t M, int64_t N, int64_t K, double alpha,
 int gpx_d_potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev,
                 void *stream);
 
+/* The two building blocks of gpx_d_potrf, exported for multi-GPU drivers (1-D
+ * block-cyclic block columns).
+ * gpx_d_potrf_panel factors rows [r0, n) x columns [c0, c0 + kb) of A in place; the
+ * kb x kb diagonal block sits at (r0, c0) (c0 == r0 on one GPU; a local column
+ * offset on a distributed matrix).  info_dev as in gpx_d_potrf (index r0-based
+ * global: r0 + j + 1), never cleared here.
+ * gpx_d_syrk_bc applies a factored panel Pb (row i = global row k0 + i, kb columns,
+ * ldp) to this rank's block columns: local columns [cl0, cl1) of Cloc (n rows,
+ * ldc), rows [row_begin, n); local block jl is global block jl * P + rank of width
+ * nb;  C[g, c] -= sum_k Pb[g - k0, k] * Pb[gcol(c) - k0, k]  where g >= gcol(c). */
+int gpx_d_potrf_panel(int dtype, void *A, int64_t lda, int64_t n, int64_t r0, int64_t c0,
+                      int64_t kb, int *info_dev, void *stream);
+int gpx_d_syrk_bc(int dtype, int64_t n, int64_t row_begin, void *Cloc, int64_t ldc,
+                  int64_t cl0, int64_t cl1, const void *Pb, int64_t ldp, int64_t k0,
+                  int64_t kb, int64_t nb, int P, int rank, void *stream);
+
 /* Zero the strict upper triangle (scipy's cholesky returns a clean L). */
 int gpx_d_tril(int dtype, void *A, int64_t n, int64_t lda, void *stream);
 

@@ -381,3 +381,65 @@ def test_full_size_properties_config2():
     np.testing.assert_allclose(mean[:16], orc.kernel_matrix("gaussian", "K", Xo[:16], X, (h, w)) @ alpha,
                                rtol=1e-9, atol=1e-11)
     assert g.fit_timing()["total"] > 0
+
+
+# ------------------------------------------- block-cyclic building blocks --
+@pytest.mark.parametrize("n,nb,P,k", [(2000, 256, 3, 1), (4096, 512, 2, 0), (3100, 128, 4, 5),
+                                      (2560, 256, 1, 2), (5000, 512, 8, 0)])
+def test_syrk_bc_block_cyclic_vs_numpy(n, nb, P, k):
+    rng = np.random.RandomState(n + P)
+    k0 = k * nb
+    kb = nb
+    row_begin = k0 + kb
+    panel = rng.randn(n - k0, kb)                      # row i = global row k0 + i
+    dP = DeviceBuffer.from_host(panel)
+    nblk = (n + nb - 1) // nb
+    for rank in range(P):
+        gblocks = [j for j in range(nblk) if j % P == rank]
+        ncl = len(gblocks) * nb
+        ldc = ((ncl + 15) // 16) * 16
+        C = np.zeros((n, ldc)); C[:, :ncl] = rng.randn(n, ncl)
+        dC = DeviceBuffer.from_host(C)
+        # local block columns whose global index is > k
+        first = next((jl for jl, j in enumerate(gblocks) if j > k), None)
+        if first is None:
+            continue
+        cl0 = first * nb
+        cl1 = min(ncl, ncl)
+        _lib.check(_lib.load().gpx_d_syrk_bc(_lib.F64, n, row_begin, dC.ptr, ldc, cl0, cl1, dP.ptr, kb,
+                                             k0, kb, nb, P, rank, None))
+        sync()
+        got = dC.to_host()
+        ref = C.copy()
+        for jl, j in enumerate(gblocks):
+            if jl < first:
+                continue
+            for cc in range(nb):
+                gc = j * nb + cc
+                if gc >= n:
+                    continue       # padding columns beyond the matrix: rows >= gc do not exist
+                rows = np.arange(max(row_begin, gc), n)
+                ref[rows, jl * nb + cc] -= panel[rows - k0] @ panel[gc - k0]
+        np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-10)
+
+
+def test_potrf_panel_device_api_matches_full_factor():
+    n, nb = 1500, 256
+    A = _spd(n, 7)
+    lda = ((n + 15) // 16) * 16
+    Ap = np.zeros((n, lda)); Ap[:, :n] = A
+    dA = DeviceBuffer.from_host(Ap)
+    info = DeviceBuffer((4,), np.int32).zero()
+    lib = _lib.load()
+    for k0 in range(0, n, nb):
+        kb = min(nb, n - k0)
+        _lib.check(lib.gpx_d_potrf_panel(_lib.F64, dA.ptr, lda, n, k0, k0, kb, info.ptr, None))
+        r = k0 + kb
+        if r < n:
+            off = ctypes.c_void_p(dA.ptr.value + (k0 * lda + k0) * 8)
+            _lib.check(lib.gpx_d_syrk_bc(_lib.F64, n, r, dA.ptr, lda, r, n, off, lda, k0, kb, nb, 1, 0,
+                                         None))
+    sync()
+    L = np.tril(dA.to_host()[:, :n])
+    assert info.to_host()[0] == 0
+    np.testing.assert_allclose(L, scipy.linalg.cholesky(A, lower=True), rtol=1e-9, atol=1e-11)
