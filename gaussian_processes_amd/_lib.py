@@ -75,6 +75,10 @@ _SIGNATURES = {
     "gpx_d_tril": (c_int, [c_int, c_void_p, c_int64, c_int64, c_void_p]),
     "gpx_d_trsv_lower": (c_int, [c_int, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int,
                                  c_void_p]),
+    "gpx_d_trsv_lower_cols": (c_int, [c_int, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p,
+                                      c_void_p]),
+    "gpx_d_panel_gemv_t": (c_int, [c_int, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p,
+                                   c_void_p, c_void_p]),
     "gpx_d_trsm_right_lt": (c_int, [c_int, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                     c_void_p]),
     "gpx_d_logdet_chol": (c_int, [c_int, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),

@@ -106,12 +106,17 @@ __global__ __launch_bounds__(256) void trsv_bwd_step(const T *__restrict__ L, in
 }
 
 template <typename T>
-static int trsv_t(const T *L, int64_t n, int64_t ldl, T *b, T *x, int transpose, hipStream_t st)
+static int trsv_t(const T *L, int64_t n, int64_t ldl, T *b, T *x, int transpose, hipStream_t st,
+                  int64_t ncols = -1)
 {
-    ProfScope prof(PC_TRSV, 0.5 * (double)n * (n + 1) * sizeof(T), st);
+    // ncols < n (forward only): the matrix is a trapezoid -- an ncols x ncols lower
+    // triangle on top of (n - ncols) further rows; x[0:ncols] is solved and the
+    // remaining right-hand side b[ncols:n] is reduced by L[ncols:n, 0:ncols] x.
+    if (ncols < 0 || ncols > n) ncols = n;
+    ProfScope prof(PC_TRSV, ((double)n * ncols - 0.5 * (double)ncols * (ncols - 1)) * sizeof(T), st);
     if (!transpose) {
-        for (int64_t k0 = 0; k0 < n; k0 += SB) {
-            const int jb = (int)std::min<int64_t>(SB, n - k0);
+        for (int64_t k0 = 0; k0 < ncols; k0 += SB) {
+            const int jb = (int)std::min<int64_t>(SB, ncols - k0);
             const int64_t below = n - k0 - jb;
             dim3 grid((unsigned)std::max<int64_t>(1, cdiv(below, SB))), block(256);
             hipLaunchKernelGGL((trsv_fwd_step<T>), grid, block, 0, st, L, ldl, b, x, k0, jb, n);
@@ -135,6 +140,69 @@ int trsv_lower(int dtype, const void *L, int64_t n, int64_t ldl, void *b, void *
     if (n <= 0) return GPX_OK;
     if (dtype == GPX_F64) return trsv_t<double>((const double *)L, n, ldl, (double *)b, (double *)x, transpose, st);
     return trsv_t<float>((const float *)L, n, ldl, (float *)b, (float *)x, transpose, st);
+}
+
+int trsv_lower_cols(int dtype, const void *L, int64_t n, int64_t ldl, int64_t ncols, void *b, void *x,
+                    hipStream_t st)
+{
+    if (n <= 0 || ncols <= 0) return GPX_OK;
+    if (dtype == GPX_F64)
+        return trsv_t<double>((const double *)L, n, ldl, (double *)b, (double *)x, 0, st, ncols);
+    return trsv_t<float>((const float *)L, n, ldl, (float *)b, (float *)x, 0, st, ncols);
+}
+
+// y[c] -= sum_r Lp[r, c] * x[r]   (c < ncols <= 1024, r < rows): the transposed
+// panel product of the distributed back substitution.  Two stages, fixed
+// summation order: 256-row chunks -> partial sums in `work`, then one reduction.
+template <typename T>
+__global__ __launch_bounds__(256) void panel_gemv_t_partial(const T *__restrict__ Lp, int64_t ldl,
+                                                            int64_t rows, int ncols,
+                                                            const T *__restrict__ x, double *__restrict__ work)
+{
+    __shared__ T sx[256];
+    const int tid = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * 256;
+    sx[tid] = (r0 + tid < rows) ? x[r0 + tid] : (T)0;
+    __syncthreads();
+    const int nr = (int)std::min<int64_t>(256, rows - r0);
+    for (int c = tid; c < ncols; c += 256) {
+        const T *col = Lp + r0 * ldl + c;
+        double acc = 0.0;
+        for (int i = 0; i < nr; ++i) acc = fma((double)col[(int64_t)i * ldl], (double)sx[i], acc);
+        work[(int64_t)blockIdx.x * ncols + c] = acc;
+    }
+}
+
+template <typename T>
+__global__ void panel_gemv_t_reduce(const double *__restrict__ work, int64_t nchunks, int ncols,
+                                    T *__restrict__ y)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncols) return;
+    double acc = 0.0;
+    for (int64_t k = 0; k < nchunks; ++k) acc += work[k * ncols + c];
+    y[c] = (T)((double)y[c] - acc);
+}
+
+int panel_gemv_t(int dtype, const void *Lp, int64_t ldl, int64_t rows, int64_t ncols, const void *x,
+                 void *y, double *work, hipStream_t st)
+{
+    if (rows <= 0 || ncols <= 0) return GPX_OK;
+    const int64_t nchunks = cdiv(rows, 256);
+    ProfScope prof(PC_TRSV, (double)rows * ncols * esize(dtype), st);
+    if (dtype == GPX_F64) {
+        hipLaunchKernelGGL((panel_gemv_t_partial<double>), dim3((unsigned)nchunks), dim3(256), 0, st,
+                           (const double *)Lp, ldl, rows, (int)ncols, (const double *)x, work);
+        hipLaunchKernelGGL((panel_gemv_t_reduce<double>), dim3((unsigned)cdiv(ncols, 256)), dim3(256), 0, st,
+                           work, nchunks, (int)ncols, (double *)y);
+    } else {
+        hipLaunchKernelGGL((panel_gemv_t_partial<float>), dim3((unsigned)nchunks), dim3(256), 0, st,
+                           (const float *)Lp, ldl, rows, (int)ncols, (const float *)x, work);
+        hipLaunchKernelGGL((panel_gemv_t_reduce<float>), dim3((unsigned)cdiv(ncols, 256)), dim3(256), 0, st,
+                           work, nchunks, (int)ncols, (float *)y);
+    }
+    GPX_LAUNCH_CHECK();
+    return GPX_OK;
 }
 
 // X (m x n) <- X * L^-T, blocked: level-3 updates on the MFMA gemm_nt, 64-wide
@@ -254,6 +322,34 @@ int gpx_d_dot(int dtype, const void *a, const void *b, int64_t n, double *out_de
     GPX_ARG(dtype == GPX_F64 || dtype == GPX_F32, "dtype must be GPX_F64 or GPX_F32");
     GPX_ARG(n >= 0 && out_dev && (n == 0 || (a && b)), "bad arguments");
     return dot(dtype, a, b, n, out_dev, S(stream));
+}
+
+}  // extern "C"
+
+extern "C" {
+
+int gpx_d_trsv_lower_cols(int dtype, const void *L, int64_t n, int64_t ldl, int64_t ncols, void *b,
+                          void *x, void *stream)
+{
+    GPX_TRY(ensure_device());
+    GPX_ARG(dtype == GPX_F64 || dtype == GPX_F32, "dtype must be GPX_F64 or GPX_F32");
+    GPX_ARG(n >= 0 && ncols >= 0 && ncols <= n, "need 0 <= ncols <= n");
+    if (n == 0 || ncols == 0) return GPX_OK;
+    GPX_ARG(L && b && x && b != x, "NULL pointer or b == x");
+    GPX_ARG(ldl >= ncols, "ldl < ncols");
+    return trsv_lower_cols(dtype, L, n, ldl, ncols, b, x, S(stream));
+}
+
+int gpx_d_panel_gemv_t(int dtype, const void *Lp, int64_t ldl, int64_t rows, int64_t ncols,
+                       const void *x, void *y, void *work, void *stream)
+{
+    GPX_TRY(ensure_device());
+    GPX_ARG(dtype == GPX_F64 || dtype == GPX_F32, "dtype must be GPX_F64 or GPX_F32");
+    GPX_ARG(rows >= 0 && ncols >= 0, "negative dimension");
+    if (rows == 0 || ncols == 0) return GPX_OK;
+    GPX_ARG(Lp && x && y && work, "NULL pointer");
+    GPX_ARG(ldl >= ncols, "ldl < ncols");
+    return panel_gemv_t(dtype, Lp, ldl, rows, ncols, x, y, (double *)work, S(stream));
 }
 
 }  // extern "C"

@@ -1,0 +1,449 @@
+"""Multi-GPU GP fit/predict: 1-D block-cyclic block columns, one process per GPU.
+
+The reference has nothing distributed (SURVEY sections 2 and 5); this is the
+north-star's scaling path.  The n x n kernel matrix is split into
+block columns of width nb; global block column j lives on rank j % P as local
+block j // P (row-major local matrix, n rows x ceil(nblk / P) * nb columns).
+
+Per panel k (right-looking, one-panel look-ahead):
+  owner(k)   factors its block column below the diagonal        gpx_d_potrf_panel
+             packs it into a contiguous (n - k0) x nb buffer    (device 2-D copy)
+  all ranks  broadcast of that buffer, root = owner(k)          torch.distributed
+             (backend "nccl" = RCCL over xGMI on the node)
+  all ranks  update their own block columns j > k               gpx_d_syrk_bc
+The owner of panel k + 1 updates that block column first and factors +
+broadcasts it on a side stream while everybody finishes update k.
+
+Solves: forward substitution walks the block columns with one all-reduce of an
+nb-vector per block (the residual of that block, whose updates are spread over
+the ranks); back substitution broadcasts each finished alpha block.  logdet and
+the posterior mean are local sums + one all-reduce.
+
+Device work is reached through an `ops` object (HipOps: libgpx.so on torch CUDA
+tensors).  The schedule itself is plain Python and is exercised on CPU by the
+gloo tests with an emulator `ops` that lives in tests/.
+"""
+import ctypes
+import json
+import math
+import os
+import time
+
+import numpy as np
+
+from . import _lib
+
+
+# --------------------------------------------------------------------- layout --
+class BlockCyclic(object):
+    """Index maps of the 1-D block-cyclic column distribution."""
+
+    def __init__(self, n, nb, P, rank):
+        assert nb % 64 == 0 and 1024 % nb == 0, "nb must be 64/128/256/512/1024"
+        self.n, self.nb, self.P, self.rank = int(n), int(nb), int(P), int(rank)
+        self.nblk = -(-self.n // self.nb)
+        self.my_blocks = [j for j in range(self.nblk) if j % self.P == self.rank]
+        self.ncols_local = max(1, len(self.my_blocks)) * self.nb
+        self.ld = self.ncols_local            # multiple of 64 => 16-element aligned
+
+    def owner(self, j):
+        return j % self.P
+
+    def local_col(self, j):
+        return (j // self.P) * self.nb
+
+    def k0(self, j):
+        return j * self.nb
+
+    def kb(self, j):
+        return min(self.nb, self.n - j * self.nb)
+
+    def first_local_block_after(self, k):
+        """Index into my_blocks of the first local block whose global index is > k."""
+        for jl, j in enumerate(self.my_blocks):
+            if j > k:
+                return jl
+        return None
+
+
+def default_nb(n):
+    env = os.environ.get("GPX_POTRF_NB")
+    if env:
+        return int(env)
+    if n <= 2048:
+        return 128
+    if n <= 16384:
+        return 256
+    return 512
+
+
+# ------------------------------------------------------------------- HIP ops --
+class HipOps(object):
+    """Device operations through the C ABI, on torch CUDA tensors (torch is used
+    for memory, streams and torch.distributed only)."""
+
+    def __init__(self, dtype_id, device):
+        import torch
+        self.torch = torch
+        self.lib = _lib.load()
+        self.dtype_id = dtype_id
+        self.tdtype = torch.float64 if dtype_id == _lib.F64 else torch.float32
+        self.es = 8 if dtype_id == _lib.F64 else 4
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        _lib.check(self.lib.gpx_set_device(device))
+        self.main = torch.cuda.Stream(device=self.device)
+        self.side = torch.cuda.Stream(device=self.device)
+
+    # memory
+    def empty(self, shape, dtype=None):
+        return self.torch.empty(shape, dtype=dtype or self.tdtype, device=self.device)
+
+    def zeros(self, shape, dtype=None):
+        return self.torch.zeros(shape, dtype=dtype or self.tdtype, device=self.device)
+
+    def from_host(self, a):
+        return self.torch.as_tensor(np.ascontiguousarray(a)).to(self.device, dtype=self.tdtype)
+
+    def to_host(self, t):
+        return t.detach().to("cpu").numpy().astype(np.float64)
+
+    def copy_(self, dst, src, stream):
+        with self.torch.cuda.stream(stream):
+            dst.copy_(src)
+
+    # streams / events
+    def record(self, stream):
+        e = self.torch.cuda.Event()
+        e.record(stream)
+        return e
+
+    def wait(self, stream, event):
+        stream.wait_event(event)
+
+    def sync(self):
+        self.torch.cuda.synchronize(self.device)
+
+    def stream_ctx(self, stream):
+        return self.torch.cuda.stream(stream)
+
+    def _p(self, t, off_elems=0):
+        return ctypes.c_void_p(t.data_ptr() + off_elems * self.es)
+
+    @staticmethod
+    def _s(stream):
+        return ctypes.c_void_p(stream.cuda_stream)
+
+    # kernels
+    def kmat_block(self, A, ld, x, n, d, r0, cl, kb, kernel_id, params, s, stream):
+        """A[r0:n, cl:cl+kb] <- K(x[r0:n], x[r0:r0+kb]) + s^2 on the block's diagonal (lower tiles)."""
+        p = np.ascontiguousarray(params, dtype=np.float64)
+        _lib.check(self.lib.gpx_d_kmat(self.dtype_id, kernel_id, _lib.K, self._p(x, r0 * d), n - r0,
+                                       self._p(x, r0 * d), kb, d, _lib.dptr(p), float(s) * float(s),
+                                       _lib.LOWER, self._p(A, r0 * ld + cl), ld, self._s(stream)))
+
+    def potrf_panel(self, A, ld, n, r0, c0, kb, info, stream):
+        _lib.check(self.lib.gpx_d_potrf_panel(self.dtype_id, self._p(A), ld, n, r0, c0, kb,
+                                              ctypes.c_void_p(info.data_ptr()), self._s(stream)))
+
+    def pack_panel(self, A, ld, r0, c0, rows, kb, buf, nb, stream):
+        with self.torch.cuda.stream(stream):
+            buf.view(-1)[: rows * nb].view(rows, nb)[:, :kb].copy_(A[r0:r0 + rows, c0:c0 + kb])
+
+    def syrk_bc(self, A, ld, n, row_begin, cl0, cl1, buf, ldp, k0, kb, nb, P, rank, stream):
+        _lib.check(self.lib.gpx_d_syrk_bc(self.dtype_id, n, row_begin, self._p(A), ld, cl0, cl1,
+                                          self._p(buf), ldp, k0, kb, nb, P, rank, self._s(stream)))
+
+    def trsv_cols(self, A, ld, r0, cl, nrows, ncols, w, z, stream):
+        """Trapezoid forward solve on block column (r0, cl): z[r0:r0+ncols], w[r0+ncols:] updated."""
+        _lib.check(self.lib.gpx_d_trsv_lower_cols(self.dtype_id, self._p(A, r0 * ld + cl), nrows, ld,
+                                                  ncols, self._p(w, r0), self._p(z, r0), self._s(stream)))
+
+    def panel_gemv_t(self, A, ld, r0, cl, rows, ncols, x, x_off, y, work, stream):
+        _lib.check(self.lib.gpx_d_panel_gemv_t(self.dtype_id, self._p(A, r0 * ld + cl), ld, rows, ncols,
+                                               self._p(x, x_off), self._p(y),
+                                               ctypes.c_void_p(work.data_ptr()), self._s(stream)))
+
+    def trsv_diag_t(self, A, ld, r0, cl, kb, b, x, x_off, stream):
+        """x[x_off:x_off+kb] <- L_jj^-T b for the kb x kb diagonal block at (r0, cl)."""
+        _lib.check(self.lib.gpx_d_trsv_lower(self.dtype_id, self._p(A, r0 * ld + cl), kb, ld, self._p(b),
+                                             self._p(x, x_off), 1, self._s(stream)))
+
+    def logdet_block(self, A, ld, r0, cl, kb, out, stream):
+        _lib.check(self.lib.gpx_d_logdet_chol(self.dtype_id, self._p(A, r0 * ld + cl), kb, ld,
+                                              ctypes.c_void_p(out.data_ptr()), self._s(stream)))
+
+    def dot(self, a, b, n, out, stream):
+        _lib.check(self.lib.gpx_d_dot(self.dtype_id, self._p(a), self._p(b), n,
+                                      ctypes.c_void_p(out.data_ptr()), self._s(stream)))
+
+    def mean(self, kernel_id, xo, m0, m1, x, n, d, params, alpha, out, stream):
+        p = np.ascontiguousarray(params, dtype=np.float64)
+        if m1 > m0:
+            _lib.check(self.lib.gpx_d_mean(self.dtype_id, kernel_id, self._p(xo, m0 * d), m1 - m0,
+                                           self._p(x), n, d, _lib.dptr(p), self._p(alpha),
+                                           self._p(out, m0), self._s(stream)))
+
+
+class TorchComm(object):
+    """torch.distributed collectives on flat slices (backend nccl = RCCL on GPUs, gloo in tests)."""
+
+    def __init__(self, dist, to_tensor=None):
+        self.dist = dist
+        self.rank = dist.get_rank()
+        self.world = dist.get_world_size()
+        self.to_tensor = to_tensor or (lambda a: a)
+
+    def broadcast(self, arr, start, count, src):
+        if self.world > 1 and count > 0:
+            self.dist.broadcast(self.to_tensor(arr).view(-1)[start:start + count], src=src)
+
+    def all_reduce_sum(self, arr, start, count):
+        if self.world > 1 and count > 0:
+            self.dist.all_reduce(self.to_tensor(arr).view(-1)[start:start + count])
+
+    def all_reduce_max(self, arr, start, count):
+        if self.world > 1 and count > 0:
+            self.dist.all_reduce(self.to_tensor(arr).view(-1)[start:start + count],
+                                 op=self.dist.ReduceOp.MAX)
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+
+
+class LocalComm(object):
+    """Single-rank stand-in (world size 1): every collective is a no-op."""
+    rank, world = 0, 1
+
+    def broadcast(self, arr, start, count, src):
+        pass
+
+    def all_reduce_sum(self, arr, start, count):
+        pass
+
+    def all_reduce_max(self, arr, start, count):
+        pass
+
+    def barrier(self):
+        pass
+
+
+# ------------------------------------------------------------ the distributed GP --
+class DistributedGP(object):
+    """One GP spread over P ranks (this object = one rank's share)."""
+
+    def __init__(self, ops, comm, n, d, kernel_id=_lib.KERNEL_GAUSSIAN, nb=None):
+        self.ops, self.comm = ops, comm
+        self.n, self.d, self.kernel_id = int(n), int(d), kernel_id
+        self.lay = BlockCyclic(n, nb or default_nb(n), comm.world, comm.rank)
+        lay = self.lay
+        self.A = ops.empty((lay.n, lay.ld))
+        self.pbuf = [ops.empty((lay.n, lay.nb)), ops.empty((lay.n, lay.nb))]
+        self.w = ops.empty((lay.n,))
+        self.z = ops.empty((lay.n,))
+        self.alpha = ops.empty((lay.n,))
+        self.tmp = ops.empty((lay.nb,))
+        self.work = ops.empty((max(1, -(-lay.n // 256)) * lay.nb,), dtype=ops.torch.float64)
+        self.scal = ops.zeros((4,), dtype=ops.torch.float64)    # [0] logdet block [1] y^T alpha
+        self.info = ops.zeros((4,), dtype=ops.torch.int32)
+        self.x = self.y = None
+        self.logdet = None
+        self.yta = None
+        self.info_host = None
+
+    def set_data(self, x, y):
+        self.x = self.ops.from_host(np.asarray(x).reshape(self.n, self.d))
+        self.y = self.ops.from_host(np.asarray(y).reshape(self.n))
+        self.ops.sync()
+
+    # -- kernel matrix: every rank builds the block columns it owns (no exchange) --
+    def build(self, params, s):
+        ops, lay = self.ops, self.lay
+        for j in lay.my_blocks:
+            ops.kmat_block(self.A, lay.ld, self.x, lay.n, self.d, lay.k0(j), lay.local_col(j), lay.kb(j),
+                           self.kernel_id, params, s, ops.main)
+
+    # -- factorisation --
+    def _factor_and_bcast(self, j, buf, stream):
+        ops, lay, comm = self.ops, self.lay, self.comm
+        r0, kb = lay.k0(j), lay.kb(j)
+        rows = lay.n - r0
+        if lay.owner(j) == comm.rank:
+            cl = lay.local_col(j)
+            ops.potrf_panel(self.A, lay.ld, lay.n, r0, cl, kb, self.info, stream)
+            ops.pack_panel(self.A, lay.ld, r0, cl, rows, kb, buf, lay.nb, stream)
+        with ops.stream_ctx(stream):
+            comm.broadcast(buf, 0, rows * lay.nb, lay.owner(j))
+
+    def factor(self):
+        ops, lay, comm = self.ops, self.lay, self.comm
+        S, Q = ops.main, ops.side
+        ops.wait(Q, ops.record(S))                       # the kernel build is done
+        self._factor_and_bcast(0, self.pbuf[0], Q)
+        ep = ops.record(Q)
+        readers_done = [None, None]                      # last update that read pbuf[i]
+        for k in range(lay.nblk):
+            k0, kb = lay.k0(k), lay.kb(k)
+            r = k0 + kb
+            ops.wait(S, ep)                              # panel k is here, in pbuf[k % 2]
+            if r >= lay.n:
+                break
+            P_k = self.pbuf[k % 2]
+            nxt = k + 1
+            own_next = lay.owner(nxt) == comm.rank
+            jl_first = lay.first_local_block_after(k)
+            if own_next:
+                cl = lay.local_col(nxt)
+                ops.syrk_bc(self.A, lay.ld, lay.n, r, cl, cl + lay.nb, P_k, lay.nb, k0, kb, lay.nb,
+                            lay.P, lay.rank, S)
+                ops.wait(Q, ops.record(S))
+                jl_first = lay.first_local_block_after(nxt)
+            if readers_done[nxt % 2] is not None:
+                ops.wait(Q, readers_done[nxt % 2])       # update k-1 no longer reads that buffer
+            self._factor_and_bcast(nxt, self.pbuf[nxt % 2], Q)
+            ep = ops.record(Q)
+            if jl_first is not None:
+                ops.syrk_bc(self.A, lay.ld, lay.n, r, jl_first * lay.nb, lay.ncols_local, P_k, lay.nb, k0,
+                            kb, lay.nb, lay.P, lay.rank, S)
+            readers_done[k % 2] = ops.record(S)
+        ops.wait(S, ops.record(Q))
+
+    # -- solves: alpha = K^-1 y, replicated on every rank at the end --
+    def solve(self):
+        ops, lay, comm = self.ops, self.lay, self.comm
+        S = ops.main
+        with ops.stream_ctx(S):
+            if comm.rank == 0:
+                ops.copy_(self.w, self.y, S)
+            else:
+                self.w.zero_()
+            for j in range(lay.nblk):                    # forward: L z = y
+                r0, kb = lay.k0(j), lay.kb(j)
+                comm.all_reduce_sum(self.w, r0, kb)
+                if lay.owner(j) == comm.rank:
+                    ops.trsv_cols(self.A, lay.ld, r0, lay.local_col(j), lay.n - r0, kb, self.w, self.z, S)
+            for j in reversed(range(lay.nblk)):          # backward: L^T alpha = z
+                r0, kb = lay.k0(j), lay.kb(j)
+                if lay.owner(j) == comm.rank:
+                    cl = lay.local_col(j)
+                    ops.copy_(self.tmp[:kb], self.z[r0:r0 + kb], S)
+                    below = lay.n - r0 - kb
+                    if below > 0:
+                        ops.panel_gemv_t(self.A, lay.ld, r0 + kb, cl, below, kb, self.alpha, r0 + kb,
+                                         self.tmp, self.work, S)
+                    ops.trsv_diag_t(self.A, lay.ld, r0, cl, kb, self.tmp, self.alpha, r0, S)
+                comm.broadcast(self.alpha, r0, kb, lay.owner(j))
+
+    def reduce_scalars(self):
+        ops, lay, comm = self.ops, self.lay, self.comm
+        S = ops.main
+        with ops.stream_ctx(S):
+            acc = ops.zeros((2,), dtype=ops.torch.float64)
+            for j in lay.my_blocks:
+                ops.logdet_block(self.A, lay.ld, lay.k0(j), lay.local_col(j), lay.kb(j), self.scal, S)
+                acc[0:1] += self.scal[0:1]
+            ops.dot(self.y, self.alpha, lay.n, self.scal[1:2], S)
+            comm.all_reduce_sum(acc, 0, 1)
+            # LAPACK info: the FIRST failing minor over all ranks; 0 when none failed
+            big = 2 ** 30
+            info = self.info[0:1]
+            key = ((big - info) * (info > 0)).to(ops.torch.int32)
+            comm.all_reduce_max(key, 0, 1)
+        ops.sync()
+        host = ops.to_host(acc)
+        self.logdet = float(host[0])
+        self.yta = float(ops.to_host(self.scal)[1])
+        k = int(ops.to_host(key)[0])
+        self.info_host = 0 if k == 0 else big - k
+
+    def fit(self, params, s):
+        with self.ops.stream_ctx(self.ops.main):
+            self.info.zero_()
+        self.build(params, s)
+        self.factor()
+        self.solve()
+        self.reduce_scalars()
+        return self.log_lh
+
+    @property
+    def log_lh(self):
+        # gp/gp.py:362-365 and gp_c.pyx:22-29
+        if self.info_host != 0 or not (self.logdet >= _lib.MIN_LOG):
+            return -np.inf
+        return -0.5 * self.yta - 0.5 * self.logdet - 0.5 * self.n * math.log(2 * math.pi)
+
+    def mean(self, xo_dev, m, params, out):
+        """Posterior mean at m test points: every rank evaluates a slice, one all-reduce."""
+        ops, comm = self.ops, self.comm
+        S = ops.main
+        per = -(-m // comm.world)
+        m0, m1 = min(m, comm.rank * per), min(m, (comm.rank + 1) * per)
+        with ops.stream_ctx(S):
+            out.zero_()
+            ops.mean(self.kernel_id, xo_dev, m0, m1, self.x, self.n, self.d, params, self.alpha, out, S)
+            comm.all_reduce_sum(out, 0, m)
+        return out
+
+
+# ------------------------------------------------------------------ benchmark --
+def bench_distributed(args, X, y, Xo, params, s, dtype_id):
+    """bench.py's N > 1 leg: same workload as N = 1 (strong scaling), one rank per GPU."""
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ["RANK"])
+    world = int(os.environ["WORLD_SIZE"])
+    local_rank = int(os.environ.get("LOCAL_RANK", rank))
+    torch.cuda.set_device(local_rank)
+    backend = os.environ.get("GPX_DIST_BACKEND", "nccl")
+    dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                            device_id=torch.device("cuda", local_rank) if backend == "nccl" else None)
+    ops = HipOps(dtype_id, local_rank)
+    comm = TorchComm(dist)
+    N, d, m = args.n, args.d, args.m
+    gp = DistributedGP(ops, comm, N, d)
+    gp.set_data(X, y)
+    xo_dev = ops.from_host(Xo)
+    mean_dev = ops.empty((m,))
+
+    def step():
+        llh = gp.fit(params, s)
+        gp.mean(xo_dev, m, params, mean_dev)
+        ops.sync()
+        return llh
+
+    for _ in range(args.warmup):
+        step()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        llh = step()
+    dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=ops.device)
+    dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    sec = float(elapsed.item()) / args.steps
+    mean_host = ops.to_host(mean_dev)
+    assert np.isfinite(llh) and np.isfinite(mean_host).all()
+    peak = 78.6 if dtype_id == _lib.F64 else 157.3
+    tfl = (N ** 3 / 3.0) / sec / 1e12
+    result = {
+        "metric": "GP fit+predict wall-clock (kernel build + Cholesky + solve + log_lh + posterior mean)",
+        "value": round(sec, 4), "unit": "s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(sec * 1e3, 2), "higher_is_better": False, "scaling": "strong",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "N=%d d=%d RBF(GaussianKernel) %s, m=%d test points, h=1 w=0.5*sqrt(d) s=1"
+                               % (N, d, args.dtype, m), "N": N, "d": d, "m": m,
+                   "parallelism": "1-D block-cyclic block columns (nb=%d) over %d GPUs, RCCL panel broadcast"
+                                  % (gp.lay.nb, world)},
+        "log_lh": llh,
+        "whole_step_tflops_n3_over_3": round(tfl, 3),
+        "roofline": {"bound": "mfma", "kernel": "gemm_nt_fast_kernel (trailing update, all ranks)",
+                     "achieved": round(tfl, 3), "peak": peak * world, "unit": "TFLOP/s",
+                     "frac": round(tfl / (peak * world), 4), "traffic": None,
+                     "note": "whole-step N^3/3 flops over wall-clock, all GPUs; per-kernel events are "
+                             "reported by the 1-GPU run"},
+    }
+    dist.destroy_process_group()
+    return result

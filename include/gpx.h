@@ -189,6 +189,19 @@ int gpx_d_tril(int dtype, void *A, int64_t n, int64_t lda, void *stream);
 int gpx_d_trsv_lower(int dtype, const void *L, int64_t n, int64_t ldl, void *b,
                      void *x, int transpose, void *stream);
 
+/* Distributed-solve building blocks (block columns live on different GPUs).
+ * gpx_d_trsv_lower_cols: forward substitution through a trapezoid -- an
+ * ncols x ncols lower triangle on top of n - ncols further rows (one factored
+ * block column, rows from its diagonal down): x[0:ncols] <- solution,
+ * b[ncols:n] -= L[ncols:n, 0:ncols] x.  b is scratch, x != b.
+ * gpx_d_panel_gemv_t: y[c] -= sum_r Lp[r, c] * x[r] for c < ncols, r < rows (the
+ * sub-diagonal part of a block column, transposed); work: cdiv(rows, 256) * ncols
+ * doubles of DEVICE scratch.  Deterministic (no atomics). */
+int gpx_d_trsv_lower_cols(int dtype, const void *L, int64_t n, int64_t ldl, int64_t ncols,
+                          void *b, void *x, void *stream);
+int gpx_d_panel_gemv_t(int dtype, const void *Lp, int64_t ldl, int64_t rows, int64_t ncols,
+                       const void *x, void *y, void *work, void *stream);
+
 /* X (m x n, ldx) <- X * L^-T  : rows of X are right-hand sides; i.e. solves
  * L * x_row^T = b_row^T for every row.  With X = Kxox this yields V^T where
  * V = L^-1 Kxxo, the factor of the posterior covariance (gp/gp.py:622-625). */
