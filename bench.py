@@ -40,9 +40,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=65536)
-    ap.add_argument("--d", type=int, default=32)
-    ap.add_argument("--m", type=int, default=1000)
+    ap.add_argument("--problem-n", dest="n", type=int, default=65536)
+    ap.add_argument("--problem-d", dest="d", type=int, default=32)
+    ap.add_argument("--problem-m", dest="m", type=int, default=1000)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--cpu-sample-n", type=int, default=6144)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -113,6 +113,8 @@ def main():
     lib = _lib.load()
     if _lib.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: " + _lib.last_error())
+    if os.environ.get("GPX_BENCH_SINGLE_DEVICE"):
+        local_rank = 0
     _lib.check(lib.gpx_set_device(local_rank))
 
     N, d, m = args.n, args.d, args.m

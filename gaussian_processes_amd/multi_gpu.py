@@ -394,6 +394,8 @@ def bench_distributed(args, X, y, Xo, params, s, dtype_id):
     rank = int(os.environ["RANK"])
     world = int(os.environ["WORLD_SIZE"])
     local_rank = int(os.environ.get("LOCAL_RANK", rank))
+    if os.environ.get("GPX_BENCH_SINGLE_DEVICE"):      # rehearsal on a 1-GPU box (use with gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     backend = os.environ.get("GPX_DIST_BACKEND", "nccl")
     dist.init_process_group(backend=backend, rank=rank, world_size=world,
