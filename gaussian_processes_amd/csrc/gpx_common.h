@@ -64,9 +64,10 @@ struct KParams {
 int make_kparams(int kernel, int member, const double *params, double diag_add, KParams *out);
 
 // internal (non-ABI) helpers shared between translation units
+// C = beta * C + alpha * A * B^T with beta = 1 (default) or 0 (beta0 != 0: C is not read)
 int gemm_nt(int dtype, int64_t M, int64_t N, int64_t K, const void *A, int64_t lda, const void *B,
             int64_t ldb, void *C, int64_t ldc, double alpha, int tri, int64_t row0, int64_t col0,
-            hipStream_t st);
+            hipStream_t st, int beta0 = 0);
 // X[r, 0:jb] <- X[r, 0:jb] * Ljj^-T for rows r in [0, rows); Ljj = jb x jb lower block
 int trsm_rows(int dtype, void *X, int64_t ldx, int64_t rows, const void *Ljj, int64_t ldl, int jb,
               hipStream_t st);

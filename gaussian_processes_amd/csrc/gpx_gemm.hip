@@ -78,39 +78,43 @@ __device__ __forceinline__ Chunk16 load_chunk(const T *__restrict__ base, int64_
     return c;
 }
 
-// Epilogue shared by both kernels: C += alpha * acc for one wave's 64 x 64 tile.
-// All 16 loads of an MFMA tile row are issued before the first use (clamped
-// addresses keep them unconditional), so a lane pays 4 memory round trips per
-// tile instead of 64.
-template <typename T>
-__device__ __forceinline__ void store_wave_tile(typename MF<T>::acc_t (&acc)[4][4], T *__restrict__ C,
+// Epilogue shared by both kernels: C = beta * C + alpha * acc (beta = 1, or 0 when
+// `beta0`) for one wave's 64 x (16 * NTW) tile.  The 32 loads of two MFMA tile rows
+// are issued before the first use (clamped addresses keep them unconditional), so a
+// lane pays 2 memory round trips per tile instead of 64.
+template <typename T, int NTW>
+__device__ __forceinline__ void store_wave_tile(typename MF<T>::acc_t (&acc)[4][NTW], T *__restrict__ C,
                                                 int64_t ldc, int64_t M, int64_t N, int64_t r_base,
                                                 int64_t c_base, int lane, T alpha, int tri,
-                                                int64_t row0, int64_t col0)
+                                                int64_t row0, int64_t col0, int beta0)
 {
     const int ccol = lane & 15;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        T cv[4][4];
+    for (int ib = 0; ib < 4; ib += 2) {
+        T cv[2][NTW][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int64_t gc = min(c_base + j * 16 + ccol, N - 1);
+        for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t gr = min(r_base + i * 16 + MF<T>::row(lane, r), M - 1);
-                cv[j][r] = C[gr * ldc + gc];
+            for (int j = 0; j < NTW; ++j) {
+                const int64_t gc = min(c_base + j * 16 + ccol, N - 1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t gr = min(r_base + (ib + ii) * 16 + MF<T>::row(lane, r), M - 1);
+                    cv[ii][j][r] = beta0 ? (T)0 : C[gr * ldc + gc];
+                }
             }
-        }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int64_t gc = c_base + j * 16 + ccol;
+        for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t gr = r_base + i * 16 + MF<T>::row(lane, r);
-                if (gr < M && gc < N && !(tri == GPX_LOWER && row0 + gr < col0 + gc))
-                    C[gr * ldc + gc] = fma(alpha, acc[i][j][r], cv[j][r]);
+            for (int j = 0; j < NTW; ++j) {
+                const int64_t gc = c_base + j * 16 + ccol;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t gr = r_base + (ib + ii) * 16 + MF<T>::row(lane, r);
+                    if (gr < M && gc < N && !(tri == GPX_LOWER && row0 + gr < col0 + gc))
+                        C[gr * ldc + gc] = fma(alpha, acc[ib + ii][j][r], cv[ii][j][r]);
+                }
             }
-        }
     }
 }
 
@@ -211,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(int64_t M, int64_t N, i
     }
 
     // epilogue: C += alpha * acc  (16 lanes = 16 consecutive columns = one 128-B / 64-B segment)
-    store_wave_tile<T>(acc, C, ldc, M, N, bm0 + wr * 64, bn0 + wc * 64, lane, alpha, tri, row0, col0);
+    store_wave_tile<T, 4>(acc, C, ldc, M, N, bm0 + wr * 64, bn0 + wc * 64, lane, alpha, tri, row0, col0, 0);
 }
 
 // number of C elements a launch updates (all of M x N, or those with row0+i >= col0+j)
@@ -263,11 +267,17 @@ int launch_gemm_nt(int64_t M, int64_t N, int64_t K, const void *A, int64_t lda, 
 //   given to the blocks with blockIdx % 8 == p % 8, so that the 32 blocks that
 //   run together on one XCD share 4 A-panels and 8 B-panels in that XCD's L2.
 // ===========================================================================
-constexpr int F_BM = 256, F_BN = 128;
-constexpr int F_ROWS = F_BM + F_BN;            // 384 tile rows per stage
-constexpr int F_STAGE = F_ROWS * G_ROWB;       // 49,152 B
+// BN = 128: the square-ish work-horse.  BN = 64: the same pipeline on 256 x 64 tiles
+// for the skinny (N <= 64) products of the panel factorisation.
+constexpr int F_BM = 256;
 constexpr int F_NST = 3;
-constexpr int F_SMEM = F_NST * F_STAGE;        // 147,456 B
+template <int BN> struct FGeo {
+    static constexpr int ROWS = F_BM + BN;          // tile rows per stage: 384 / 320
+    static constexpr int STAGE = ROWS * G_ROWB;     // 49,152 / 40,960 B
+    static constexpr int SMEM = F_NST * STAGE;      // 147,456 / 122,880 B
+    static constexpr int PW = ROWS / 64;            // DMA pieces (1 KiB) per wave and stage: 6 / 5
+    static constexpr int NTW = BN / 32;             // 16-column MFMA tiles per wave: 4 / 2
+};
 
 // chunk swizzle of tile row r: a permutation of (r >> 1) & 7 chosen so that every
 // 16-lane group of a ds_read_b128 fragment read hits 16 distinct 16-B slots
@@ -285,23 +295,34 @@ __device__ __forceinline__ int f_swz(int r) { return (0x64753120u >> (4 * ((r >>
 struct GemmMap {
     int64_t boff, cbase, nb, pm1nb, brows;
     int np, a, b, R;
+    // start-up stagger: the first `stag_blocks` workgroups delay their start by
+    // blockIdx * stag_cycles / stag_blocks shader cycles, so that the C read-modify-write
+    // epilogues of the 256 CUs (which otherwise all fall together, stalling the chip on
+    // one HBM burst per round of tiles) spread evenly over a tile time.
+    int stag_blocks, stag_cycles;
+    // diagnostic: when non-null, wave 0 of every workgroup stores 4 s_memtime stamps
+    // (start, first barrier passed, k-loop done, epilogue done) at stamps[4 * blockIdx]
+    unsigned long long *stamps;
+    int ablate;   // diagnostic (GPX_GEMM_ABLATE): 1 no barrier/vmcnt, 2 no DMA in loop, 4 no LDS reads in loop
 };
+static unsigned long long *g_gemm_stamps = nullptr;
 
 typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
 #define GPX_DSR(dst, addr, off) \
     asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
 
-template <typename T>
+template <typename T, int BN>
 __global__ __launch_bounds__(512, 2) void gemm_nt_fast_kernel(int64_t M, int64_t N, int64_t K,
                                                               const T *__restrict__ A, int64_t lda,
                                                               const T *__restrict__ B, int64_t ldb,
                                                               T *__restrict__ C, int64_t ldc, T alpha,
                                                               int tri, int64_t row0, int64_t col0,
-                                                              GemmMap fm)
+                                                              GemmMap fm, int beta0)
 {
     typedef typename MF<T>::acc_t acc_t;
     constexpr int EPK = MF<T>::EPK;
     constexpr int SUB = EPK / 4;
+    constexpr int F_STAGE = FGeo<BN>::STAGE, PW = FGeo<BN>::PW, NTW = FGeo<BN>::NTW;
 
     // ---- block -> tile (XCD-aware patch order) ----
     const int bid = blockIdx.x;
@@ -323,7 +344,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_fast_kernel(int64_t M, int64_t
         pb_c = pc; pb_r = fm.b + fm.a * pc + (patch - cum(pc));
     }
     const int64_t bm0 = ((int64_t)pb_r * 4 + (within >> 3)) * F_BM;
-    const int64_t bn0 = ((int64_t)pb_c * 8 + (within & 7)) * F_BN;
+    const int64_t bn0 = ((int64_t)pb_c * 8 + (within & 7)) * BN;
     if (bm0 >= M || bn0 >= N) return;
     const int64_t cshift = ((fm.cbase + bn0) / fm.nb) * fm.pm1nb;   // same for the tile's 128 columns
     col0 += cshift;
@@ -335,13 +356,21 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_fast_kernel(int64_t M, int64_t
     const int lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
 
-    // ---- DMA source pointers: wave w owns pieces 6w .. 6w+5 (1 KiB = 8 rows each) of every stage ----
-    const unsigned char *gsrc[6];
+    unsigned long long st0 = 0, st1 = 0, st2 = 0;
+    if (fm.stamps) st0 = __builtin_amdgcn_s_memtime();
+    if (bid < fm.stag_blocks) {
+        const unsigned long long target = (unsigned long long)bid * (unsigned)fm.stag_cycles / (unsigned)fm.stag_blocks;
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0 < target) __builtin_amdgcn_s_sleep(16);
+    }
+
+    // ---- DMA source pointers: wave w owns pieces PW*w .. PW*w + PW-1 (1 KiB = 8 rows each) of every stage ----
+    const unsigned char *gsrc[PW];
     {
         const int r_in = lane >> 3, c = lane & 7;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const int tr = 8 * (wave * 6 + j) + r_in;          // tile row 0..383
+        for (int j = 0; j < PW; ++j) {
+            const int tr = 8 * (wave * PW + j) + r_in;         // tile row 0 .. ROWS-1
             const int g = c ^ f_swz(tr);                       // global 16-B chunk held by LDS chunk c
             if (tr < F_BM) {
                 const int64_t r = min(bm0 + tr, M - 1);
@@ -353,32 +382,33 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_fast_kernel(int64_t M, int64_t
         }
     }
     auto issue = [&](int kt, int stage) {
-        unsigned char *dst = smem + stage * F_STAGE + (wave * 6) * 1024;
+        unsigned char *dst = smem + stage * F_STAGE + (wave * PW) * 1024;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
+        for (int j = 0; j < PW; ++j) {
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void *)(gsrc[j] + (size_t)kt * G_ROWB),
                 (__attribute__((address_space(3))) void *)(dst + j * 1024), 16, 0, 0);
         }
     };
 
-    acc_t acc[4][4];
+    acc_t acc[4][NTW];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NTW; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[i][j][r] = (T)0;
 
     const int nk = (int)(K / EPK);
+    // three stages in flight before the first wait
     issue(0, 0);
     if (nk > 1) issue(1, 1);
+    if (nk > 2) issue(2, 2);
 
     // Fragment reads are inline asm: hipcc cannot prove that the in-flight LDS-DMA
     // writes (other stages) do not alias them and would otherwise drain vmcnt(0)
-    // before every k-step's first ds_read.  Ordering is by hand: the counted vmcnt
-    // + barrier makes the stage visible, lgkmcnt(0) + sched_barrier fences the
-    // MFMAs behind the reads.
+    // before every k-step's first ds_read.  Ordering is by hand (counted vmcnt /
+    // lgkmcnt + raw barrier + sched_barrier).
     // per-lane read address: row (lane & 15) of a 16-row MFMA tile, chunks 2q, 2q+1 swizzled
     const int q = lane >> 4;
     const int fl = f_swz(lane & 15);
@@ -386,62 +416,132 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_fast_kernel(int64_t M, int64_t
     const unsigned rd0 = (unsigned)((lane & 15) * G_ROWB + ((2 * q) ^ fl) * 16);
     const unsigned rd1 = (unsigned)((lane & 15) * G_ROWB + ((2 * q + 1) ^ fl) * 16);
     const unsigned a_base = lds0 + (unsigned)((wr * 64) * G_ROWB);
-    const unsigned b_base = lds0 + (unsigned)((F_BM + wc * 64) * G_ROWB);
+    const unsigned b_base = lds0 + (unsigned)((F_BM + wc * (BN / 2)) * G_ROWB);
 
+    // Schedule of one k-step.  R0 = first-half fragments (MFMA sub-steps 0..H-1),
+    // R1 = second half.  Every memory instruction is issued BETWEEN groups of four
+    // MFMAs, so that its issue cost (an LDS-DMA costs the wave ~60 cycles) falls into
+    // the 256 cycles the matrix pipe needs for the group before it:
+    //   wait R0 | 8 x { 4 MFMA(R0) ; ds_read R1[g] } | wait R1 | wait stage kt+1 | barrier |
+    //   8 x { 4 MFMA(R1) ; DMA piece g of stage kt+3 -> buffer kt%3 ; ds_read R0(kt+1)[g] }
+    constexpr int H = SUB / 2;
+    u4_t r0a[4], r0b[4], r1a[4], r1b[4];
+    auto issue1 = [&](int kt, int stage, int j) {
+        unsigned char *dst = smem + stage * F_STAGE + (wave * PW + j) * 1024;
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void *)(gsrc[j] + (size_t)kt * G_ROWB),
+            (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    };
+#define GPX_SLOT_READ(g, RA, RB, AA, AB)                                                        \
+    do {                                                                                        \
+        switch (g) {                                                                            \
+        case 0: GPX_DSR(RA[0], AA, 0); break;    case 1: GPX_DSR(RB[0], AB, 0); break;          \
+        case 2: GPX_DSR(RA[1], AA, 2048); break; case 3: GPX_DSR(RB[1], AB, 2048); break;       \
+        case 4: GPX_DSR(RA[2], AA, 4096); break;                                                \
+        case 5: if (NTW > 2) GPX_DSR(RB[2], AB, 4096); break;                                   \
+        case 6: GPX_DSR(RA[3], AA, 6144); break;                                                \
+        case 7: if (NTW > 2) GPX_DSR(RB[3], AB, 6144); break;                                   \
+        default: break;                                                                         \
+        }                                                                                       \
+    } while (0)
+
+    // stage 0 landed (this wave's pieces), then everybody's
+    if (PW == 6) {
+        if (nk > 2)       asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (nk == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        if (nk > 2)       asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (nk == 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (fm.stamps) st1 = __builtin_amdgcn_s_memtime();
+    {
+        const unsigned aa0 = a_base + rd0, ab0 = b_base + rd0;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) GPX_SLOT_READ(g, r0a, r0b, aa0, ab0);
+    }
     int stage = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (kt + 2 < nk) {
-            int ns = stage + 2; if (ns >= F_NST) ns -= F_NST;
-            issue(kt + 2, ns);
-        }
         const unsigned so = (unsigned)(stage * F_STAGE);
-        const unsigned aa0 = a_base + so + rd0, aa1 = a_base + so + rd1;
-        const unsigned ab0 = b_base + so + rd0, ab1 = b_base + so + rd1;
-        u4_t ra[4][2], rb[4][2];
-        GPX_DSR(ra[0][0], aa0, 0);    GPX_DSR(ra[0][1], aa1, 0);
-        GPX_DSR(rb[0][0], ab0, 0);    GPX_DSR(rb[0][1], ab1, 0);
-        GPX_DSR(ra[1][0], aa0, 2048); GPX_DSR(ra[1][1], aa1, 2048);
-        GPX_DSR(rb[1][0], ab0, 2048); GPX_DSR(rb[1][1], ab1, 2048);
-        GPX_DSR(ra[2][0], aa0, 4096); GPX_DSR(ra[2][1], aa1, 4096);
-        GPX_DSR(rb[2][0], ab0, 4096); GPX_DSR(rb[2][1], ab1, 4096);
-        GPX_DSR(ra[3][0], aa0, 6144); GPX_DSR(ra[3][1], aa1, 6144);
-        GPX_DSR(rb[3][0], ab0, 6144); GPX_DSR(rb[3][1], ab1, 6144);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        T fa[4][SUB], fb[4][SUB];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            memcpy(&fa[i][0], &ra[i][0], 16);
-            memcpy(&fa[i][SUB / 2], &ra[i][1], 16);
-            memcpy(&fb[i][0], &rb[i][0], 16);
-            memcpy(&fb[i][SUB / 2], &rb[i][1], 16);
-        }
-#pragma unroll
-        for (int s = 0; s < SUB; ++s)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = MF<T>::mfma(fa[i][s], fb[j][s], acc[i][j]);
-        ++stage; if (stage >= F_NST) stage = 0;
-    }
+        const unsigned aa1 = a_base + so + rd1, ab1 = b_base + so + rd1;
+        int nstage = stage + 1; if (nstage >= F_NST) nstage = 0;
+        const unsigned sn = (unsigned)(nstage * F_STAGE);
+        const unsigned aa0 = a_base + sn + rd0, ab0 = b_base + sn + rd0;
+        const bool more1 = kt + 1 < nk, more3 = kt + 3 < nk;
 
-    store_wave_tile<T>(acc, C, ldc, M, N, bm0 + wr * 64, bn0 + wc * 64, lane, alpha, tri, row0, col0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // R0 of this stage is in
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            T ha[4][H], hb[4][H];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { memcpy(&ha[i][0], &r0a[i], 16); memcpy(&hb[i][0], &r0b[i], 16); }
+#pragma unroll
+            for (int ss = 0; ss < H; ++ss)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j) acc[i][j] = MF<T>::mfma(ha[i][ss], hb[j][ss], acc[i][j]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!(fm.ablate & 4)) GPX_SLOT_READ(ss * 4 + i, r1a, r1b, aa1, ab1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // R1 in: this wave is done reading the stage
+        if (more1 && !(fm.ablate & 1)) {
+            if (kt + 2 < nk) {
+                if (PW == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else         asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            T ha[4][H], hb[4][H];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { memcpy(&ha[i][0], &r1a[i], 16); memcpy(&hb[i][0], &r1b[i], 16); }
+#pragma unroll
+            for (int ss = 0; ss < H; ++ss)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j) acc[i][j] = MF<T>::mfma(ha[i][ss], hb[j][ss], acc[i][j]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int g = ss * 4 + i;
+                    if (g < PW && more3 && !(fm.ablate & 2)) issue1(kt + 3, stage, g);  // into the buffer just consumed
+                    if (g < 8 && more1 && !(fm.ablate & 4)) GPX_SLOT_READ(g, r0a, r0b, aa0, ab0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        }
+        stage = nstage;
+    }
+#undef GPX_SLOT_READ
+
+    if (fm.stamps) { __builtin_amdgcn_s_barrier(); st2 = __builtin_amdgcn_s_memtime(); }   // all waves done
+    store_wave_tile<T, NTW>(acc, C, ldc, M, N, bm0 + wr * 64, bn0 + wc * (BN / 2), lane, alpha, tri, row0, col0,
+                            beta0);
+    if (fm.stamps && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long st3 = __builtin_amdgcn_s_memtime();
+        unsigned long long *o = fm.stamps + 4 * (size_t)bid;
+        o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3;
+    }
 }
 #undef GPX_DSR
 
-template <typename T>
+template <typename T, int BN = 128>
 static int launch_gemm_nt_fast(int64_t M, int64_t N, int64_t K, const void *A, int64_t lda,
                                const void *B, int64_t ldb, void *C, int64_t ldc, double alpha, int tri,
                                int64_t row0, int64_t col0, hipStream_t st, const GemmMap *map = nullptr,
-                               double work = -1.0)
+                               double work = -1.0, int beta0 = 0)
 {
+    constexpr int F_SMEM = FGeo<BN>::SMEM;
     static bool attr_done = false;
     if (!attr_done) {
-        GPX_HIP(hipFuncSetAttribute((const void *)gemm_nt_fast_kernel<T>,
+        GPX_HIP(hipFuncSetAttribute((const void *)gemm_nt_fast_kernel<T, BN>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, F_SMEM));
         attr_done = true;
     }
@@ -450,9 +550,9 @@ static int launch_gemm_nt_fast(int64_t M, int64_t N, int64_t K, const void *A, i
         fm = *map;
     } else {
         fm.boff = 0; fm.cbase = 0; fm.nb = (int64_t)1 << 40; fm.pm1nb = 0; fm.brows = N;
-        const int64_t pbr = cdiv(M, 1024), pbc = cdiv(N, 1024);
+        const int64_t pbr = cdiv(M, 1024), pbc = cdiv(N, 8 * BN);
         fm.a = 0; fm.b = 0;
-        if (tri == GPX_LOWER && col0 >= row0) { fm.a = 1; fm.b = (int)((col0 - row0) / 1024); }
+        if (BN == 128 && tri == GPX_LOWER && col0 >= row0) { fm.a = 1; fm.b = (int)((col0 - row0) / 1024); }
         fm.R = (int)pbr - fm.b;
         if (fm.R <= 0) return GPX_OK;                       // nothing at or below the diagonal
         int64_t np = 0;
@@ -465,17 +565,31 @@ static int launch_gemm_nt_fast(int64_t M, int64_t N, int64_t K, const void *A, i
     }
     const int64_t np = fm.np;
     if (np <= 0) return GPX_OK;
+    {
+        // stagger only when the launch runs for several rounds of tiles
+        static const int pct = getenv("GPX_GEMM_STAGGER") ? atoi(getenv("GPX_GEMM_STAGGER")) : 100;
+        const int64_t nkk = K / (128 / (int64_t)sizeof(T));
+        const int64_t tile_cycles = nkk * 8192 * (sizeof(T) == 8 ? 1 : 1) + 40000;
+        fm.stag_blocks = 0; fm.stag_cycles = 0;
+        fm.stamps = g_gemm_stamps;
+        static const int abl = getenv("GPX_GEMM_ABLATE") ? atoi(getenv("GPX_GEMM_ABLATE")) : 0;
+        fm.ablate = abl;
+        if (pct > 0 && np * 32 >= 4 * 256) {
+            fm.stag_blocks = 256;
+            fm.stag_cycles = (int)std::min<int64_t>(tile_cycles * pct / 100, 4000000);
+        }
+    }
     const int64_t blocks = cdiv(np, 8) * 8 * 32;
     ProfScope prof(PC_GEMM, work >= 0 ? work : 2.0 * (double)K * updated_elements(M, N, tri, row0, col0), st);
-    hipLaunchKernelGGL((gemm_nt_fast_kernel<T>), dim3((unsigned)blocks), dim3(512), F_SMEM, st, M, N, K,
-                       (const T *)A, lda, (const T *)B, ldb, (T *)C, ldc, (T)alpha, tri, row0, col0, fm);
+    hipLaunchKernelGGL((gemm_nt_fast_kernel<T, BN>), dim3((unsigned)blocks), dim3(512), F_SMEM, st, M, N, K,
+                       (const T *)A, lda, (const T *)B, ldb, (T *)C, ldc, (T)alpha, tri, row0, col0, fm, beta0);
     GPX_LAUNCH_CHECK();
     return GPX_OK;
 }
 
 int gemm_nt(int dtype, int64_t M, int64_t N, int64_t K, const void *A, int64_t lda, const void *B,
             int64_t ldb, void *C, int64_t ldc, double alpha, int tri, int64_t row0, int64_t col0,
-            hipStream_t st)
+            hipStream_t st, int beta0)
 {
     if (M <= 0 || N <= 0 || K <= 0) return GPX_OK;
     static const bool no_fast = getenv("GPX_GEMM_NO_FAST") != nullptr;
@@ -483,10 +597,20 @@ int gemm_nt(int dtype, int64_t M, int64_t N, int64_t K, const void *A, int64_t l
     const bool fast = !no_fast && K % epk == 0 && lda % ch == 0 && ldb % ch == 0 &&
                       ((uintptr_t)A) % 16 == 0 && ((uintptr_t)B) % 16 == 0;
     if (fast) {
+        if (N <= 64) {
+            if (dtype == GPX_F64)
+                return launch_gemm_nt_fast<double, 64>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0, col0,
+                                                       st, nullptr, -1.0, beta0);
+            return launch_gemm_nt_fast<float, 64>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0, col0, st,
+                                                  nullptr, -1.0, beta0);
+        }
         if (dtype == GPX_F64)
-            return launch_gemm_nt_fast<double>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0, col0, st);
-        return launch_gemm_nt_fast<float>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0, col0, st);
+            return launch_gemm_nt_fast<double>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0, col0, st,
+                                               nullptr, -1.0, beta0);
+        return launch_gemm_nt_fast<float>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0, col0, st, nullptr,
+                                          -1.0, beta0);
     }
+    if (beta0) { set_error("gemm_nt: beta = 0 needs the aligned fast path"); return GPX_ERR_UNSUPPORTED; }
     if (dtype == GPX_F64)
         return launch_gemm_nt<double>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0, col0, st);
     return launch_gemm_nt<float>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0, col0, st);
@@ -543,6 +667,7 @@ int syrk_bc(int dtype, int64_t n, int64_t row_begin, void *Cloc, int64_t ldc, in
             np += cnt;
         }
         fm.np = (int)np;
+        fm.stag_blocks = 0; fm.stag_cycles = 0; fm.stamps = nullptr; fm.ablate = 0;
         if (dtype == GPX_F64)
             return launch_gemm_nt_fast<double>(M, Ncols, kb, A, ldp, Pb, ldp, C, ldc, -1.0, GPX_LOWER,
                                                row_begin, cl0 + (int64_t)rank * nb, st, &fm, work);
@@ -597,4 +722,11 @@ extern "C" int gpx_d_syrk_bc(int dtype, int64_t n, int64_t row_begin, void *Cloc
     const int64_t ch = 16 / (int64_t)esize(dtype);
     GPX_ARG(ldp >= kb && ldp % ch == 0 && ((uintptr_t)Pb) % 16 == 0, "panel must be 16-byte aligned");
     return syrk_bc(dtype, n, row_begin, Cloc, ldc, cl0, cl1, Pb, ldp, k0, kb, nb, P, rank, S(stream));
+}
+
+// diagnostic hook (not declared in gpx.h): per-workgroup s_memtime stamps of the fast GEMM
+extern "C" int gpx_debug_gemm_stamps(void *dev_buffer)
+{
+    g_gemm_stamps = (unsigned long long *)dev_buffer;
+    return GPX_OK;
 }

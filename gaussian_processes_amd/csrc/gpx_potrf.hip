@@ -22,44 +22,91 @@ namespace gpx {
 constexpr int IB = 64;
 constexpr int IBP = IB + 1;   // LDS pitch (elements): conflict-free column walks
 
-// ---- (b) diagonal block: unblocked right-looking Cholesky in LDS ----------
+// ---- (b) diagonal block: unblocked right-looking Cholesky, register resident ----
+// 256 threads hold the 64 x 64 block as 16 x 16 register tiles of 4 x 4 (thread
+// (tr, tc) owns rows 4tr.., columns 4tc..).  Column j of the running matrix goes
+// through a double-buffered 64-entry LDS vector: one barrier per column.  Scaling
+// uses the reciprocal of the pivot's square root, as LAPACK's dpotf2 does.
+// Blocks smaller than 64 are padded with the identity (pivot 1, no effect).
 template <typename T>
 __global__ __launch_bounds__(256) void potrf_diag_kernel(T *__restrict__ blk, int64_t lda, int64_t j0,
                                                          int jb, int *__restrict__ info)
 {
     // blk: the jb x jb diagonal block; j0: its global (0-based) index, for `info`
-    __shared__ T s[IB * IBP];
-    __shared__ T sdiag[IB];
+    __shared__ T colbuf[2][IB];
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < jb * jb; idx += 256) {
-        const int i = idx / jb, c = idx - i * jb;
-        s[i * IBP + c] = (c <= i) ? blk[(int64_t)i * lda + c] : (T)0;
+    const int tr = tid >> 4, tc = tid & 15;
+    T a[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int row = 4 * tr + r, col = 4 * tc + c;
+            T v = (row == col) ? (T)1 : (T)0;
+            if (row < jb && col <= row) v = blk[(int64_t)row * lda + col];
+            a[r][c] = v;
+        }
+    if (tc == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) colbuf[0][4 * tr + r] = a[r][0];
     }
     __syncthreads();
-    for (int j = 0; j < jb; ++j) {
-        const T piv = s[j * IBP + j];
-        if (!(piv > (T)0)) {                       // also catches NaN
-            if (tid == 0 && *info == 0) *info = (int)(j0 + j + 1);
-        }
-        const T ljj = sqrt(piv);
-        if (tid == 0) sdiag[j] = ljj;
-        if (tid > j && tid < jb) s[tid * IBP + j] = s[tid * IBP + j] / ljj;
-        __syncthreads();
-        const int rem = jb - j - 1;
-        for (int idx = tid; idx < rem * rem; idx += 256) {
-            const int ii = idx / rem, cc = idx - ii * rem;
-            if (cc <= ii) {
-                const int i = j + 1 + ii, c = j + 1 + cc;
-                s[i * IBP + c] = fma(-s[i * IBP + j], s[c * IBP + j], s[i * IBP + c]);
+    int cur = 0;
+#pragma unroll 1
+    for (int jt = 0; jt < IB / 4; ++jt) {
+#pragma unroll
+        for (int jo = 0; jo < 4; ++jo) {
+            const int j = 4 * jt + jo;
+            const T piv = colbuf[cur][j];
+            if (j < jb && !(piv > (T)0)) {               // also catches NaN
+                if (tid == 0 && *info == 0) *info = (int)(j0 + j + 1);
             }
+            const T ljj = sqrt(piv);
+            const T rinv = (T)1 / ljj;
+            T li[4], lc[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                li[k] = colbuf[cur][4 * tr + k] * rinv;
+                lc[k] = colbuf[cur][4 * tc + k] * rinv;
+            }
+            if (tc == jt) {                                // owners of column j: store the final L values
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 4 * tr + r;
+                    if (row > j) a[r][jo] = li[r];
+                    else if (row == j) a[r][jo] = ljj;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int row = 4 * tr + r, col = 4 * tc + c;
+                    if (row > j && col > j) a[r][c] = fma(-li[r], lc[c], a[r][c]);
+                }
+            // publish column j + 1 for the next step
+            const int jn = j + 1;
+            if (jn < IB && tc == (jn >> 2)) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    T v = a[r][0];
+                    if ((jn & 3) == 1) v = a[r][1];
+                    if ((jn & 3) == 2) v = a[r][2];
+                    if ((jn & 3) == 3) v = a[r][3];
+                    colbuf[cur ^ 1][4 * tr + r] = v;
+                }
+            }
+            __syncthreads();
+            cur ^= 1;
         }
-        __syncthreads();
     }
-    for (int idx = tid; idx < jb * jb; idx += 256) {
-        const int i = idx / jb, c = idx - i * jb;
-        if (c < i) blk[(int64_t)i * lda + c] = s[i * IBP + c];
-        else if (c == i) blk[(int64_t)i * lda + c] = sdiag[i];
-    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int row = 4 * tr + r, col = 4 * tc + c;
+            if (row < jb && col <= row) blk[(int64_t)row * lda + col] = a[r][c];
+        }
 }
 
 // ---- (c) X[r, 0:jb] <- X[r, 0:jb] * Ljj^-T : one lane per row --------------

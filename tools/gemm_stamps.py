@@ -1,0 +1,33 @@
+"""tools/gemm_stamps.py -- where does a tile of the fast GEMM spend its cycles? (diagnostic)"""
+import ctypes, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gaussian_processes_amd import _lib
+from gaussian_processes_amd.device import DeviceBuffer, sync
+lib = _lib.load()
+lib.gpx_debug_gemm_stamps.argtypes = [ctypes.c_void_p]
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+rng = np.random.RandomState(0)
+A = DeviceBuffer.from_host(rng.randn(M, K))
+C = DeviceBuffer((M, M)).zero()
+nblocks = 4 * 1024 * 1024
+S = DeviceBuffer((nblocks * 4,), np.uint64).zero()
+for rep in range(2):
+    _lib.check(lib.gpx_d_gemm_nt(_lib.F64, M, M, K, -1.0, A.ptr, K, A.ptr, K, C.ptr, M, 1, 0, 0, None))
+sync()
+S.zero()
+lib.gpx_debug_gemm_stamps(S.ptr)
+_lib.check(lib.gpx_d_gemm_nt(_lib.F64, M, M, K, -1.0, A.ptr, K, A.ptr, K, C.ptr, M, 1, 0, 0, None))
+sync()
+lib.gpx_debug_gemm_stamps(None)
+st = S.to_host().reshape(-1, 4).astype(np.int64)
+st = st[st[:, 3] > 0]
+pro, loop, epi = st[:, 1] - st[:, 0], st[:, 2] - st[:, 1], st[:, 3] - st[:, 2]
+print("tiles", len(st), "span cycles", st[:, 3].max() - st[:, 0].min())
+for nm, v in (("prologue", pro), ("k-loop", loop), ("epilogue", epi), ("total", st[:, 3] - st[:, 0])):
+    print("%-9s mean %9.0f  p10 %9.0f  p50 %9.0f  p90 %9.0f  max %9.0f" % (nm, v.mean(), np.percentile(v, 10), np.percentile(v, 50), np.percentile(v, 90), v.max()))
+nk = K // 16
+print("ideal k-loop cycles at 2 waves/SIMD: %d (=%d k-steps x 8192)" % (nk * 8192, nk))
+busy = (st[:, 3] - st[:, 0]).sum() / 256.0
+print("sum(tile total)/256 CUs = %.0f cycles vs span %d -> CU idle fraction %.3f" % (busy, st[:, 3].max() - st[:, 0].min(), 1 - busy / (st[:, 3].max() - st[:, 0].min())))
