@@ -118,6 +118,80 @@ __device__ __forceinline__ void store_wave_tile(typename MF<T>::acc_t (&acc)[4][
     }
 }
 
+// exchange a value with the neighbouring lane (lane ^ 1) through DPP quad_perm [1,0,3,2]
+__device__ __forceinline__ double swap_pair(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float swap_pair(float v)
+{
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
+}
+
+// Vector epilogue (ldc even, C 2-element aligned, N even): neighbouring lanes hold
+// neighbouring columns of the same rows, so after one DPP exchange per register
+// pair the even lane owns two columns of rows {q, q+8} and the odd lane two columns
+// of rows {q+4, q+12}: every lane moves 2 elements per access and the tile needs half
+// the memory instructions.  Elements outside the triangle are written back unchanged.
+template <typename T, int NTW>
+__device__ __forceinline__ void store_wave_tile_v2(typename MF<T>::acc_t (&acc)[4][NTW], T *__restrict__ C,
+                                                   int64_t ldc, int64_t M, int64_t N, int64_t r_base,
+                                                   int64_t c_base, int lane, T alpha, int tri,
+                                                   int64_t row0, int64_t col0, int beta0)
+{
+    struct alignas(2 * sizeof(T)) P2 { T x, y; };
+    const int odd = lane & 1;
+    const int ccol = (lane & 15) & ~1;                 // first column of the lane pair
+#pragma unroll
+    for (int ib = 0; ib < 4; ib += 2) {                // two MFMA tile rows per round trip
+        P2 cv[2][NTW][2];
+        int64_t grr[2][2];
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)                // h = 0: registers (0,1), h = 1: registers (2,3)
+                grr[ii][h] = r_base + (ib + ii) * 16 + MF<T>::row(lane, 2 * h + odd);
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                const int64_t gc = min(c_base + j * 16 + ccol, N - 2);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int64_t gr = min(grr[ii][h], M - 1);
+                    if (beta0) { cv[ii][j][h].x = (T)0; cv[ii][j][h].y = (T)0; }
+                    else cv[ii][j][h] = *reinterpret_cast<const P2 *>(C + gr * ldc + gc);
+                }
+            }
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                const int64_t gc = c_base + j * 16 + ccol;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    // even lane keeps register 2h (sends 2h+1), odd lane keeps 2h+1 (sends 2h)
+                    const T keep = odd ? acc[ib + ii][j][2 * h + 1] : acc[ib + ii][j][2 * h];
+                    const T send = odd ? acc[ib + ii][j][2 * h] : acc[ib + ii][j][2 * h + 1];
+                    const T recv = swap_pair(send);
+                    const T vx = odd ? recv : keep;    // column gc
+                    const T vy = odd ? keep : recv;    // column gc + 1
+                    const int64_t gr = grr[ii][h];
+                    if (gr < M && gc + 1 < N) {
+                        P2 o = cv[ii][j][h];
+                        if (!(tri == GPX_LOWER && row0 + gr < col0 + gc)) o.x = fma(alpha, vx, o.x);
+                        if (!(tri == GPX_LOWER && row0 + gr < col0 + gc + 1)) o.y = fma(alpha, vy, o.y);
+                        if (!(tri == GPX_LOWER && row0 + gr < col0 + gc))     // at least column gc is inside
+                            *reinterpret_cast<P2 *>(C + gr * ldc + gc) = o;
+                    }
+                }
+            }
+    }
+}
+
 // C (M x N) += alpha * A (M x K) * B (N x K)^T ; tri: skip/mask the strict upper part,
 // where element (i, j) is upper iff row0 + i < col0 + j.
 template <typename T>
@@ -304,6 +378,7 @@ struct GemmMap {
     // (start, first barrier passed, k-loop done, epilogue done) at stamps[4 * blockIdx]
     unsigned long long *stamps;
     int ablate;   // diagnostic (GPX_GEMM_ABLATE): 1 no barrier/vmcnt, 2 no DMA in loop, 4 no LDS reads in loop
+    int vec_c;    // C allows 2-element vector accesses (ldc even, aligned base, N even)
 };
 static unsigned long long *g_gemm_stamps = nullptr;
 
@@ -521,8 +596,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_fast_kernel(int64_t M, int64_t
 #undef GPX_SLOT_READ
 
     if (fm.stamps) { __builtin_amdgcn_s_barrier(); st2 = __builtin_amdgcn_s_memtime(); }   // all waves done
-    store_wave_tile<T, NTW>(acc, C, ldc, M, N, bm0 + wr * 64, bn0 + wc * (BN / 2), lane, alpha, tri, row0, col0,
-                            beta0);
+    if (fm.vec_c)
+        store_wave_tile_v2<T, NTW>(acc, C, ldc, M, N, bm0 + wr * 64, bn0 + wc * (BN / 2), lane, alpha, tri, row0,
+                                   col0, beta0);
+    else
+        store_wave_tile<T, NTW>(acc, C, ldc, M, N, bm0 + wr * 64, bn0 + wc * (BN / 2), lane, alpha, tri, row0,
+                                col0, beta0);
     if (fm.stamps && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned long long st3 = __builtin_amdgcn_s_memtime();
@@ -565,6 +644,10 @@ static int launch_gemm_nt_fast(int64_t M, int64_t N, int64_t K, const void *A, i
     }
     const int64_t np = fm.np;
     if (np <= 0) return GPX_OK;
+    {
+        static const bool no_vec = getenv("GPX_GEMM_NO_VEC_C") != nullptr;
+        fm.vec_c = (!no_vec && ldc % 2 == 0 && N % 2 == 0 && N >= 2 && ((uintptr_t)C) % (2 * sizeof(T)) == 0) ? 1 : 0;
+    }
     {
         // stagger only when the launch runs for several rounds of tiles
         static const int pct = getenv("GPX_GEMM_STAGGER") ? atoi(getenv("GPX_GEMM_STAGGER")) : 100;
