@@ -7,10 +7,11 @@
 //
 // Roofline: HBM read bandwidth -- a single-right-hand-side solve reads the
 // lower triangle of L once per direction (n^2/2 * sizeof(T) bytes, 2 n^2 flop for
-// both directions together).  Each 64-wide block step is ONE launch: every
-// workgroup re-solves the 64 x 64 diagonal system in its first wave (register
-// resident, lane-broadcast substitution, no barriers) and then streams its own
-// slice of the panel below (forward) / to the left (backward) in coalesced rows.
+// both directions together).  The 64 x 64 diagonal blocks are inverted up front in
+// ONE batched launch (trinv64_kernel); each 64-wide block step is then one launch
+// whose workgroups all form z = inv(L_jj) b_j by a 64 x 64 mat-vec (no serial
+// substitution on the critical path) and stream their own slice of the panel
+// below (forward) / to the left (backward) in coalesced rows.
 #include "gpx_common.h"
 
 namespace gpx {
@@ -18,31 +19,85 @@ namespace gpx {
 constexpr int SB = 64;
 constexpr int SBP = SB + 1;
 
+// ---- batched inverse of the 64 x 64 diagonal blocks --------------------------
+// One workgroup per block (all blocks in one launch); lane c builds column c of
+// inv(L_jj) by forward substitution.  Blocks shorter than 64 are padded with the
+// identity.  Output: Linv[blk][64][64], row-major, strictly-upper part zero.
 template <typename T>
-__device__ __forceinline__ void load_diag_block(T *sL, T *sRinv, const T *__restrict__ L, int64_t ldl,
-                                                int64_t k0, int jb, int tid)
-{
-    const T *blk = L + k0 * ldl + k0;
-    for (int idx = tid; idx < jb * SB; idx += 256) {
-        const int i = idx >> 6, c = idx & 63;
-        sL[i * SBP + c] = (c <= i && c < jb) ? blk[(int64_t)i * ldl + c] : (T)0;
-    }
-    if (tid < SB) sRinv[tid] = (tid < jb) ? (T)1 / blk[(int64_t)tid * ldl + tid] : (T)0;
-}
-
-// forward: solves L[k0:k0+jb, k0:k0+jb] z = b[k0:k0+jb], writes x[k0:k0+jb] = z and
-// b[r] -= L[r, k0:k0+jb] . z for all r >= k0 + jb.
-template <typename T>
-__global__ __launch_bounds__(256) void trsv_fwd_step(const T *__restrict__ L, int64_t ldl,
-                                                     T *__restrict__ b, T *__restrict__ x, int64_t k0,
-                                                     int jb, int64_t n)
+__global__ __launch_bounds__(64) void trinv64_kernel(const T *__restrict__ L, int64_t ldl, int64_t ncols,
+                                                     T *__restrict__ Linv)
 {
     __shared__ T sL[SB * SBP];
+    __shared__ T sX[SB * SBP];
+    const int c = threadIdx.x;
+    const int64_t k0 = (int64_t)blockIdx.x * SB;
+    const int jb = (int)min((int64_t)SB, ncols - k0);
+    const T *blk = L + k0 * ldl + k0;
+    for (int i = 0; i < SB; ++i) {
+        T v = (i == c) ? (T)1 : (T)0;
+        if (i < jb && c <= i) v = blk[(int64_t)i * ldl + c];
+        sL[i * SBP + c] = v;
+    }
+    __syncthreads();
+    // column c of X = L^-1: X[c][c] = 1 / L[c][c]; X[i][c] = -(sum_{t=c}^{i-1} L[i][t] X[t][c]) / L[i][i]
+    for (int i = 0; i < c; ++i) sX[i * SBP + c] = (T)0;
+    sX[c * SBP + c] = (T)1 / sL[c * SBP + c];
+    for (int i = c + 1; i < SB; ++i) {
+        T acc = (T)0;
+        for (int t = c; t < i; ++t) acc = fma(sL[i * SBP + t], sX[t * SBP + c], acc);
+        sX[i * SBP + c] = -acc / sL[i * SBP + i];
+    }
+    __syncthreads();
+    T *out = Linv + (int64_t)blockIdx.x * SB * SB;
+    for (int i = 0; i < SB; ++i) out[i * SB + c] = sX[i * SBP + c];
+}
+
+// grow-only device scratch for the block inverses (one per host thread)
+struct SolveScratch { void *p = nullptr; size_t bytes = 0; int device = -1; };
+static thread_local SolveScratch g_scr;
+static int scratch(size_t bytes, void **out)
+{
+    int dev = 0;
+    GPX_HIP(hipGetDevice(&dev));
+    if (g_scr.device != dev || g_scr.bytes < bytes) {
+        if (g_scr.p && g_scr.device == dev) { GPX_HIP(hipDeviceSynchronize()); (void)hipFree(g_scr.p); }
+        g_scr.p = nullptr; g_scr.bytes = 0; g_scr.device = dev;
+        GPX_HIP(hipMalloc(&g_scr.p, bytes));
+        g_scr.bytes = bytes;
+    }
+    *out = g_scr.p;
+    return GPX_OK;
+}
+
+// z = Linv_blk * v (forward) or Linv_blk^T * v (backward) for one 64-block, by all
+// 256 threads of the workgroup; v in LDS (sv), result to LDS (sz).
+template <typename T, bool TRANS>
+__device__ __forceinline__ void block_matvec(const T *__restrict__ Li, const T *sv, T *sz, T *red, int tid)
+{
+    const int r = tid & 63, part = tid >> 6;            // 4 partial sums per output row
+    T acc = (T)0;
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) {
+        const int c = part * 16 + cc;
+        const T m = TRANS ? Li[c * SB + r] : Li[r * SB + c];
+        acc = fma(m, sv[c], acc);
+    }
+    red[part * SB + r] = acc;
+    __syncthreads();
+    if (tid < SB) sz[tid] = ((red[tid] + red[SB + tid]) + red[2 * SB + tid]) + red[3 * SB + tid];
+    __syncthreads();
+}
+
+// forward: z = inv(L_jj) b[k0:k0+jb], x[k0:k0+jb] = z, b[r] -= L[r, k0:k0+jb] . z for r >= k0 + jb
+template <typename T>
+__global__ __launch_bounds__(256) void trsv_fwd_step(const T *__restrict__ L, int64_t ldl,
+                                                     const T *__restrict__ Linv, T *__restrict__ b,
+                                                     T *__restrict__ x, int64_t k0, int jb, int64_t n)
+{
     __shared__ T sTile[SB * SBP];
-    __shared__ T sz[SB];
-    __shared__ T sRinv[SB];
+    __shared__ T sv[SB], sz[SB], red[4 * SB];
     const int tid = threadIdx.x;
-    load_diag_block<T>(sL, sRinv, L, ldl, k0, jb, tid);
+    if (tid < SB) sv[tid] = (tid < jb) ? b[k0 + tid] : (T)0;
     // this workgroup's slice of the panel below: 64 rows x jb columns, coalesced along the row
     const int64_t r0 = k0 + jb + (int64_t)blockIdx.x * SB;
     for (int idx = tid; idx < SB * SB; idx += 256) {
@@ -50,17 +105,8 @@ __global__ __launch_bounds__(256) void trsv_fwd_step(const T *__restrict__ L, in
         sTile[i * SBP + c] = (r0 + i < n && c < jb) ? L[(r0 + i) * ldl + k0 + c] : (T)0;
     }
     __syncthreads();
-    if (tid < SB) {
-        T v = (tid < jb) ? b[k0 + tid] : (T)0;
-        for (int j = 0; j < jb; ++j) {
-            const T zj = __shfl(v, j, 64) * sRinv[j];
-            if (tid == j) v = zj;
-            else if (tid > j) v = fma(-sL[tid * SBP + j], zj, v);
-        }
-        sz[tid] = v;
-        if (blockIdx.x == 0 && tid < jb) x[k0 + tid] = v;
-    }
-    __syncthreads();
+    block_matvec<T, false>(Linv + (k0 / SB) * SB * SB, sv, sz, red, tid);
+    if (blockIdx.x == 0 && tid < jb) x[k0 + tid] = sz[tid];
     // 4 lanes per row, 16 columns each
     const int row = tid >> 2, part = tid & 3;
     T acc = (T)0;
@@ -71,30 +117,18 @@ __global__ __launch_bounds__(256) void trsv_fwd_step(const T *__restrict__ L, in
     if (part == 0 && r0 + row < n) b[r0 + row] -= acc;
 }
 
-// backward: solves L[k0:k0+jb, k0:k0+jb]^T a = b[k0:k0+jb], writes x[k0:k0+jb] = a and
-// b[c] -= sum_i L[k0+i, c] * a_i for all c < k0.
+// backward: a = inv(L_jj)^T b[k0:k0+jb], x[k0:k0+jb] = a, b[c] -= sum_i L[k0+i, c] a_i for c < k0
 template <typename T>
 __global__ __launch_bounds__(256) void trsv_bwd_step(const T *__restrict__ L, int64_t ldl,
-                                                     T *__restrict__ b, T *__restrict__ x, int64_t k0,
-                                                     int jb)
+                                                     const T *__restrict__ Linv, T *__restrict__ b,
+                                                     T *__restrict__ x, int64_t k0, int jb)
 {
-    __shared__ T sL[SB * SBP];
-    __shared__ T sz[SB];
-    __shared__ T sRinv[SB];
+    __shared__ T sv[SB], sz[SB], red[4 * SB];
     const int tid = threadIdx.x;
-    load_diag_block<T>(sL, sRinv, L, ldl, k0, jb, tid);
+    if (tid < SB) sv[tid] = (tid < jb) ? b[k0 + tid] : (T)0;
     __syncthreads();
-    if (tid < SB) {
-        T v = (tid < jb) ? b[k0 + tid] : (T)0;
-        for (int j = jb - 1; j >= 0; --j) {
-            const T aj = __shfl(v, j, 64) * sRinv[j];
-            if (tid == j) v = aj;
-            else if (tid < j) v = fma(-sL[j * SBP + tid], aj, v);
-        }
-        sz[tid] = v;
-        if (blockIdx.x == 0 && tid < jb) x[k0 + tid] = v;
-    }
-    __syncthreads();
+    block_matvec<T, true>(Linv + (k0 / SB) * SB * SB, sv, sz, red, tid);
+    if (blockIdx.x == 0 && tid < jb) x[k0 + tid] = sz[tid];
     const int64_t c = (int64_t)blockIdx.x * 256 + tid;
     if (c < k0) {
         const T *col = L + k0 * ldl + c;
@@ -114,20 +148,24 @@ static int trsv_t(const T *L, int64_t n, int64_t ldl, T *b, T *x, int transpose,
     // remaining right-hand side b[ncols:n] is reduced by L[ncols:n, 0:ncols] x.
     if (ncols < 0 || ncols > n) ncols = n;
     ProfScope prof(PC_TRSV, ((double)n * ncols - 0.5 * (double)ncols * (ncols - 1)) * sizeof(T), st);
+    const int64_t nblk = cdiv(ncols, SB);
+    void *scr = nullptr;
+    GPX_TRY(scratch((size_t)nblk * SB * SB * sizeof(T), &scr));
+    T *Linv = (T *)scr;
+    hipLaunchKernelGGL((trinv64_kernel<T>), dim3((unsigned)nblk), dim3(64), 0, st, L, ldl, ncols, Linv);
     if (!transpose) {
         for (int64_t k0 = 0; k0 < ncols; k0 += SB) {
             const int jb = (int)std::min<int64_t>(SB, ncols - k0);
             const int64_t below = n - k0 - jb;
             dim3 grid((unsigned)std::max<int64_t>(1, cdiv(below, SB))), block(256);
-            hipLaunchKernelGGL((trsv_fwd_step<T>), grid, block, 0, st, L, ldl, b, x, k0, jb, n);
+            hipLaunchKernelGGL((trsv_fwd_step<T>), grid, block, 0, st, L, ldl, Linv, b, x, k0, jb, n);
         }
     } else {
-        const int64_t nblk = cdiv(n, SB);
         for (int64_t kb = nblk - 1; kb >= 0; --kb) {
             const int64_t k0 = kb * SB;
             const int jb = (int)std::min<int64_t>(SB, n - k0);
             dim3 grid((unsigned)std::max<int64_t>(1, cdiv(k0, 256))), block(256);
-            hipLaunchKernelGGL((trsv_bwd_step<T>), grid, block, 0, st, L, ldl, b, x, k0, jb);
+            hipLaunchKernelGGL((trsv_bwd_step<T>), grid, block, 0, st, L, ldl, Linv, b, x, k0, jb);
         }
     }
     GPX_LAUNCH_CHECK();
