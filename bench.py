@@ -170,7 +170,8 @@ def main():
 
     prof = {}
     if not args.no_prof:
-        names = ["kmat", "gemm_nt", "potrf_diag", "trsm_rows", "trsv", "mean", "reduce"]
+        names = ["kmat", "gemm_trailing", "potrf_diag", "trsm_rows", "trsv", "mean", "reduce",
+                 "gemm_panel_bn64", "gemm_generic", "gemm_panel_bn128"]
         for cls, nm in enumerate(names):
             a, b, c = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
             _lib.check(lib.gpx_prof_read(cls, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
@@ -184,10 +185,12 @@ def main():
 
     peak = FP64_MFMA_PEAK_TFLOPS if args.dtype == "f64" else FP32_MFMA_PEAK_TFLOPS
     roofline = None
-    if prof.get("gemm_nt", {}).get("ms", 0) > 0:
-        g = prof["gemm_nt"]
+    if prof.get("gemm_trailing", {}).get("ms", 0) > 0:
+        g = prof["gemm_trailing"]
         achieved = g["work"] / (g["ms"] * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "gemm_nt_kernel<%s>" % ("double" if args.dtype == "f64" else "float"),
+        roofline = {"bound": "mfma",
+                    "kernel": "gpx::gemm_nt_fast_kernel<%s, 128, 1> (trailing SYRK updates of the factorisation)"
+                              % ("double" if args.dtype == "f64" else "float"),
                     "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": None,
                     "launches_per_step": g["launches"] / args.steps,

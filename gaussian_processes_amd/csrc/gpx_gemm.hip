@@ -320,7 +320,7 @@ int launch_gemm_nt(int64_t M, int64_t N, int64_t K, const void *A, int64_t lda, 
         attr_done = true;
     }
     dim3 grid((unsigned)cdiv(N, GB_N), (unsigned)cdiv(M, GB_M)), block(256);
-    ProfScope prof(PC_GEMM, 2.0 * (double)K * updated_elements(M, N, tri, row0, col0), st);
+    ProfScope prof(PC_GEMM_GENERIC, 2.0 * (double)K * updated_elements(M, N, tri, row0, col0), st);
     hipLaunchKernelGGL((gemm_nt_kernel<T>), grid, block, G_SMEM, st, M, N, K, (const T *)A, lda,
                        (const T *)B, ldb, (T *)C, ldc, (T)alpha, tri, row0, col0);
     GPX_LAUNCH_CHECK();
@@ -386,7 +386,10 @@ typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
 #define GPX_DSR(dst, addr, off) \
     asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
 
-template <typename T, int BN>
+// TAG only changes the symbol name: 1 = the block-cyclic trailing update of the
+// factorisation (gpx_d_syrk_bc), so that profilers list the dominant kernel separately
+// from the panel / covariance products that share its code.
+template <typename T, int BN, int TAG>
 __global__ __launch_bounds__(512, 2) void gemm_nt_fast_kernel(int64_t M, int64_t N, int64_t K,
                                                               const T *__restrict__ A, int64_t lda,
                                                               const T *__restrict__ B, int64_t ldb,
@@ -611,7 +614,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_fast_kernel(int64_t M, int64_t
 }
 #undef GPX_DSR
 
-template <typename T, int BN = 128>
+template <typename T, int BN = 128, int TAG = 0>
 static int launch_gemm_nt_fast(int64_t M, int64_t N, int64_t K, const void *A, int64_t lda,
                                const void *B, int64_t ldb, void *C, int64_t ldc, double alpha, int tri,
                                int64_t row0, int64_t col0, hipStream_t st, const GemmMap *map = nullptr,
@@ -620,7 +623,7 @@ static int launch_gemm_nt_fast(int64_t M, int64_t N, int64_t K, const void *A, i
     constexpr int F_SMEM = FGeo<BN>::SMEM;
     static bool attr_done = false;
     if (!attr_done) {
-        GPX_HIP(hipFuncSetAttribute((const void *)gemm_nt_fast_kernel<T, BN>,
+        GPX_HIP(hipFuncSetAttribute((const void *)gemm_nt_fast_kernel<T, BN, TAG>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, F_SMEM));
         attr_done = true;
     }
@@ -663,8 +666,9 @@ static int launch_gemm_nt_fast(int64_t M, int64_t N, int64_t K, const void *A, i
         }
     }
     const int64_t blocks = cdiv(np, 8) * 8 * 32;
-    ProfScope prof(PC_GEMM, work >= 0 ? work : 2.0 * (double)K * updated_elements(M, N, tri, row0, col0), st);
-    hipLaunchKernelGGL((gemm_nt_fast_kernel<T, BN>), dim3((unsigned)blocks), dim3(512), F_SMEM, st, M, N, K,
+    ProfScope prof(TAG == 1 ? PC_GEMM : (BN == 128 ? PC_GEMM_PANEL : PC_GEMM_SKINNY),
+                   work >= 0 ? work : 2.0 * (double)K * updated_elements(M, N, tri, row0, col0), st);
+    hipLaunchKernelGGL((gemm_nt_fast_kernel<T, BN, TAG>), dim3((unsigned)blocks), dim3(512), F_SMEM, st, M, N, K,
                        (const T *)A, lda, (const T *)B, ldb, (T *)C, ldc, (T)alpha, tri, row0, col0, fm, beta0);
     GPX_LAUNCH_CHECK();
     return GPX_OK;
@@ -752,10 +756,10 @@ int syrk_bc(int dtype, int64_t n, int64_t row_begin, void *Cloc, int64_t ldc, in
         fm.np = (int)np;
         fm.stag_blocks = 0; fm.stag_cycles = 0; fm.stamps = nullptr; fm.ablate = 0;
         if (dtype == GPX_F64)
-            return launch_gemm_nt_fast<double>(M, Ncols, kb, A, ldp, Pb, ldp, C, ldc, -1.0, GPX_LOWER,
-                                               row_begin, cl0 + (int64_t)rank * nb, st, &fm, work);
-        return launch_gemm_nt_fast<float>(M, Ncols, kb, A, ldp, Pb, ldp, C, ldc, -1.0, GPX_LOWER,
-                                          row_begin, cl0 + (int64_t)rank * nb, st, &fm, work);
+            return launch_gemm_nt_fast<double, 128, 1>(M, Ncols, kb, A, ldp, Pb, ldp, C, ldc, -1.0, GPX_LOWER,
+                                                       row_begin, cl0 + (int64_t)rank * nb, st, &fm, work);
+        return launch_gemm_nt_fast<float, 128, 1>(M, Ncols, kb, A, ldp, Pb, ldp, C, ldc, -1.0, GPX_LOWER,
+                                                  row_begin, cl0 + (int64_t)rank * nb, st, &fm, work);
     }
     // generic route: one launch per local block column
     for (int64_t c = cl0; c < cl1;) {

@@ -8,7 +8,7 @@
 //
 // Algorithm (N x N, outer block nb, inner block IB = 64):
 //   for each block column k0 (width kb <= nb)                      -- right-looking
-//     for each 64-wide sub-column j0 inside it                     -- left-looking
+//     panel: recursive halving down to 64 columns (see potrf_panel_t)
 //       (a) A[j0:, j0:j0+64] -= A[j0:, k0:j0] * A[j0:j0+64, k0:j0]^T    MFMA gemm_nt
 //       (b) factor the 64 x 64 diagonal block in LDS (one workgroup)
 //       (c) rows below: A[r, j0:j0+64] <- A[r, j0:j0+64] * Ljj^-T       (one lane per row)
@@ -214,27 +214,32 @@ static int64_t outer_block(int64_t n)
 }
 
 // ---- panel: rows [r0, n) x columns [c0, c0 + kb), diagonal block at (r0, c0) ----
+// Recursive halving down to 64 columns: factor the left half, apply it to the right
+// half with ONE MFMA GEMM (N = K = half the width: 57 % of a 512-wide panel's flops
+// run as a 256 x 256-deep product, 29 % as 128 x 128, 14 % as 64 x 64), factor the
+// right half.  A 64-wide leaf is the diagonal block (one workgroup) followed by the
+// row substitution below it.
 template <typename T>
 static int potrf_panel_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int64_t kb, int *info_dev,
                          hipStream_t st, int dtype)
 {
-    for (int64_t j = 0; j < kb; j += IB) {
-        const int jb = (int)std::min<int64_t>(IB, kb - j);
-        T *Aj = A + (r0 + j) * lda + c0;            // row r0 + j, first panel column
-        if (j > 0)
-            GPX_TRY(gemm_nt(dtype, n - (r0 + j), jb, j, Aj, lda, Aj, lda, Aj + j, lda, -1.0, GPX_LOWER, 0,
-                            0, st));
+    if (kb <= IB) {
+        const int jb = (int)kb;
+        T *D = A + r0 * lda + c0;
         {
             ProfScope prof(PC_POTRF_DIAG, (double)jb * jb * jb / 3.0, st);
-            hipLaunchKernelGGL((potrf_diag_kernel<T>), dim3(1), dim3(256), 0, st, Aj + j, lda, r0 + j, jb,
-                               info_dev);
+            hipLaunchKernelGGL((potrf_diag_kernel<T>), dim3(1), dim3(256), 0, st, D, lda, r0, jb, info_dev);
         }
         GPX_LAUNCH_CHECK();
-        const int64_t below = n - (r0 + j + jb);
-        if (below > 0)
-            GPX_TRY(trsm_rows(dtype, A + (r0 + j + jb) * lda + c0 + j, lda, below, Aj + j, lda, jb, st));
+        const int64_t below = n - (r0 + jb);
+        if (below > 0) GPX_TRY(trsm_rows(dtype, A + (r0 + jb) * lda + c0, lda, below, D, lda, jb, st));
+        return GPX_OK;
     }
-    return GPX_OK;
+    const int64_t h = ((kb / IB + 1) / 2) * IB;          // left half, a multiple of 64
+    GPX_TRY(potrf_panel_t<T>(A, lda, n, r0, c0, h, info_dev, st, dtype));
+    T *R = A + (r0 + h) * lda + c0;                       // rows below the left half's diagonal block
+    GPX_TRY(gemm_nt(dtype, n - (r0 + h), kb - h, h, R, lda, R, lda, R + h, lda, -1.0, GPX_LOWER, 0, 0, st));
+    return potrf_panel_t<T>(A, lda, n, r0 + h, c0 + h, kb - h, info_dev, st, dtype);
 }
 
 int potrf_panel(int dtype, void *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int64_t kb,

@@ -118,12 +118,15 @@ int gpx_stream_wait_event(void *stream, void *event);
  * (flops for GPX_PROF_GEMM, bytes for the others).  bench.py derives
  * roofline.achieved from these. */
 #define GPX_PROF_KMAT       0   /* bytes written                                  */
-#define GPX_PROF_GEMM       1   /* flops: 2*K per updated element (lower: i >= j) */
+#define GPX_PROF_GEMM       1   /* gemm_nt_fast_kernel<T,128,1>: trailing updates (gpx_d_syrk_bc); flops: 2*K per updated element */
 #define GPX_PROF_POTRF_DIAG 2   /* flops jb^3/3                                   */
 #define GPX_PROF_TRSM_ROWS  3   /* flops rows*jb^2                                */
 #define GPX_PROF_TRSV       4   /* bytes of L read                                */
 #define GPX_PROF_MEAN       5   /* kernel evaluations m*n                         */
 #define GPX_PROF_REDUCE     6   /* bytes read                                     */
+#define GPX_PROF_GEMM_SKINNY  7 /* gemm_nt_fast_kernel<T,64> (panel products); flops */
+#define GPX_PROF_GEMM_GENERIC 8 /* gemm_nt_kernel<T> (unaligned / K-tail shapes); flops */
+#define GPX_PROF_GEMM_PANEL   9 /* gemm_nt_fast_kernel<T,128,0>: panel / covariance products; flops */
 int gpx_prof_enable(int on);    /* also clears the registry */
 int gpx_prof_read(int cls, double *launches, double *total_ms, double *total_work);
 
