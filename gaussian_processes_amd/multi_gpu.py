@@ -193,17 +193,19 @@ class TorchComm(object):
         self.rank = dist.get_rank()
         self.world = dist.get_world_size()
         self.to_tensor = to_tensor or (lambda a: a)
+        # rehearsal switch: issue the collectives even in a world of one rank
+        self.always = bool(os.environ.get("GPX_FORCE_COLLECTIVES"))
 
     def broadcast(self, arr, start, count, src):
-        if self.world > 1 and count > 0:
+        if (self.world > 1 or self.always) and count > 0:
             self.dist.broadcast(self.to_tensor(arr).view(-1)[start:start + count], src=src)
 
     def all_reduce_sum(self, arr, start, count):
-        if self.world > 1 and count > 0:
+        if (self.world > 1 or self.always) and count > 0:
             self.dist.all_reduce(self.to_tensor(arr).view(-1)[start:start + count])
 
     def all_reduce_max(self, arr, start, count):
-        if self.world > 1 and count > 0:
+        if (self.world > 1 or self.always) and count > 0:
             self.dist.all_reduce(self.to_tensor(arr).view(-1)[start:start + count],
                                  op=self.dist.ReduceOp.MAX)
 
@@ -389,8 +391,14 @@ class DistributedGP(object):
 # ------------------------------------------------------------------ benchmark --
 def bench_distributed(args, X, y, Xo, params, s, dtype_id):
     """bench.py's N > 1 leg: same workload as N = 1 (strong scaling), one rank per GPU."""
+    import sys
     import torch
     import torch.distributed as dist
+    # RCCL prints a version banner on stdout when its communicator is created; keep
+    # stdout clean for the single JSON line (stderr still shows everything)
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ["RANK"])
     world = int(os.environ["WORLD_SIZE"])
     local_rank = int(os.environ.get("LOCAL_RANK", rank))
@@ -448,4 +456,7 @@ def bench_distributed(args, X, y, Xo, params, s, dtype_id):
                              "reported by the 1-GPU run"},
     }
     dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
+    os.close(saved_stdout)
     return result
