@@ -1,0 +1,84 @@
+"""Batched ML-II evaluation: log marginal likelihood of many hyper-parameter settings.
+
+The reference has no optimiser (``fit_MLII`` was removed in 1.0.3, CHANGELOG.md:19);
+its ML-II inner step is "set params -> read log_lh" (gp/gp.py:216-223, 337-367).
+This harness runs that step for a whole table of restarts on one resident data set:
+one ``gpx_gp`` handle per process, x / y uploaded once, then set_params + fit +
+log_lh per row.  With a process group the rows are dealt round-robin to the ranks
+(replicas only: no intra-GP sharding) and one all-reduce assembles the
+table on every rank.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+__all__ = ["log_lh_batch", "best_restart"]
+
+_KERNEL_IDS = {"gaussian": (_lib.KERNEL_GAUSSIAN, 2), "periodic": (_lib.KERNEL_PERIODIC, 3)}
+
+
+def log_lh_batch(x, y, thetas, kernel="gaussian", dtype="float64", dist=None, device=None):
+    """log_lh for every row ``(kernel params..., s)`` of `thetas`.
+
+    x: (n,) or (n, d); y: (n,); thetas: (r, n_params + 1).  Rows with invalid parameters
+    (kernel parameter < EPS or s < 0, the reference's ValueError conditions) and rows whose
+    kernel matrix is not positive definite give ``-inf`` / ``nan`` as the reference would
+    (-inf for non-PD, gp/gp.py:362-365; nan marks a row that would have raised ValueError).
+    `dist`: an initialised ``torch.distributed`` module (any backend) or None.
+    """
+    kid, nkp = _KERNEL_IDS[kernel]
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    thetas = np.atleast_2d(np.asarray(thetas, dtype=np.float64))
+    if thetas.shape[1] != nkp + 1:
+        raise ValueError("thetas must have %d columns (kernel params + s)" % (nkp + 1))
+    n = x.shape[0]
+    d = 1 if x.ndim == 1 else x.shape[1]
+    if y.shape != (n,):
+        raise ValueError("invalid shape for y: %s" % str(y.shape))
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
+    lib = _lib.load()
+    if device is not None:
+        _lib.check(lib.gpx_set_device(int(device)))
+    dt = _lib.F64 if dtype in ("float64", "f64") else _lib.F32
+    out = np.zeros(thetas.shape[0], dtype=np.float64)
+    eps = np.finfo(np.float64).eps
+    h = ctypes.c_void_p()
+    _lib.check(lib.gpx_gp_create(ctypes.byref(h), dt, kid, n, d))
+    try:
+        _lib.check(lib.gpx_gp_set_data(h, _lib.dptr(x), _lib.dptr(y)))
+        for i in range(rank, thetas.shape[0], world):
+            p = np.ascontiguousarray(thetas[i, :nkp])
+            s = float(thetas[i, nkp])
+            if (p < eps).any() or s < 0 or not np.isfinite(thetas[i]).all():
+                out[i] = np.nan
+                continue
+            _lib.check(lib.gpx_gp_set_params(h, _lib.dptr(p), s))
+            _lib.check(lib.gpx_gp_fit(h, None))
+            v = ctypes.c_double(0.0)
+            _lib.check(lib.gpx_gp_log_lh(h, ctypes.byref(v)))
+            out[i] = v.value
+    finally:
+        lib.gpx_gp_destroy(h)
+    if world > 1:
+        import torch
+        # -inf / nan do not survive a SUM all-reduce of zero-padded tables: ship a finite code
+        code = np.where(np.isnan(out), 2.0, np.where(np.isneginf(out), 1.0, 0.0))
+        val = np.where(code > 0, 0.0, out)
+        t = torch.from_numpy(np.stack([val, code]))
+        if dist.get_backend() == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t)
+        t = t.cpu().numpy()
+        out = np.where(t[1] == 2.0, np.nan, np.where(t[1] == 1.0, -np.inf, t[0]))
+    return out
+
+
+def best_restart(x, y, thetas, **kw):
+    """(index, theta, log_lh) of the restart with the largest log marginal likelihood."""
+    llh = log_lh_batch(x, y, thetas, **kw)
+    ok = np.where(np.isnan(llh), -np.inf, llh)
+    i = int(np.argmax(ok))
+    return i, np.asarray(thetas)[i], llh[i]

@@ -426,6 +426,9 @@ def bench_distributed(args, X, y, Xo, params, s, dtype_id):
         step()
     dist.barrier()
     torch.cuda.synchronize()
+    lib = _lib.load()
+    if rank == 0 and not args.no_prof:
+        _lib.check(lib.gpx_prof_enable(1))       # per-launch HIP events on this rank's streams
     t0 = time.perf_counter()
     for _ in range(args.steps):
         llh = step()
@@ -438,6 +441,14 @@ def bench_distributed(args, X, y, Xo, params, s, dtype_id):
     assert np.isfinite(llh) and np.isfinite(mean_host).all()
     peak = 78.6 if dtype_id == _lib.F64 else 157.3
     tfl = (N ** 3 / 3.0) / sec / 1e12
+    rank0_gemm = None
+    if rank == 0 and not args.no_prof:
+        a, b, c = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        _lib.check(lib.gpx_prof_read(1, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        _lib.check(lib.gpx_prof_enable(0))
+        if b.value > 0:
+            rank0_gemm = {"launches_per_step": a.value / args.steps, "ms_per_step": b.value / args.steps,
+                          "tflops": c.value / (b.value * 1e-3) / 1e12}
     result = {
         "metric": "GP fit+predict wall-clock (kernel build + Cholesky + solve + log_lh + posterior mean)",
         "value": round(sec, 4), "unit": "s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -449,11 +460,14 @@ def bench_distributed(args, X, y, Xo, params, s, dtype_id):
                                   % (gp.lay.nb, world)},
         "log_lh": llh,
         "whole_step_tflops_n3_over_3": round(tfl, 3),
-        "roofline": {"bound": "mfma", "kernel": "gemm_nt_fast_kernel (trailing update, all ranks)",
-                     "achieved": round(tfl, 3), "peak": peak * world, "unit": "TFLOP/s",
-                     "frac": round(tfl / (peak * world), 4), "traffic": None,
-                     "note": "whole-step N^3/3 flops over wall-clock, all GPUs; per-kernel events are "
-                             "reported by the 1-GPU run"},
+        "whole_step_frac_of_peak_all_gpus": round(tfl / (peak * world), 4),
+        "roofline": ({"bound": "mfma",
+                      "kernel": "gpx::gemm_nt_fast_kernel<T, 128, 1> (trailing SYRK updates) on rank 0",
+                      "achieved": round(rank0_gemm["tflops"], 3), "peak": peak, "unit": "TFLOP/s",
+                      "frac": round(rank0_gemm["tflops"] / peak, 4), "traffic": None,
+                      "launches_per_step": rank0_gemm["launches_per_step"],
+                      "kernel_ms_per_step_rank0": round(rank0_gemm["ms_per_step"], 3)}
+                     if rank0_gemm else None),
     }
     dist.destroy_process_group()
     sys.stdout.flush()

@@ -58,3 +58,34 @@ def test_info_reduction_and_minus_inf():
     g.info[0] = 137
     g.reduce_scalars()
     assert g.info_host == 137 and g.log_lh == -np.inf
+
+
+def _mlii_worker(rank, world, port, outdir):
+    import os
+    import torch.distributed as dist
+    from gaussian_processes_amd import mlii, _lib
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # no GPU here: rows are all invalid (-> nan without touching the device) except that
+        # the dealing / all-reduce / code path for nan must round-trip on every rank
+        thetas = np.array([[1.0, 0.0, 1.0], [0.0, 1.0, 1.0], [1.0, 1.0, -1.0], [np.nan, 1.0, 1.0], [1.0, -3.0, 0.1]])
+        try:
+            out = mlii.log_lh_batch(np.zeros(8), np.zeros(8), thetas, dist=dist)
+            np.save(os.path.join(outdir, "mlii_%d.npy" % rank), out)
+        except _lib.GpxError:
+            np.save(os.path.join(outdir, "mlii_%d.npy" % rank), np.array([-1.0]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_mlii_round_robin_over_gloo(tmp_path):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_mlii_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        out = np.load(str(tmp_path / ("mlii_%d.npy" % r)))
+        # without a GPU the handle cannot be created: the product fails loudly (no CPU fallback)
+        assert (out.shape == (1,) and out[0] == -1.0) or np.isnan(out).all()
