@@ -243,20 +243,22 @@ int panel_gemv_t(int dtype, const void *Lp, int64_t ldl, int64_t rows, int64_t n
     return GPX_OK;
 }
 
-// X (m x n) <- X * L^-T, blocked: level-3 updates on the MFMA gemm_nt, 64-wide
-// substitutions by trsm_rows (shared with the Cholesky panel).
+// X (m x n) <- X * L^-T, blocked and RIGHT-looking: after the columns of a block are
+// solved they are applied at once to every remaining column,
+//   X[:, r:] -= X[:, blk] * L[r:, blk]^T      (m x (n - r) output, K = block width),
+// which keeps all CUs busy even for few right-hand sides (m ~ 1000 test points); a
+// left-looking sweep would launch m/256 x 2 tiles per step.  Inside a block: 64-wide
+// substitutions by trsm_rows (shared with the Cholesky panel) with small MFMA updates.
 int trsm_right_lt(int dtype, const void *L, int64_t n, int64_t ldl, void *X, int64_t m, int64_t ldx,
                   hipStream_t st)
 {
     if (n <= 0 || m <= 0) return GPX_OK;
     const size_t es = esize(dtype);
-    const int64_t NB = 256;
+    const int64_t NB = n >= 8192 ? 512 : 256;
     auto Lp = [&](int64_t r, int64_t c) { return (const char *)L + (r * ldl + c) * es; };
     auto Xp = [&](int64_t c) { return (char *)X + c * es; };
     for (int64_t k0 = 0; k0 < n; k0 += NB) {
         const int64_t kb = std::min(NB, n - k0);
-        if (k0 > 0)
-            GPX_TRY(gemm_nt(dtype, m, kb, k0, X, ldx, Lp(k0, 0), ldl, Xp(k0), ldx, -1.0, GPX_FULL, 0, 0, st));
         for (int64_t j0 = k0; j0 < k0 + kb; j0 += SB) {
             const int jb = (int)std::min<int64_t>(SB, k0 + kb - j0);
             if (j0 > k0)
@@ -264,6 +266,10 @@ int trsm_right_lt(int dtype, const void *L, int64_t n, int64_t ldl, void *X, int
                                 GPX_FULL, 0, 0, st));
             GPX_TRY(trsm_rows(dtype, Xp(j0), ldx, m, Lp(j0, j0), ldl, jb, st));
         }
+        const int64_t r = k0 + kb;
+        if (r < n)
+            GPX_TRY(gemm_nt(dtype, m, n - r, kb, Xp(k0), ldx, Lp(r, k0), ldl, Xp(r), ldx, -1.0, GPX_FULL, 0, 0,
+                            st));
     }
     return GPX_OK;
 }
