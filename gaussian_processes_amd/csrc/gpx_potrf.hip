@@ -28,12 +28,17 @@ constexpr int IBP = IB + 1;   // LDS pitch (elements): conflict-free column walk
 // through a double-buffered 64-entry LDS vector: one barrier per column.  Scaling
 // uses the reciprocal of the pivot's square root, as LAPACK's dpotf2 does.
 // Blocks smaller than 64 are padded with the identity (pivot 1, no effect).
+// When `inv` is non-null the same sweep also carries X = L^-1 (forward elimination of
+// the identity: row j of X is scaled by 1/L[j][j] and subtracted, times L[i][j], from
+// the rows below) and stores it as a dense 64 x 64 row-major block: the row substitution
+// below the leaf then becomes one small MFMA product X_rows * inv(L)^T.
 template <typename T>
 __global__ __launch_bounds__(256) void potrf_diag_kernel(T *__restrict__ blk, int64_t lda, int64_t j0,
-                                                         int jb, int *__restrict__ info)
+                                                         int jb, int *__restrict__ info, T *__restrict__ inv)
 {
     // blk: the jb x jb diagonal block; j0: its global (0-based) index, for `info`
     __shared__ T colbuf[2][IB];
+    __shared__ T rowbuf[2][IB];
     const int tid = threadIdx.x;
     const int tr = tid >> 4, tc = tid & 15;
     T a[4][4];
@@ -46,9 +51,18 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(T *__restrict__ blk, in
             if (row < jb && col <= row) v = blk[(int64_t)row * lda + col];
             a[r][c] = v;
         }
+    T x[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) x[r][c] = (4 * tr + r == 4 * tc + c) ? (T)1 : (T)0;
     if (tc == 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) colbuf[0][4 * tr + r] = a[r][0];
+    }
+    if (tr == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) rowbuf[0][4 * tc + c] = x[0][c];
     }
     __syncthreads();
     int cur = 0;
@@ -84,6 +98,31 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(T *__restrict__ blk, in
                     const int row = 4 * tr + r, col = 4 * tc + c;
                     if (row > j && col > j) a[r][c] = fma(-li[r], lc[c], a[r][c]);
                 }
+            if (inv) {
+                T xs[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) xs[k] = rowbuf[cur][4 * tc + k] * rinv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 4 * tr + r;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        if (row > j) x[r][c] = fma(-li[r], xs[c], x[r][c]);
+                        else if (row == j) x[r][c] = xs[c];
+                    }
+                }
+                const int jn2 = j + 1;
+                if (jn2 < IB && tr == (jn2 >> 2)) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        T v = x[0][c];
+                        if ((jn2 & 3) == 1) v = x[1][c];
+                        if ((jn2 & 3) == 2) v = x[2][c];
+                        if ((jn2 & 3) == 3) v = x[3][c];
+                        rowbuf[cur ^ 1][4 * tc + c] = v;
+                    }
+                }
+            }
             // publish column j + 1 for the next step
             const int jn = j + 1;
             if (jn < IB && tc == (jn >> 2)) {
@@ -106,6 +145,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(T *__restrict__ blk, in
         for (int c = 0; c < 4; ++c) {
             const int row = 4 * tr + r, col = 4 * tc + c;
             if (row < jb && col <= row) blk[(int64_t)row * lda + col] = a[r][c];
+            if (inv) inv[row * IB + col] = (col <= row) ? x[r][c] : (T)0;
         }
 }
 
@@ -213,6 +253,24 @@ static int64_t outer_block(int64_t n)
     return 1024;     // measured at n = 65536: 1024 -> 1.58 s, 512 -> 1.65 s, 256 -> 2.0 s per fit
 }
 
+// one 64 x 64 scratch block per host thread and device for the leaf's inverse (leaves of a
+// panel are stream-ordered, so one block is enough)
+struct LeafScratch { void *p = nullptr; size_t bytes = 0; int device = -1; };
+static thread_local LeafScratch g_leaf;
+static int leaf_scratch(size_t bytes, void **out)
+{
+    int dev = 0;
+    GPX_HIP(hipGetDevice(&dev));
+    if (g_leaf.device != dev || g_leaf.bytes < bytes) {
+        g_leaf.p = nullptr;                      // a previous device's block is left to that context
+        GPX_HIP(hipMalloc(&g_leaf.p, std::max<size_t>(bytes, IB * IB * 8)));
+        g_leaf.bytes = std::max<size_t>(bytes, IB * IB * 8);
+        g_leaf.device = dev;
+    }
+    *out = g_leaf.p;
+    return GPX_OK;
+}
+
 // ---- panel: rows [r0, n) x columns [c0, c0 + kb), diagonal block at (r0, c0) ----
 // Recursive halving down to 64 columns: factor the left half, apply it to the right
 // half with ONE MFMA GEMM (N = K = half the width: 57 % of a 512-wide panel's flops
@@ -226,13 +284,32 @@ static int potrf_panel_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, i
     if (kb <= IB) {
         const int jb = (int)kb;
         T *D = A + r0 * lda + c0;
+        const int64_t below = n - (r0 + jb);
+        static const bool force_rows = getenv("GPX_POTRF_TRSM_ROWS") != nullptr;
+        // measured: the inverse + MFMA route wins for short panels (N = 8192: -2.7 % per fit) and
+        // loses for tall ones (N = 65536: +2 %, its 120 KiB tiles displace trailing-update workgroups)
+        const bool via_inverse = !force_rows && below > 0 && below <= 16384 && jb == IB &&
+                                 lda % (16 / (int64_t)sizeof(T)) == 0 &&
+                                 ((uintptr_t)(A + (r0 + jb) * lda + c0)) % 16 == 0;
+        T *inv = nullptr;
+        if (via_inverse) {
+            void *p = nullptr;
+            GPX_TRY(leaf_scratch(IB * IB * sizeof(T), &p));
+            inv = (T *)p;
+        }
         {
             ProfScope prof(PC_POTRF_DIAG, (double)jb * jb * jb / 3.0, st);
-            hipLaunchKernelGGL((potrf_diag_kernel<T>), dim3(1), dim3(256), 0, st, D, lda, r0, jb, info_dev);
+            hipLaunchKernelGGL((potrf_diag_kernel<T>), dim3(1), dim3(256), 0, st, D, lda, r0, jb, info_dev, inv);
         }
         GPX_LAUNCH_CHECK();
-        const int64_t below = n - (r0 + jb);
-        if (below > 0) GPX_TRY(trsm_rows(dtype, A + (r0 + jb) * lda + c0, lda, below, D, lda, jb, st));
+        if (via_inverse) {
+            // rows below: X <- X * inv(L_jj)^T, in place (each tile reads all 64 columns of its own
+            // rows before its epilogue stores them; no other tile touches those rows)
+            T *Xb = A + (r0 + jb) * lda + c0;
+            GPX_TRY(gemm_nt(dtype, below, jb, jb, Xb, lda, inv, IB, Xb, lda, 1.0, GPX_FULL, 0, 0, st, 1));
+        } else if (below > 0) {
+            GPX_TRY(trsm_rows(dtype, A + (r0 + jb) * lda + c0, lda, below, D, lda, jb, st));
+        }
         return GPX_OK;
     }
     const int64_t h = ((kb / IB + 1) / 2) * IB;          // left half, a multiple of 64
