@@ -32,6 +32,20 @@ constexpr int IBP = IB + 1;   // LDS pitch (elements): conflict-free column walk
 // the identity: row j of X is scaled by 1/L[j][j] and subtracted, times L[i][j], from
 // the rows below) and stores it as a dense 64 x 64 row-major block: the row substitution
 // below the leaf then becomes one small MFMA product X_rows * inv(L)^T.
+__device__ __forceinline__ double fast_rsqrt(double p)
+{
+    double y = __builtin_amdgcn_rsq(p);
+    y = y * fma(-0.5 * p * y, y, 1.5);
+    y = y * fma(-0.5 * p * y, y, 1.5);
+    return y;
+}
+__device__ __forceinline__ float fast_rsqrt(float p)
+{
+    float y = __builtin_amdgcn_rsqf(p);
+    y = y * fmaf(-0.5f * p * y, y, 1.5f);
+    return y;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void potrf_diag_kernel(T *__restrict__ blk, int64_t lda, int64_t j0,
                                                          int jb, int *__restrict__ info, T *__restrict__ inv)
@@ -75,8 +89,11 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(T *__restrict__ blk, in
             if (j < jb && !(piv > (T)0)) {               // also catches NaN
                 if (tid == 0 && *info == 0) *info = (int)(j0 + j + 1);
             }
-            const T ljj = sqrt(piv);
-            const T rinv = (T)1 / ljj;
+            // 1/sqrt(piv) by v_rsq + two Newton steps (error ~1 ulp), then sqrt(piv) = piv * rinv:
+            // a third of the dependent-instruction chain of sqrt() followed by a division,
+            // and this chain is the critical path of every column
+            const T rinv = fast_rsqrt(piv);
+            const T ljj = piv * rinv;
             T li[4], lc[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -352,7 +369,11 @@ static int lookahead_setup()
     if (g_la.device != dev) {
         g_la = LookAhead();
         g_la.device = dev;
-        GPX_HIP(hipStreamCreateWithFlags(&g_la.q, hipStreamNonBlocking));
+        // the panel is on the critical path of the NEXT step: give its stream the highest
+        // priority so that its workgroups get the CUs that trailing-update workgroups free up
+        int least = 0, greatest = 0;
+        GPX_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        GPX_HIP(hipStreamCreateWithPriority(&g_la.q, hipStreamNonBlocking, greatest));
     }
     g_la.next = 0;
     return GPX_OK;

@@ -93,7 +93,8 @@ class HipOps(object):
         torch.cuda.set_device(self.device)
         _lib.check(self.lib.gpx_set_device(device))
         self.main = torch.cuda.Stream(device=self.device)
-        self.side = torch.cuda.Stream(device=self.device)
+        # panel factorisation + broadcast: critical path of the next step -> high priority
+        self.side = torch.cuda.Stream(device=self.device, priority=-1)
 
     # memory
     def empty(self, shape, dtype=None):
