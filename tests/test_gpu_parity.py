@@ -495,3 +495,23 @@ def test_mlii_batch_matches_oracle_and_reference_conventions():
     assert np.isnan(llh[6]) and np.isnan(llh[7])
     i, th, best = mlii.best_restart(X, y, thetas)
     assert i == int(np.argmax(llh[:6])) and best == llh[i]
+
+
+@pytest.mark.parametrize("N,d", [(16389, 5), (17408 + 63, 2)])
+def test_ragged_sizes_above_the_nb1024_threshold(N, d):
+    """n just above 16384 selects the 1024-wide outer block with look-ahead; the last block
+    column is ragged (5 resp. 63 columns).  Checked by size-independent properties."""
+    X, y, Xo = orc.synth_inputs(N, d, 64)
+    h, w, s = 1.0, 0.5 * np.sqrt(d), 1.0
+    g = gp.GP(gp.GaussianKernel(h, w), X, y, s=s)
+    alpha = g.inv_Kxx_y
+    rows = np.array([0, 1, 1023, 1024, 8191, 16383, 16384, N - 2, N - 1])
+    Krows = orc.kernel_matrix("gaussian", "K", X[rows], X, (h, w))
+    Krows[np.arange(rows.size), rows] += s * s
+    np.testing.assert_allclose(Krows @ alpha, y[rows], rtol=1e-9, atol=1e-10)
+    L = g.Lxx
+    np.testing.assert_allclose(L[rows] @ L.T, Krows, rtol=1e-11, atol=1e-12)
+    logdet = 2 * np.log(np.diag(L)).sum()
+    np.testing.assert_allclose(g.log_lh, -0.5 * y @ alpha - 0.5 * logdet - 0.5 * N * np.log(2 * np.pi), rtol=1e-12)
+    np.testing.assert_allclose(g.mean(Xo)[:8], orc.kernel_matrix("gaussian", "K", Xo[:8], X, (h, w)) @ alpha,
+                               rtol=1e-9, atol=1e-11)
