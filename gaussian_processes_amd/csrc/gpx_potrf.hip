@@ -46,7 +46,7 @@ __device__ __forceinline__ float fast_rsqrt(float p)
     return y;
 }
 
-template <typename T>
+template <typename T, bool INV>
 __global__ __launch_bounds__(256) void potrf_diag_kernel(T *__restrict__ blk, int64_t lda, int64_t j0,
                                                          int jb, int *__restrict__ info, T *__restrict__ inv)
 {
@@ -94,11 +94,15 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(T *__restrict__ blk, in
             // and this chain is the critical path of every column
             const T rinv = fast_rsqrt(piv);
             const T ljj = piv * rinv;
+            // scaled column j, zeroed outside the trailing part (rows / columns <= j): the
+            // rank-1 update below then needs no per-element mask
             T li[4], lc[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                li[k] = colbuf[cur][4 * tr + k] * rinv;
-                lc[k] = colbuf[cur][4 * tc + k] * rinv;
+                const T vi = colbuf[cur][4 * tr + k] * rinv;
+                const T vc = colbuf[cur][4 * tc + k] * rinv;
+                li[k] = (4 * tr + k > j) ? vi : (T)0;
+                lc[k] = (4 * tc + k > j) ? vc : (T)0;
             }
             if (tc == jt) {                                // owners of column j: store the final L values
 #pragma unroll
@@ -111,23 +115,19 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(T *__restrict__ blk, in
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int row = 4 * tr + r, col = 4 * tc + c;
-                    if (row > j && col > j) a[r][c] = fma(-li[r], lc[c], a[r][c]);
-                }
-            if (inv) {
+                for (int c = 0; c < 4; ++c) a[r][c] = fma(-li[r], lc[c], a[r][c]);
+            if (INV) {
                 T xs[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) xs[k] = rowbuf[cur][4 * tc + k] * rinv;
+                if (tr == jt) {                            // owners of row j of X: it is final now
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 4 * tr + r;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        if (row > j) x[r][c] = fma(-li[r], xs[c], x[r][c]);
-                        else if (row == j) x[r][c] = xs[c];
-                    }
+                    for (int c = 0; c < 4; ++c) x[jo][c] = xs[c];
                 }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) x[r][c] = fma(-li[r], xs[c], x[r][c]);
                 const int jn2 = j + 1;
                 if (jn2 < IB && tr == (jn2 >> 2)) {
 #pragma unroll
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(T *__restrict__ blk, in
         for (int c = 0; c < 4; ++c) {
             const int row = 4 * tr + r, col = 4 * tc + c;
             if (row < jb && col <= row) blk[(int64_t)row * lda + col] = a[r][c];
-            if (inv) inv[row * IB + col] = (col <= row) ? x[r][c] : (T)0;
+            if (INV) inv[row * IB + col] = (col <= row) ? x[r][c] : (T)0;
         }
 }
 
@@ -316,7 +316,12 @@ static int potrf_panel_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, i
         }
         {
             ProfScope prof(PC_POTRF_DIAG, (double)jb * jb * jb / 3.0, st);
-            hipLaunchKernelGGL((potrf_diag_kernel<T>), dim3(1), dim3(256), 0, st, D, lda, r0, jb, info_dev, inv);
+            if (inv)
+                hipLaunchKernelGGL((potrf_diag_kernel<T, true>), dim3(1), dim3(256), 0, st, D, lda, r0, jb, info_dev,
+                                   inv);
+            else
+                hipLaunchKernelGGL((potrf_diag_kernel<T, false>), dim3(1), dim3(256), 0, st, D, lda, r0, jb,
+                                   info_dev, inv);
         }
         GPX_LAUNCH_CHECK();
         if (via_inverse) {
