@@ -47,6 +47,7 @@ def parse_args():
     ap.add_argument("--cpu-sample-n", type=int, default=6144)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip per-launch HIP-event profiling")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the N=8192 (configs[1]) side measurement")
     return ap.parse_args()
 
 
@@ -132,6 +133,26 @@ def main():
         return
 
     # ---- single GPU: everything through the gpx_gp handle, inputs resident in HBM ----
+    result = measure_single(args, lib, _lib, N, d, m, dtid, npdt, args.steps, args.warmup, local_rank,
+                            prof_on=not args.no_prof)
+    if not args.no_secondary and (N, d) != (8192, 8):
+        # BASELINE configs[1] (N=8192, d=8 fp64, 1024 test points), same run, for reference
+        sec = measure_single(args, lib, _lib, 8192, 8, 1024, _lib.F64, np.float64, 10, 2, local_rank,
+                             prof_on=False)
+        result["secondary"] = {"config": sec["config"]["workload"], "value": sec["value"], "unit": "s",
+                               "stages_ms": sec["stages_ms"], "potrf_tflops": sec["potrf_tflops"],
+                               "potrf_frac_of_peak": sec["potrf_frac_of_peak"], "log_lh": sec["log_lh"]}
+    if not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(N, d, m, args.cpu_sample_n)
+    print(json.dumps(result))
+
+
+def measure_single(args, lib, _lib, N, d, m, dtid, npdt, steps, warmup, local_rank, prof_on):
+    from gaussian_processes_amd.device import DeviceBuffer, sync
+    dtype_name = "f64" if dtid == _lib.F64 else "f32"
+    h, w, s = 1.0, 0.5 * np.sqrt(d), 1.0
+    params = np.array([h, w], dtype=np.float64)
+    X, y, Xo = synth(N, d, m, npdt)
     dX, dy, dXo = DeviceBuffer.from_host(X), DeviceBuffer.from_host(y), DeviceBuffer.from_host(Xo)
     dmean = DeviceBuffer((m,), npdt)
     handle = ctypes.c_void_p()
@@ -151,25 +172,25 @@ def main():
         _lib.check(lib.gpx_gp_log_lh(handle, ctypes.byref(out)))    # syncs the stream
         return out.value
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     sync()
-    if not args.no_prof:
+    if prof_on:
         _lib.check(lib.gpx_prof_enable(1))
     stage_ms = np.zeros(5)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         llh = step()
         ms = (ctypes.c_float * 5)()
         _lib.check(lib.gpx_gp_last_timing(handle, ms))
         stage_ms += np.array(list(ms))
     sync()
     elapsed = time.perf_counter() - t0
-    sec_per_step = elapsed / args.steps
-    stage_ms /= args.steps
+    sec_per_step = elapsed / steps
+    stage_ms /= steps
 
     prof = {}
-    if not args.no_prof:
+    if prof_on:
         names = ["kmat", "gemm_trailing", "potrf_diag", "trsm_rows", "trsv", "mean", "reduce",
                  "gemm_panel_bn64", "gemm_generic", "gemm_panel_bn128"]
         for cls, nm in enumerate(names):
@@ -183,29 +204,29 @@ def main():
     _lib.check(lib.gpx_gp_info(handle, ctypes.byref(info)))
     assert info.value == 0 and np.isfinite(llh) and np.isfinite(mean_host).all()
 
-    peak = FP64_MFMA_PEAK_TFLOPS if args.dtype == "f64" else FP32_MFMA_PEAK_TFLOPS
+    peak = FP64_MFMA_PEAK_TFLOPS if dtype_name == "f64" else FP32_MFMA_PEAK_TFLOPS
     roofline = None
     if prof.get("gemm_trailing", {}).get("ms", 0) > 0:
         g = prof["gemm_trailing"]
         achieved = g["work"] / (g["ms"] * 1e-3) / 1e12
         roofline = {"bound": "mfma",
                     "kernel": "gpx::gemm_nt_fast_kernel<%s, 128, 1> (trailing SYRK updates of the factorisation)"
-                              % ("double" if args.dtype == "f64" else "float"),
+                              % ("double" if dtype_name == "f64" else "float"),
                     "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": None,
-                    "launches_per_step": g["launches"] / args.steps,
+                    "launches_per_step": g["launches"] / steps,
                     "avg_launch_ms": round(g["ms"] / g["launches"], 4),
-                    "flops_per_step": g["work"] / args.steps}
+                    "flops_per_step": g["work"] / steps}
     potrf_tflops = (N ** 3 / 3.0) / (stage_ms[1] * 1e-3) / 1e12 if stage_ms[1] > 0 else None
 
     result = {
         "metric": "GP fit+predict wall-clock (kernel build + Cholesky + solve + log_lh + posterior mean)",
-        "value": round(sec_per_step, 4), "unit": "s", "n_gpus": 1, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(sec_per_step * 1e3, 2),
+        "value": round(sec_per_step, 4), "unit": "s", "n_gpus": 1, "steps": steps,
+        "warmup": warmup, "ms_per_step": round(sec_per_step * 1e3, 2),
         "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic",
+        "dtype": dtype_name, "data": "synthetic",
         "config": {"workload": "N=%d d=%d RBF(GaussianKernel) %s, m=%d test points, h=1 w=0.5*sqrt(d) s=1"
-                               % (N, d, args.dtype, m),
+                               % (N, d, dtype_name, m),
                    "N": N, "d": d, "m": m, "parallelism": "1 GPU"},
         "stages_ms": {k: round(float(v), 3) for k, v in
                       zip(("kernel_build", "potrf", "solve", "logdet_dot", "fit_total"), stage_ms)},
@@ -213,16 +234,16 @@ def main():
         "potrf_frac_of_peak": round(potrf_tflops / peak, 4) if potrf_tflops else None,
         "log_lh": llh,
         "roofline": roofline,
-        "kernels": {k: {"launches_per_step": v["launches"] / args.steps,
-                        "ms_per_step": round(v["ms"] / args.steps, 3)} for k, v in prof.items()},
+        "kernels": {k: {"launches_per_step": v["launches"] / steps,
+                        "ms_per_step": round(v["ms"] / steps, 3)} for k, v in prof.items()},
         "device": _lib.device_info(local_rank),
     }
     if prof.get("kmat", {}).get("ms", 0) > 0:
         result["kmat_write_GBps"] = round(prof["kmat"]["work"] / (prof["kmat"]["ms"] * 1e-3) / 1e9, 1)
     lib.gpx_gp_destroy(handle)
-    if not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(N, d, m, args.cpu_sample_n)
-    print(json.dumps(result))
+    for buf in (dX, dy, dXo, dmean):
+        buf.free()
+    return result
 
 
 if __name__ == "__main__":

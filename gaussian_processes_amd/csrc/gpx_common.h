@@ -85,6 +85,9 @@ int trsm_right_lt(int dtype, const void *L, int64_t n, int64_t ldl, void *X, int
 int logdet_chol(int dtype, const void *L, int64_t n, int64_t ldl, double *out_dev, hipStream_t st);
 int dot(int dtype, const void *a, const void *b, int64_t n, double *out_dev, hipStream_t st);
 int tril(int dtype, void *A, int64_t n, int64_t lda, hipStream_t st);
+int dloglh_reduce(int dtype, int kernel, const void *x, int64_t n, int d, const double *params,
+                  const void *alpha, const void *W, int64_t ldw, double *partial_dev, double *out4,
+                  hipStream_t st);
 int kmat(int dtype, int kernel, int member, const void *x1, int64_t n, const void *x2, int64_t m,
          int d, const double *params, double diag_add, int tri, void *out, int64_t ld, hipStream_t st);
 

@@ -432,6 +432,48 @@ int gpx_gp_get_inv_Kxx(gpx_gp_t *g, double *out, int64_t ld)
     return download_f64(g->dtype, out, ld, C.p, lda, n, n, 0, g->st);
 }
 
+// Gradient of the log marginal likelihood w.r.t. (kernel params..., s), RW06 eq. 5.9
+// (gp/gp.py:398-433 + gp_c.pyx:34-49): K^-1 is formed on the device (X = L^-T by the blocked
+// right-looking TRSM, W = X X^T lower triangle on the MFMA kernel), then ONE fused pass
+// reduces (alpha alpha^T - W) against the kernel derivatives evaluated on the fly.
+int gpx_gp_dloglh_dtheta(gpx_gp_t *g, double *out)
+{
+    GPX_ARG(g && g->fitted && out, "bad arguments");
+    const size_t es = esize(g->dtype);
+    const int64_t n = g->n, lda = g->lda;
+    double h4[4];
+    GPX_HIP(hipMemcpyAsync(h4, g->scal, sizeof(h4), hipMemcpyDeviceToHost, g->st));
+    GPX_HIP(hipStreamSynchronize(g->st));
+    int info;
+    memcpy(&info, &h4[3], sizeof(int));
+    if (info != 0) {                                   // gp/gp.py:424-428: NaN when K is not PD
+        for (int i = 0; i <= g->nparams; ++i) out[i] = NAN;
+        return GPX_OK;
+    }
+    DevBuf X, W, part, aa;
+    GPX_TRY(X.alloc((size_t)n * lda * es));
+    GPX_TRY(W.alloc((size_t)n * lda * es));
+    GPX_TRY(part.alloc((size_t)1024 * 4 * sizeof(double)));
+    GPX_TRY(aa.alloc(sizeof(double)));
+    dim3 grid((unsigned)cdiv(lda, 256), (unsigned)std::min<int64_t>(n, 32768)), block(256);
+    if (g->dtype == GPX_F64) hipLaunchKernelGGL((eye_kernel<double>), grid, block, 0, g->st, (double *)X.p, n, lda);
+    else hipLaunchKernelGGL((eye_kernel<float>), grid, block, 0, g->st, (float *)X.p, n, lda);
+    GPX_LAUNCH_CHECK();
+    GPX_HIP(hipMemsetAsync(W.p, 0, (size_t)n * lda * es, g->st));
+    GPX_TRY(trsm_right_lt(g->dtype, g->A, n, lda, X.p, n, lda, g->st));
+    GPX_TRY(gemm_nt(g->dtype, n, n, n, X.p, lda, X.p, lda, W.p, lda, 1.0, GPX_LOWER, 0, 0, g->st));
+    double p4[4];
+    GPX_TRY(dloglh_reduce(g->dtype, g->kernel, g->x, n, g->d, g->params, g->alpha, W.p, lda, (double *)part.p,
+                          p4, g->st));
+    GPX_TRY(dot(g->dtype, g->alpha, g->alpha, n, (double *)aa.p, g->st));
+    double ata = 0.0;
+    GPX_HIP(hipMemcpyAsync(&ata, aa.p, sizeof(double), hipMemcpyDeviceToHost, g->st));
+    GPX_HIP(hipStreamSynchronize(g->st));
+    for (int i = 0; i < g->nparams; ++i) out[i] = 0.5 * p4[i];
+    out[g->nparams] = g->s * (ata - p4[3]);            // dK/ds = 2 s I  (gp_c.pyx:46)
+    return GPX_OK;
+}
+
 int gpx_gp_last_timing(gpx_gp_t *g, float *ms5)
 {
     GPX_ARG(g && g->fitted && ms5, "bad arguments");

@@ -12,6 +12,7 @@
 // sum_k (a_k - b_k)^2 (never |a|^2+|b|^2-2ab: that loses the digits near r = 0
 // that the reference keeps).
 #include "gpx_common.h"
+#include <vector>
 
 namespace gpx {
 
@@ -381,6 +382,148 @@ static int launch_mean(int kernel, const void *xo, int64_t m, const void *x, int
                            (const T *)xo, m, (const T *)x, n, d, kp, (const T *)alpha, (T *)out);
     }
     GPX_LAUNCH_CHECK();
+    return GPX_OK;
+}
+
+
+// ---------------------------------------------------------------------------
+// Fused gradient reduction (gp/ext/gp_c.pyx:34-49 without its dense products):
+//   P[p]  = sum_{j,k} (alpha_j alpha_k - W[j,k]) * dK_p(x_j, x_k)      p < n_kp
+//   P[n_kp] = trace(W)
+// with W = K^-1 (lower triangle read; both W and dK_p are symmetric, so the sum runs over
+// the lower triangle with weight 2 off the diagonal).  The kernel derivatives are evaluated
+// on the fly from the squared distance (no n x n Jacobian is materialised).  Deterministic:
+// a fixed grid of workgroups walks the tiles in a fixed order, per-workgroup partial sums
+// are written out and added up by the host in index order.
+// ---------------------------------------------------------------------------
+struct GradParams {
+    double c1, c2h, c2w, c3w;      // gaussian: e = c1*d2 ; dK_dh = c2h*exp(e) ; dK_dw = exp(e)*(c3w*d2 - c2w)
+    double h, w, p;                // periodic
+    int kernel, nkp;
+};
+
+constexpr int GR_T = 64;           // tile edge
+constexpr int GR_BLOCKS = 1024;
+
+template <typename T>
+__global__ __launch_bounds__(256) void dloglh_reduce_kernel(const T *__restrict__ x, int64_t n, int d,
+                                                            const T *__restrict__ alpha,
+                                                            const T *__restrict__ W, int64_t ldw,
+                                                            GradParams gp, int64_t ntiles_r,
+                                                            double *__restrict__ partial)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *s1 = reinterpret_cast<T *>(smem_raw);          // [GR_T][d]   rows
+    T *s2 = s1 + (size_t)GR_T * d;                    // [d][GR_T]   columns, transposed
+    T *sa1 = s2 + (size_t)GR_T * d;                   // alpha rows
+    T *sa2 = sa1 + GR_T;                              // alpha cols
+    __shared__ double red[4][4];
+    const int tid = threadIdx.x, col = tid & 63, rg = tid >> 6;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};             // up to 3 kernel params + trace
+    const int64_t total = ntiles_r * (ntiles_r + 1) / 2;
+    for (int64_t t = blockIdx.x; t < total; t += gridDim.x) {
+        int64_t tr = (int64_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+        while ((tr + 1) * (tr + 2) / 2 <= t) ++tr;
+        while (tr * (tr + 1) / 2 > t) --tr;
+        const int64_t tc = t - tr * (tr + 1) / 2;
+        const int64_t r0 = tr * GR_T, c0 = tc * GR_T;
+        __syncthreads();
+        for (int idx = tid; idx < GR_T * d; idx += 256) {
+            const int r = idx / d, k = idx - r * d;
+            s1[idx] = (r0 + r < n) ? x[(r0 + r) * d + k] : (T)0;
+            s2[(size_t)k * GR_T + r] = (c0 + r < n) ? x[(c0 + r) * d + k] : (T)0;
+        }
+        if (tid < GR_T) {
+            sa1[tid] = (r0 + tid < n) ? alpha[r0 + tid] : (T)0;
+            sa2[tid] = (c0 + tid < n) ? alpha[c0 + tid] : (T)0;
+        }
+        __syncthreads();
+        const int64_t gc = c0 + col;
+        const T ak = sa2[col];
+        for (int i = 0; i < 16; ++i) {
+            const int r = rg + 4 * i;
+            const int64_t gr = r0 + r;
+            if (gr >= n || gc >= n || gc > gr) continue;
+            const double wt = (gc == gr) ? 1.0 : 2.0;
+            const double wjk = (double)W[gr * ldw + gc];
+            const double coef = wt * ((double)sa1[r] * (double)ak - wjk);
+            if (gc == gr) acc[3] += wjk;
+            if (gp.kernel == GPX_KERNEL_GAUSSIAN) {
+                T d2 = (T)0;
+                for (int k = 0; k < d; ++k) {
+                    const T tt = s1[r * d + k] - s2[(size_t)k * GR_T + col];
+                    d2 = fma(tt, tt, d2);
+                }
+                const double e = gp.c1 * (double)d2;
+                if (!(e < GPX_MIN_LOG)) {
+                    const double ex = exp(e);
+                    acc[0] += coef * (gp.c2h * ex);
+                    acc[1] += coef * (ex * (gp.c3w * (double)d2 - gp.c2w));
+                }
+            } else {
+                const T dd = s1[r] - s2[col];          // d == 1
+                acc[0] += coef * (double)periodic_entry<T>(GPX_DK_DH, dd, (T)gp.h, (T)gp.w, (T)gp.p);
+                acc[1] += coef * (double)periodic_entry<T>(GPX_DK_DW, dd, (T)gp.h, (T)gp.w, (T)gp.p);
+                acc[2] += coef * (double)periodic_entry<T>(GPX_DK_DP, dd, (T)gp.h, (T)gp.w, (T)gp.p);
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        double v = acc[q];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((tid & 63) == 0) red[tid >> 6][q] = v;
+    }
+    __syncthreads();
+    if (tid < 4) partial[(int64_t)blockIdx.x * 4 + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+}
+
+// partial: GR_BLOCKS * 4 doubles of DEVICE memory; out4: host, [P0, P1, P2, trace W]
+int dloglh_reduce(int dtype, int kernel, const void *x, int64_t n, int d, const double *params,
+                  const void *alpha, const void *W, int64_t ldw, double *partial_dev, double *out4,
+                  hipStream_t st)
+{
+    GradParams gpar;
+    memset(&gpar, 0, sizeof(gpar));
+    gpar.kernel = kernel;
+    if (kernel == GPX_KERNEL_GAUSSIAN) {
+        const double h = params[0], w = params[1], S = sqrt(2.0 / M_PI);
+        gpar.nkp = 2;
+        gpar.c1 = -0.5 / (w * w);
+        gpar.c2h = S * h / w;                          // gaussian_c.pyx:61
+        gpar.c2w = 0.5 * S * h * h / (w * w);          // :82
+        gpar.c3w = 0.5 * S * h * h / pow(w, 4);        // :83
+    } else {
+        if (d != 1) { set_error("periodic gradient needs d == 1"); return GPX_ERR_UNSUPPORTED; }
+        gpar.nkp = 3; gpar.h = params[0]; gpar.w = params[1]; gpar.p = params[2];
+    }
+    const size_t es = esize(dtype);
+    const size_t smem = ((size_t)2 * GR_T * d + 2 * GR_T) * es;
+    const int64_t ntr = cdiv(n, GR_T);
+    const int blocks = (int)std::min<int64_t>(GR_BLOCKS, ntr * (ntr + 1) / 2);
+    GPX_HIP(hipMemsetAsync(partial_dev, 0, (size_t)GR_BLOCKS * 4 * sizeof(double), st));
+    if (dtype == GPX_F64) {
+        if (smem > 48 * 1024)
+            GPX_HIP(hipFuncSetAttribute((const void *)dloglh_reduce_kernel<double>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL((dloglh_reduce_kernel<double>), dim3(blocks), dim3(256), smem, st, (const double *)x, n,
+                           d, (const double *)alpha, (const double *)W, ldw, gpar, ntr, partial_dev);
+    } else {
+        if (smem > 48 * 1024)
+            GPX_HIP(hipFuncSetAttribute((const void *)dloglh_reduce_kernel<float>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL((dloglh_reduce_kernel<float>), dim3(blocks), dim3(256), smem, st, (const float *)x, n, d,
+                           (const float *)alpha, (const float *)W, ldw, gpar, ntr, partial_dev);
+    }
+    GPX_LAUNCH_CHECK();
+    std::vector<double> host((size_t)GR_BLOCKS * 4);
+    GPX_HIP(hipMemcpyAsync(host.data(), partial_dev, host.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    GPX_HIP(hipStreamSynchronize(st));
+    for (int q = 0; q < 4; ++q) {
+        double v = 0.0;
+        for (int b = 0; b < GR_BLOCKS; ++b) v += host[(size_t)b * 4 + q];
+        out4[q] = v;
+    }
     return GPX_OK;
 }
 

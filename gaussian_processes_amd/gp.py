@@ -361,7 +361,17 @@ class GP(object):
 
     @memoprop
     def dloglh_dtheta(self):
-        out, Ki = self._nan_or(len(self.params))
+        r"""Gradient of the log marginal likelihood, RW06 eq. 5.9 (gp/gp.py:398-433).  Native
+        kernels: computed entirely on the device (K^-1 never leaves HBM, the kernel Jacobian
+        is never materialised); plugin kernels: the reference's formula with device products."""
+        npar = len(self.params)
+        native = getattr(self.K, "_native_kernel", None) is not None
+        if native and (self._d == 1 or self.K._native_kernel == _lib.KERNEL_GAUSSIAN):
+            st = self._fit()
+            out = np.empty(npar, dtype=DTYPE)
+            _lib.check(_lib.load().gpx_gp_dloglh_dtheta(st.handle, _lib.dptr(out)))
+            return out
+        out, Ki = self._nan_or(npar)
         if Ki is not None:
             gp_c.dloglh_dtheta(self._y, Ki, self.Kxx_J, self.inv_Kxx_y, self._s, out)
         return out

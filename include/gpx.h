@@ -263,6 +263,11 @@ int gpx_gp_get_Lxx(gpx_gp_t *gp, double *out, int64_t ld);
 int gpx_gp_get_alpha(gpx_gp_t *gp, double *out);
 /* K^-1 = L^-T L^-1 (gp/gp.py:311-312) -> out (n, n) HOST float64 */
 int gpx_gp_get_inv_Kxx(gpx_gp_t *gp, double *out, int64_t ld);
+/* d log_lh / d(theta): out[n_params + 1] HOST float64, order (kernel params..., s).  RW06 eq. 5.9
+ * (gp/gp.py:398-433, gp_c.pyx:34-49) computed on the device: K^-1 by TRSM + SYRK on the MFMA
+ * kernel, then one fused pass against kernel derivatives evaluated on the fly.  All NaN when the
+ * factorisation failed (gp/gp.py:424-428).  Periodic kernel: d == 1 only. */
+int gpx_gp_dloglh_dtheta(gpx_gp_t *gp, double *out);
 /* timing of the last fit, milliseconds per stage (HIP events on the handle's
  * stream): [0] kernel build [1] potrf [2] solve [3] logdet+dot [4] total */
 int gpx_gp_last_timing(gpx_gp_t *gp, float *ms5);

@@ -515,3 +515,30 @@ def test_ragged_sizes_above_the_nb1024_threshold(N, d):
     np.testing.assert_allclose(g.log_lh, -0.5 * y @ alpha - 0.5 * logdet - 0.5 * N * np.log(2 * np.pi), rtol=1e-12)
     np.testing.assert_allclose(g.mean(Xo)[:8], orc.kernel_matrix("gaussian", "K", Xo[:8], X, (h, w)) @ alpha,
                                rtol=1e-9, atol=1e-11)
+
+
+def test_device_gradient_vs_oracle_and_finite_differences():
+    # dloglh_dtheta computed on the device (K^-1 stays in HBM)
+    N, d = 700, 3
+    X, y, _ = orc.synth_inputs(N, d, 4)
+    h, w, s = 0.9, 0.6 * np.sqrt(d), 0.7
+    g = gp.GP(gp.GaussianKernel(h, w), X, y, s=s)
+    o = orc.OracleGP("gaussian", (h, w), X, y, s)
+    grad = g.dloglh_dtheta
+    np.testing.assert_allclose(grad, o.dloglh_dtheta, rtol=1e-7, atol=1e-9)
+    # central finite differences of the device log_lh (the reference's own check, test_gp.py:75-97)
+    eps = 1e-5
+    fd = np.empty(3)
+    for i in range(3):
+        p0, p1 = g.params.copy(), g.params.copy()
+        p0[i] -= eps; p1[i] += eps
+        g0, g1 = g.copy(), g.copy()
+        g0.params = p0; g1.params = p1
+        fd[i] = (g1.log_lh - g0.log_lh) / (2 * eps)
+    np.testing.assert_allclose(grad, fd, rtol=1e-5, atol=1e-6)
+    # 1-D periodic
+    x1 = np.sort(np.random.RandomState(3).uniform(-5, 5, 300))
+    y1 = np.sin(x1)
+    gpk = gp.GP(gp.PeriodicKernel(1.1, 0.8, 2.3), x1, y1, s=0.5)
+    opk = orc.OracleGP("periodic", (1.1, 0.8, 2.3), x1, y1, 0.5)
+    np.testing.assert_allclose(gpk.dloglh_dtheta, opk.dloglh_dtheta, rtol=1e-7, atol=1e-9)
