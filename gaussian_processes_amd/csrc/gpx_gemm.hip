@@ -465,7 +465,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_fast_kernel(int64_t M, int64_t
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: keep it scalar
     const int wr = wave >> 1, wc = wave & 1;
 
     unsigned long long st0 = 0, st1 = 0, st2 = 0;
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_fast_kernel(int64_t M, int64_t
     }
 
     // ---- DMA source pointers: wave w owns pieces PW*w .. PW*w + PW-1 (1 KiB = 8 rows each) of every stage ----
-    const unsigned char *gsrc[PW];
+    const unsigned char *gsrc[PW];      // next 128-B k-slice to fetch, per DMA piece
     {
         const int r_in = lane >> 3, c = lane & 7;
 #pragma unroll
@@ -493,13 +494,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_fast_kernel(int64_t M, int64_t
             }
         }
     }
-    auto issue = [&](int kt, int stage) {
+    auto issue = [&](int stage) {            // whole stage (prologue); advances the source pointers
         unsigned char *dst = smem + stage * F_STAGE + (wave * PW) * 1024;
 #pragma unroll
         for (int j = 0; j < PW; ++j) {
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void *)(gsrc[j] + (size_t)kt * G_ROWB),
-                (__attribute__((address_space(3))) void *)(dst + j * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc[j],
+                                             (__attribute__((address_space(3))) void *)(dst + j * 1024), 16, 0, 0);
+            gsrc[j] += G_ROWB;
         }
     };
 
@@ -513,9 +514,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_fast_kernel(int64_t M, int64_t
 
     const int nk = (int)(K / EPK);
     // three stages in flight before the first wait
-    issue(0, 0);
-    if (nk > 1) issue(1, 1);
-    if (nk > 2) issue(2, 2);
+    issue(0);
+    if (nk > 1) issue(1);
+    if (nk > 2) issue(2);
 
     // Fragment reads are inline asm: hipcc cannot prove that the in-flight LDS-DMA
     // writes (other stages) do not alias them and would otherwise drain vmcnt(0)
@@ -538,11 +539,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_fast_kernel(int64_t M, int64_t
     //   8 x { 4 MFMA(R1) ; DMA piece g of stage kt+3 -> buffer kt%3 ; ds_read R0(kt+1)[g] }
     constexpr int H = SUB / 2;
     u4_t r0a[4], r0b[4], r1a[4], r1b[4];
-    auto issue1 = [&](int kt, int stage, int j) {
+    auto issue1 = [&](int stage, int j) {    // one piece of the next un-fetched k-slice
         unsigned char *dst = smem + stage * F_STAGE + (wave * PW + j) * 1024;
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void *)(gsrc[j] + (size_t)kt * G_ROWB),
-            (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc[j],
+                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        gsrc[j] += G_ROWB;
     };
 #define GPX_SLOT_READ(g, RA, RB, AA, AB)                                                        \
     do {                                                                                        \
@@ -623,7 +624,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_fast_kernel(int64_t M, int64_t
                     for (int j = 0; j < NTW; ++j) acc[i][j] = MF<T>::mfma(ha[i][ss], hb[j][ss], acc[i][j]);
                     __builtin_amdgcn_sched_barrier(0);
                     const int g = ss * 4 + i;
-                    if (g < PW && more3 && !(fm.ablate & 2)) issue1(kt + 3, stage, g);  // into the buffer just consumed
+                    if (g < PW && more3 && !(fm.ablate & 2)) issue1(stage, g);  // into the buffer just consumed
                     if (g < 8 && more1 && !(fm.ablate & 4)) GPX_SLOT_READ(g, r0a, r0b, aa0, ab0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
