@@ -494,16 +494,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_fast_kernel(int64_t M, int64_t
             }
         }
     }
-    auto issue = [&](int stage) {            // whole stage (prologue); advances the source pointers
-        unsigned char *dst = smem + stage * F_STAGE + (wave * PW) * 1024;
-#pragma unroll
-        for (int j = 0; j < PW; ++j) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc[j],
-                                             (__attribute__((address_space(3))) void *)(dst + j * 1024), 16, 0, 0);
-            gsrc[j] += G_ROWB;
-        }
-    };
-
     acc_t acc[4][NTW];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -514,9 +504,22 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_fast_kernel(int64_t M, int64_t
 
     const int nk = (int)(K / EPK);
     // three stages in flight before the first wait
-    issue(0);
-    if (nk > 1) issue(1);
-    if (nk > 2) issue(2);
+    // three stages in flight before the first wait; when K has fewer than three slices the
+    // extra stages re-fetch the last slice (never read)
+    {
+        unsigned char *dst0 = smem + (wave * PW) * 1024;
+#pragma unroll
+        for (int st3 = 0; st3 < 3; ++st3) {
+            const int inc = (st3 + 1 < nk) ? G_ROWB : 0;
+#pragma unroll
+            for (int j = 0; j < PW; ++j) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc[j],
+                                                 (__attribute__((address_space(3))) void *)(dst0 + st3 * F_STAGE + j * 1024),
+                                                 16, 0, 0);
+                gsrc[j] += inc;
+            }
+        }
+    }
 
     // Fragment reads are inline asm: hipcc cannot prove that the in-flight LDS-DMA
     // writes (other stages) do not alias them and would otherwise drain vmcnt(0)
@@ -539,11 +542,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_fast_kernel(int64_t M, int64_t
     //   8 x { 4 MFMA(R1) ; DMA piece g of stage kt+3 -> buffer kt%3 ; ds_read R0(kt+1)[g] }
     constexpr int H = SUB / 2;
     u4_t r0a[4], r0b[4], r1a[4], r1b[4];
-    auto issue1 = [&](int stage, int j) {    // one piece of the next un-fetched k-slice
+    // one piece of the next un-fetched k-slice.  Issued unconditionally: past the last slice
+    // the increment is 0, so the tail re-fetches the final slice into a buffer nobody reads
+    // any more (no branch in the k-loop, always the same vmcnt bookkeeping).
+    auto issue1 = [&](int stage, int j, int inc) {
         unsigned char *dst = smem + stage * F_STAGE + (wave * PW + j) * 1024;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc[j],
                                          (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-        gsrc[j] += G_ROWB;
+        gsrc[j] += inc;
     };
 #define GPX_SLOT_READ(g, RA, RB, AA, AB)                                                        \
     do {                                                                                        \
@@ -559,15 +565,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_fast_kernel(int64_t M, int64_t
     } while (0)
 
     // stage 0 landed (this wave's pieces), then everybody's
-    if (PW == 6) {
-        if (nk > 2)       asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if (nk == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-        if (nk > 2)       asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        else if (nk == 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        else              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    if (PW == 6) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else         asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (fm.stamps) st1 = __builtin_amdgcn_s_memtime();
     {
@@ -582,7 +581,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_fast_kernel(int64_t M, int64_t
         int nstage = stage + 1; if (nstage >= F_NST) nstage = 0;
         const unsigned sn = (unsigned)(nstage * F_STAGE);
         const unsigned aa0 = a_base + sn + rd0, ab0 = b_base + sn + rd0;
-        const bool more1 = kt + 1 < nk, more3 = kt + 3 < nk;
+        const int inc = (kt + 4 < nk) ? G_ROWB : 0;       // slice kt+3 is fetched now; is there a kt+4?
 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // R0 of this stage is in
         __builtin_amdgcn_sched_barrier(0);
@@ -602,13 +601,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_fast_kernel(int64_t M, int64_t
                 }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // R1 in: this wave is done reading the stage
-        if (more1 && !(fm.ablate & 1)) {
-            if (kt + 2 < nk) {
-                if (PW == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                else         asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
+        if (!(fm.ablate & 1)) {
+            if (PW == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else         asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -624,14 +619,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_fast_kernel(int64_t M, int64_t
                     for (int j = 0; j < NTW; ++j) acc[i][j] = MF<T>::mfma(ha[i][ss], hb[j][ss], acc[i][j]);
                     __builtin_amdgcn_sched_barrier(0);
                     const int g = ss * 4 + i;
-                    if (g < PW && more3 && !(fm.ablate & 2)) issue1(stage, g);  // into the buffer just consumed
-                    if (g < 8 && more1 && !(fm.ablate & 4)) GPX_SLOT_READ(g, r0a, r0b, aa0, ab0);
+                    if (g < PW && !(fm.ablate & 2)) issue1(stage, g, inc);      // into the buffer just consumed
+                    if (g < 8 && !(fm.ablate & 4)) GPX_SLOT_READ(g, r0a, r0b, aa0, ab0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
         }
         stage = nstage;
     }
 #undef GPX_SLOT_READ
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // tail DMA / reads must not outlive the tile
 
     if (fm.stamps) { __builtin_amdgcn_s_barrier(); st2 = __builtin_amdgcn_s_memtime(); }   // all waves done
     if (fm.atomic_c && !beta0)
