@@ -8,10 +8,8 @@
 // Roofline: HBM read bandwidth -- a single-right-hand-side solve reads the
 // lower triangle of L once per direction (n^2/2 * sizeof(T) bytes, 2 n^2 flop for
 // both directions together).  The 64 x 64 diagonal blocks are inverted up front in
-// ONE batched launch (trinv64_kernel); each 64-wide block step is then one launch
-// whose workgroups all form z = inv(L_jj) b_j by a 64 x 64 mat-vec (no serial
-// substitution on the critical path) and stream their own slice of the panel
-// below (forward) / to the left (backward) in coalesced rows.
+// ONE batched launch (trinv64_kernel); the solve then advances 512 columns per
+// launch (trsv_fwd_fused / trsv_bwd_fused below).
 #include "gpx_common.h"
 
 namespace gpx {
@@ -21,9 +19,11 @@ constexpr int SBP = SB + 1;
 
 // ---- batched inverse of the 64 x 64 diagonal blocks --------------------------
 // One workgroup per block (all blocks in one launch); lane c builds column c of
-// inv(L_jj) by forward substitution.  Blocks shorter than 64 are padded with the
-// identity.  Output: Linv[blk][64][64], row-major, strictly-upper part zero.
-template <typename T>
+// X = inv(L_jj) by forward substitution.  Blocks shorter than 64 are padded with
+// the identity.  Output W[blk][64][64] laid out for coalesced mat-vec reads (lane =
+// output row): FWD  W[c*64 + r] = X[r][c]  (z = X v);  !FWD  W[c*64 + r] = X[c][r]
+// (a = X^T v).
+template <typename T, bool FWD>
 __global__ __launch_bounds__(64) void trinv64_kernel(const T *__restrict__ L, int64_t ldl, int64_t ncols,
                                                      T *__restrict__ Linv)
 {
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(64) void trinv64_kernel(const T *__restrict__ L, in
     }
     __syncthreads();
     T *out = Linv + (int64_t)blockIdx.x * SB * SB;
-    for (int i = 0; i < SB; ++i) out[i * SB + c] = sX[i * SBP + c];
+    for (int i = 0; i < SB; ++i) out[i * SB + c] = FWD ? sX[c * SBP + i] : sX[i * SBP + c];
 }
 
 // grow-only device scratch for the block inverses (one per host thread)
@@ -69,73 +69,335 @@ static int scratch(size_t bytes, void **out)
     return GPX_OK;
 }
 
-// z = Linv_blk * v (forward) or Linv_blk^T * v (backward) for one 64-block, by all
-// 256 threads of the workgroup; v in LDS (sv), result to LDS (sz).
-template <typename T, bool TRANS>
-__device__ __forceinline__ void block_matvec(const T *__restrict__ Li, const T *sv, T *sz, T *red, int tid)
+// ---- fused block steps of the single-right-hand-side solves ----------------
+// The solve advances in blocks of TB = 512 columns, ONE launch per block (the chain
+// of dependent launches, not bandwidth, bounded the old 64-wide stepping: 2 x 1024
+// launches of ~11 us at n = 65536).  In the launch that follows the solution of
+// block p:
+//   workgroup 0     applies block p to the rows (forward) / columns (backward) of
+//                   the NEXT block only -- a TB x TB tile -- and then solves that
+//                   block: 64-wide sub-steps, z = inv(L_ss) v by a 64 x 64 mat-vec
+//                   with the precomputed inverse, right-looking update inside the
+//                   block through LDS;
+//   workgroups 1..  stream the rest of block p's panel (everything beyond the next
+//                   block) against the same solution -- the HBM-bound part.
+// Nothing a later block needs is ever produced by two workgroups of one launch, so
+// launch order is the only synchronisation.
+constexpr int TB = 512;
+constexpr int TBT = 512;          // threads per workgroup
+constexpr int TCH = TB / 128;     // 128-column chunks of a block row (2 per lane and chunk)
+
+template <typename T>
+__device__ __forceinline__ void load2(const T *p, bool aligned, T &v0, T &v1)
 {
-    const int r = tid & 63, part = tid >> 6;            // 4 partial sums per output row
-    T acc = (T)0;
-#pragma unroll
-    for (int cc = 0; cc < 16; ++cc) {
-        const int c = part * 16 + cc;
-        const T m = TRANS ? Li[c * SB + r] : Li[r * SB + c];
-        acc = fma(m, sv[c], acc);
+    if (aligned) {
+        if constexpr (sizeof(T) == 8) {
+            const double2 t = *reinterpret_cast<const double2 *>(p);
+            v0 = t.x; v1 = t.y;
+        } else {
+            const float2 t = *reinterpret_cast<const float2 *>(p);
+            v0 = t.x; v1 = t.y;
+        }
+    } else {
+        v0 = p[0]; v1 = p[1];
     }
-    red[part * SB + r] = acc;
-    __syncthreads();
-    if (tid < SB) sz[tid] = ((red[tid] + red[SB + tid]) + red[2 * SB + tid]) + red[3 * SB + tid];
-    __syncthreads();
 }
 
-// forward: z = inv(L_jj) b[k0:k0+jb], x[k0:k0+jb] = z, b[r] -= L[r, k0:k0+jb] . z for r >= k0 + jb
-template <typename T>
-__global__ __launch_bounds__(256) void trsv_fwd_step(const T *__restrict__ L, int64_t ldl,
-                                                     const T *__restrict__ Linv, T *__restrict__ b,
-                                                     T *__restrict__ x, int64_t k0, int jb, int64_t n)
+// sum over the 16 lanes of a DPP row, result in every lane of the row: two quad
+// butterflies, then row_half_mirror and row_mirror (VALU only, no LDS traffic)
+template <int CTRL> __device__ __forceinline__ double dpp_mov(double v)
 {
-    __shared__ T sTile[SB * SBP];
-    __shared__ T sv[SB], sz[SB], red[4 * SB];
-    const int tid = threadIdx.x;
-    if (tid < SB) sv[tid] = (tid < jb) ? b[k0 + tid] : (T)0;
-    // this workgroup's slice of the panel below: 64 rows x jb columns, coalesced along the row
-    const int64_t r0 = k0 + jb + (int64_t)blockIdx.x * SB;
-    for (int idx = tid; idx < SB * SB; idx += 256) {
-        const int i = idx >> 6, c = idx & 63;
-        sTile[i * SBP + c] = (r0 + i < n && c < jb) ? L[(r0 + i) * ldl + k0 + c] : (T)0;
-    }
-    __syncthreads();
-    block_matvec<T, false>(Linv + (k0 / SB) * SB * SB, sv, sz, red, tid);
-    if (blockIdx.x == 0 && tid < jb) x[k0 + tid] = sz[tid];
-    // 4 lanes per row, 16 columns each
-    const int row = tid >> 2, part = tid & 3;
-    T acc = (T)0;
-#pragma unroll
-    for (int c = 0; c < 16; ++c) acc = fma(sTile[row * SBP + part * 16 + c], sz[part * 16 + c], acc);
-    acc += __shfl_xor(acc, 1, 64);
-    acc += __shfl_xor(acc, 2, 64);
-    if (part == 0 && r0 + row < n) b[r0 + row] -= acc;
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v)
+{
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <typename T> __device__ __forceinline__ T row16_sum(T v)
+{
+    v += dpp_mov<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);     // row_half_mirror
+    v += dpp_mov<0x140>(v);     // row_mirror
+    return v;
+}
+template <typename T> __device__ __forceinline__ T lanes32_sum(T v)
+{
+    v = row16_sum(v);
+    return v + __shfl_xor(v, 16, 64);
+}
+template <typename T> __device__ __forceinline__ T lanes64_sum(T v)
+{
+    v = lanes32_sum(v);
+    return v + __shfl_xor(v, 32, 64);
 }
 
-// backward: a = inv(L_jj)^T b[k0:k0+jb], x[k0:k0+jb] = a, b[c] -= sum_i L[k0+i, c] a_i for c < k0
-template <typename T>
-__global__ __launch_bounds__(256) void trsv_bwd_step(const T *__restrict__ L, int64_t ldl,
-                                                     const T *__restrict__ Linv, T *__restrict__ b,
-                                                     T *__restrict__ x, int64_t k0, int jb)
+// out[i] = sum_c L[r + i, p0 + c] * z[c], i < RU, for one wave: lane owns columns
+// 128 j + 2 lane (+1); all RU * TCH loads are issued before the first use.
+// FULL: the block has all TB columns (no column guards).
+template <typename T, int RU, bool FULL>
+__device__ __forceinline__ void rows_dot(const T *__restrict__ L, int64_t ldl, int64_t p0, int pjb,
+                                         int64_t r, int64_t rlast, const T (&zr)[TCH][2], int lane,
+                                         bool aligned, T (&out)[RU])
 {
-    __shared__ T sv[SB], sz[SB], red[4 * SB];
-    const int tid = threadIdx.x;
-    if (tid < SB) sv[tid] = (tid < jb) ? b[k0 + tid] : (T)0;
-    __syncthreads();
-    block_matvec<T, true>(Linv + (k0 / SB) * SB * SB, sv, sz, red, tid);
-    if (blockIdx.x == 0 && tid < jb) x[k0 + tid] = sz[tid];
-    const int64_t c = (int64_t)blockIdx.x * 256 + tid;
-    if (c < k0) {
-        const T *col = L + k0 * ldl + c;
+    T l[RU][TCH][2];
+#pragma unroll
+    for (int i = 0; i < RU; ++i) {
+        const T *row = L + min(r + i, rlast) * ldl + p0;          // clamped: in bounds, result unused
+#pragma unroll
+        for (int j = 0; j < TCH; ++j) {
+            const int c = j * 128 + 2 * lane;
+            if (FULL) {
+                load2(row + c, aligned, l[i][j][0], l[i][j][1]);
+            } else {
+                l[i][j][0] = (T)0; l[i][j][1] = (T)0;
+                if (c + 1 < pjb) load2(row + c, aligned, l[i][j][0], l[i][j][1]);
+                else if (c < pjb) l[i][j][0] = row[c];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < RU; ++i) {
         T acc = (T)0;
-#pragma unroll 8
-        for (int i = 0; i < jb; ++i) acc = fma(col[(int64_t)i * ldl], sz[i], acc);
-        b[c] -= acc;
+#pragma unroll
+        for (int j = 0; j < TCH; ++j) { acc = fma(l[i][j][0], zr[j][0], acc); acc = fma(l[i][j][1], zr[j][1], acc); }
+        out[i] = lanes64_sum(acc);
+    }
+}
+
+template <typename T> __device__ __forceinline__ T lanes8_sum(T v)
+{
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    return v;
+}
+
+// z = X v (forward) / a = X^T v (backward) for one 64-block by the whole workgroup:
+// lane = output row, wave w sums columns 8 w .. 8 w + 7 (li = that slice of the stored
+// inverse, already in registers), fixed-order reduction over the 8 waves.
+template <typename T>
+__device__ __forceinline__ void inv_matvec(const T (&li)[8], const T *sv_s, T *red, T *out64, T *xout,
+                                           int nvalid, int tid, int lane, int wave)
+{
+    T acc = (T)0;
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) acc = fma(li[cc], sv_s[wave * 8 + cc], acc);
+    red[wave * SB + lane] = acc;
+    __syncthreads();
+    if (tid < SB) {
+        T z = red[tid];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) z += red[q * SB + tid];
+        out64[tid] = z;
+        if (tid < nvalid) xout[tid] = z;
+    }
+    __syncthreads();
+}
+
+// forward.  x[p0:p0+pjb] (block p) is final.  Workgroup 0 solves block [k0, k0+jb)
+// from b (nothing when jb == 0); workgroups w >= 1 apply block p to 64 rows each of
+// [far0, n):  b[r] -= L[r, p0:p0+pjb] . x[p0:p0+pjb].
+template <typename T>
+__global__ __launch_bounds__(TBT) void trsv_fwd_fused(const T *__restrict__ L, int64_t ldl,
+                                                      const T *__restrict__ Linv, T *__restrict__ b,
+                                                      T *__restrict__ x, int64_t n, int64_t k0, int jb,
+                                                      int64_t p0, int pjb, int64_t far0, int aligned_i, int ablate)
+{
+    __shared__ T szp[TB + 2];       // far workgroups: solution of block p, zero padded
+    __shared__ T sv[TB];            // workgroup 0: right-hand side of the block being solved
+    __shared__ T szb[TB];           // workgroup 0: solution of the block so far
+    __shared__ T red[8 * SB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool aligned = aligned_i != 0;
+
+    if (blockIdx.x != 0) {
+        if (pjb <= 0 || (ablate & 4)) return;
+        for (int i = tid; i < TB + 2; i += TBT) szp[i] = (i < pjb) ? x[p0 + i] : (T)0;
+        __syncthreads();
+        T zr[TCH][2];
+#pragma unroll
+        for (int j = 0; j < TCH; ++j) { zr[j][0] = szp[j * 128 + 2 * lane]; zr[j][1] = szp[j * 128 + 2 * lane + 1]; }
+        const int64_t rbeg = far0 + (int64_t)(blockIdx.x - 1) * 64, rend = min(n, rbeg + 64);
+        constexpr int RU = 8;
+        for (int64_t r = rbeg + wave * RU; r < rend; r += (TBT / 64) * RU) {
+            T acc[RU];
+            if (pjb == TB) rows_dot<T, RU, true>(L, ldl, p0, pjb, r, rend - 1, zr, lane, aligned, acc);
+            else rows_dot<T, RU, false>(L, ldl, p0, pjb, r, rend - 1, zr, lane, aligned, acc);
+            if (lane < RU && r + lane < rend) {
+                T mine = acc[0];
+#pragma unroll
+                for (int i = 1; i < RU; ++i) mine = (lane == i) ? acc[i] : mine;
+                b[r + lane] -= mine;
+            }
+        }
+        return;
+    }
+    if (jb == 0) return;
+
+    // in-block chain, LEFT-looking over 64-wide sub-blocks: sub-block s subtracts
+    // L[rows of s, columns 0 .. 64 s) . z[0 .. 64 s) -- 8 lanes per row, a lane takes 2 of
+    // every 16 columns, so each row is read as whole 128-byte lines -- and then forms
+    // z_s = inv(L_ss) v_s.  The row block of sub-step s+1 and its inverse are requested as
+    // soon as the registers of sub-step s are consumed, ahead of the mat-vec and its barriers.
+    constexpr int CG = TB / SB - 1;                     // 7 groups of 4 loads at most
+    const int ns = (jb + SB - 1) / SB;
+    const int row = tid >> 3, j8 = tid & 7;
+    const T *Lblk = L + k0 * ldl + k0;
+    const T *Li0 = Linv + (k0 >> 6) * (int64_t)(SB * SB);
+    for (int i = tid; i < TB; i += TBT) sv[i] = (i < jb) ? b[k0 + i] : (T)0;
+    T li[8], ln[8];
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) li[cc] = Li0[(wave * 8 + cc) * SB + lane];
+    T l0[CG][4], l1[CG][4];
+    __syncthreads();
+    for (int s = 0; s < ns; ++s) {
+        if (s > 0 && !(ablate & 2)) {
+            T acc = (T)0;
+#pragma unroll
+            for (int t = 0; t < CG; ++t) {
+                if (t < s) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const int c = t * SB + m * 16 + 2 * j8;
+                        acc = fma(l0[t][m], szb[c], acc);
+                        acc = fma(l1[t][m], szb[c + 1], acc);
+                    }
+                }
+            }
+            acc = lanes8_sum(acc);
+            if (j8 == 0 && s * SB + row < jb) sv[s * SB + row] -= acc;
+        }
+        if (s + 1 < ns) {
+            const T *Li = Li0 + (s + 1) * (int64_t)(SB * SB);
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc) ln[cc] = Li[(wave * 8 + cc) * SB + lane];
+            if (!(ablate & 2)) {
+                const T *rp = Lblk + (int64_t)min((s + 1) * SB + row, jb - 1) * ldl + 2 * j8;
+#pragma unroll
+                for (int t = 0; t < CG; ++t) {
+                    if (t <= s) {
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) load2(rp + t * SB + m * 16, aligned, l0[t][m], l1[t][m]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        inv_matvec(li, sv + s * SB, red, szb + s * SB, x + k0 + s * SB, jb - s * SB, tid, lane, wave);
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) li[cc] = ln[cc];
+    }
+}
+
+// backward (L^T a = v).  x[q0:q0+qjb] (block q, below the block being solved) is final.
+// Workgroup 0 solves block [k0, k0+jb) from b (nothing when jb == 0); workgroups
+// w >= 1 apply block q to CW columns each of [c0, c1):  b[c] -= L[q0:q0+qjb, c] . x[q0:q0+qjb].
+// CW = 128 for the streaming far part (1 KiB per row and wave), 32 for the 512 x 512 tile
+// next to the diagonal (16 workgroups instead of 4).
+template <typename T, int CW>
+__global__ __launch_bounds__(TBT) void trsv_bwd_fused(const T *__restrict__ L, int64_t ldl,
+                                                      const T *__restrict__ Linv, T *__restrict__ b,
+                                                      T *__restrict__ x, int64_t k0, int jb, int64_t q0,
+                                                      int qjb, int64_t c0, int64_t c1, int aligned_i, int ablate)
+{
+    __shared__ T sa[TB];            // far workgroups: solution of block q
+    __shared__ T sv[TB];
+    __shared__ T sz[SB];
+    __shared__ T red[2 * TB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool aligned = aligned_i != 0;
+
+    if (blockIdx.x != 0) {
+        if (qjb <= 0 || (ablate & 4)) return;
+        constexpr int LP = CW / 2;                  // lanes (column pairs) per row
+        constexpr int NG = TBT / LP;                // row groups
+        constexpr int PER = TB / NG;                // rows per thread
+        constexpr int BU = PER < 32 ? PER : 32;     // loads in flight per thread and batch
+        for (int i = tid; i < TB; i += TBT) sa[i] = (i < qjb) ? x[q0 + i] : (T)0;
+        __syncthreads();
+        const int64_t cbeg = c0 + (int64_t)(blockIdx.x - 1) * CW, cend = min(c1, cbeg + CW);
+        const int lp = tid % LP, g = tid / LP;
+        const int64_t c = min(cbeg + 2 * lp, cend - 1);
+        const bool pair = c + 1 < cend;
+        const T *col = L + q0 * ldl + c;
+        T a0 = (T)0, a1 = (T)0;
+#pragma unroll 1
+        for (int u0 = 0; u0 < PER; u0 += BU) {
+            T l0[BU], l1[BU];
+#pragma unroll
+            for (int u = 0; u < BU; ++u) {
+                const int i = min(g + (u0 + u) * NG, qjb - 1);
+                if (pair) load2(col + (int64_t)i * ldl, aligned, l0[u], l1[u]);
+                else { l0[u] = col[(int64_t)i * ldl]; l1[u] = (T)0; }
+            }
+#pragma unroll
+            for (int u = 0; u < BU; ++u) {
+                const int i = g + (u0 + u) * NG;
+                const T av = (i < qjb) ? sa[i] : (T)0;
+                a0 = fma(l0[u], av, a0);
+                a1 = fma(l1[u], av, a1);
+            }
+        }
+        red[g * CW + 2 * lp] = a0;
+        red[g * CW + 2 * lp + 1] = a1;
+        __syncthreads();
+        if (tid < CW && cbeg + tid < cend) {
+            T sum = red[tid];
+            for (int q = 1; q < NG; ++q) sum += red[q * CW + tid];
+            b[cbeg + tid] -= sum;
+        }
+        return;
+    }
+    if (jb == 0) return;
+
+    // in-block chain, last sub-block first, right-looking: after a_s = inv(L_ss)^T v_s the
+    // rows of sub-block s update every column to their left (thread = column pair, two
+    // groups of 32 rows: whole rows are read contiguously).  The tile of a sub-step is
+    // requested before the mat-vec that produces its multipliers.
+    const int ns = (jb + SB - 1) / SB;
+    const int cpair = tid & 255, g = tid >> 8;
+    const T *Li0 = Linv + (k0 >> 6) * (int64_t)(SB * SB);
+    for (int i = tid; i < TB; i += TBT) sv[i] = (i < jb) ? b[k0 + i] : (T)0;
+    T li[8];
+    __syncthreads();
+    for (int s = ns - 1; s >= 0; --s) {
+        const T *Li = Li0 + s * (int64_t)(SB * SB);
+        const int ncol = s * SB;
+        const int ilim = min(SB, jb - s * SB);
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) li[cc] = Li[(wave * 8 + cc) * SB + lane];
+        T l0[32], l1[32];
+        const bool act = 2 * cpair < ncol && !(ablate & 2);     // ncol is a multiple of 64: always a pair
+        if (act) {
+            const T *col = L + (k0 + s * SB) * ldl + k0 + 2 * cpair;
+#pragma unroll
+            for (int u = 0; u < 32; ++u) {
+                const int i = min(g * 32 + u, ilim - 1);
+                load2(col + (int64_t)i * ldl, aligned, l0[u], l1[u]);
+            }
+        }
+        inv_matvec(li, sv + s * SB, red, sz, x + k0 + s * SB, jb - s * SB, tid, lane, wave);
+        if (ncol > 0) {
+            T a0 = (T)0, a1 = (T)0;
+            if (act) {
+#pragma unroll
+                for (int u = 0; u < 32; ++u) {
+                    const int i = g * 32 + u;
+                    const T av = (i < ilim) ? sz[i] : (T)0;     // rows >= ilim: identity padding, unused
+                    a0 = fma(l0[u], av, a0);
+                    a1 = fma(l1[u], av, a1);
+                }
+            }
+            red[g * TB + 2 * cpair] = a0;
+            red[g * TB + 2 * cpair + 1] = a1;
+            __syncthreads();
+            if (tid < ncol) sv[tid] -= red[tid] + red[TB + tid];
+            __syncthreads();
+        }
     }
 }
 
@@ -152,20 +414,39 @@ static int trsv_t(const T *L, int64_t n, int64_t ldl, T *b, T *x, int transpose,
     void *scr = nullptr;
     GPX_TRY(scratch((size_t)nblk * SB * SB * sizeof(T), &scr));
     T *Linv = (T *)scr;
-    hipLaunchKernelGGL((trinv64_kernel<T>), dim3((unsigned)nblk), dim3(64), 0, st, L, ldl, ncols, Linv);
+    const int aligned = (((uintptr_t)L) % (2 * sizeof(T)) == 0) && (ldl % 2 == 0);
+    static const int ablate = getenv("GPX_TRSV_ABLATE") ? atoi(getenv("GPX_TRSV_ABLATE")) : 0;   // timing diagnostics only
+    const int64_t nb = cdiv(ncols, TB);
+    auto width = [&](int64_t blk) { return (int)std::min<int64_t>(TB, ncols - blk * TB); };
+    // Per block two launches: (N) the 512 x 512 tile that carries the previous block's
+    // solution into this block's rows/columns, spread over 8-16 workgroups; (F) workgroup 0
+    // solves the block while the other workgroups stream the previous block's far panel.
     if (!transpose) {
-        for (int64_t k0 = 0; k0 < ncols; k0 += SB) {
-            const int jb = (int)std::min<int64_t>(SB, ncols - k0);
-            const int64_t below = n - k0 - jb;
-            dim3 grid((unsigned)std::max<int64_t>(1, cdiv(below, SB))), block(256);
-            hipLaunchKernelGGL((trsv_fwd_step<T>), grid, block, 0, st, L, ldl, Linv, b, x, k0, jb, n);
+        hipLaunchKernelGGL((trinv64_kernel<T, true>), dim3((unsigned)nblk), dim3(64), 0, st, L, ldl, ncols, Linv);
+        for (int64_t blk = 0; blk < nb; ++blk) {
+            const int64_t k0 = blk * TB, p0 = std::max<int64_t>(blk - 1, 0) * TB;
+            const int jb = width(blk), pjb = blk > 0 ? TB : 0;
+            if (blk > 0)
+                hipLaunchKernelGGL((trsv_fwd_fused<T>), dim3((unsigned)(1 + cdiv(jb, 64))), dim3(TBT), 0, st, L, ldl,
+                                   Linv, b, x, k0 + jb, k0, 0, p0, pjb, k0, aligned, ablate);
+            const int64_t far = blk > 0 ? n - (k0 + jb) : 0;
+            hipLaunchKernelGGL((trsv_fwd_fused<T>), dim3((unsigned)(1 + cdiv(far, 64))), dim3(TBT), 0, st, L, ldl,
+                               Linv, b, x, n, k0, jb, p0, pjb, k0 + jb, aligned, ablate);
         }
+        if (n > ncols)          // trapezoid: the last block's panel below the triangle
+            hipLaunchKernelGGL((trsv_fwd_fused<T>), dim3((unsigned)(1 + cdiv(n - ncols, 64))), dim3(TBT), 0, st, L,
+                               ldl, Linv, b, x, n, ncols, 0, (nb - 1) * TB, width(nb - 1), ncols, aligned, ablate);
     } else {
-        for (int64_t kb = nblk - 1; kb >= 0; --kb) {
-            const int64_t k0 = kb * SB;
-            const int jb = (int)std::min<int64_t>(SB, n - k0);
-            dim3 grid((unsigned)std::max<int64_t>(1, cdiv(k0, 256))), block(256);
-            hipLaunchKernelGGL((trsv_bwd_step<T>), grid, block, 0, st, L, ldl, Linv, b, x, k0, jb);
+        hipLaunchKernelGGL((trinv64_kernel<T, false>), dim3((unsigned)nblk), dim3(64), 0, st, L, ldl, ncols, Linv);
+        for (int64_t blk = nb - 1; blk >= 0; --blk) {
+            const int64_t k0 = blk * TB, q0 = k0 + TB;
+            const int jb = width(blk), qjb = blk + 1 < nb ? width(blk + 1) : 0;
+            if (qjb > 0)
+                hipLaunchKernelGGL((trsv_bwd_fused<T, 32>), dim3((unsigned)(1 + cdiv(jb, 32))), dim3(TBT), 0, st, L,
+                                   ldl, Linv, b, x, k0, 0, q0, qjb, k0, k0 + jb, aligned, ablate);
+            hipLaunchKernelGGL((trsv_bwd_fused<T, 128>), dim3((unsigned)(1 + (qjb > 0 ? cdiv(k0, 128) : 0))),
+                               dim3(TBT), 0, st, L, ldl, Linv, b, x, k0, jb, q0, qjb, (int64_t)0, k0, aligned,
+                               ablate);
         }
     }
     GPX_LAUNCH_CHECK();

@@ -17,14 +17,23 @@ for rep in range(2):
     _lib.check(lib.gpx_d_gemm_nt(_lib.F64, M, M, K, -1.0, A.ptr, K, A.ptr, K, C.ptr, M, 1, 0, 0, None))
 sync()
 S.zero()
+from gaussian_processes_amd.device import Event
+REPS = int(sys.argv[3]) if len(sys.argv) > 3 else 1      # sustained load before the stamped launch
+for rep in range(REPS - 1):
+    _lib.check(lib.gpx_d_gemm_nt(_lib.F64, M, M, K, -1.0, A.ptr, K, A.ptr, K, C.ptr, M, 1, 0, 0, None))
 lib.gpx_debug_gemm_stamps(S.ptr)
+e0, e1 = Event(), Event()
+e0.record(None)
 _lib.check(lib.gpx_d_gemm_nt(_lib.F64, M, M, K, -1.0, A.ptr, K, A.ptr, K, C.ptr, M, 1, 0, 0, None))
+e1.record(None)
 sync()
+wall_ms = e0.elapsed_ms(e1)
 lib.gpx_debug_gemm_stamps(None)
 st = S.to_host().reshape(-1, 4).astype(np.int64)
 st = st[st[:, 3] > 0]
 pro, loop, epi = st[:, 1] - st[:, 0], st[:, 2] - st[:, 1], st[:, 3] - st[:, 2]
 print("tiles", len(st), "span cycles", st[:, 3].max() - st[:, 0].min())
+print("wall %.3f ms -> shader clock %.0f MHz (span cycles / event time), %.2f TF/s" % (wall_ms, (st[:, 3].max() - st[:, 0].min()) / wall_ms / 1e3, M * (M + 256.0) * K / wall_ms / 1e9))
 for nm, v in (("prologue", pro), ("k-loop", loop), ("epilogue", epi), ("total", st[:, 3] - st[:, 0])):
     print("%-9s mean %9.0f  p10 %9.0f  p50 %9.0f  p90 %9.0f  max %9.0f" % (nm, v.mean(), np.percentile(v, 10), np.percentile(v, 50), np.percentile(v, 90), v.max()))
 nk = K // 16

@@ -2,6 +2,7 @@
 // (diagnostic only; not part of libgpx).  hipcc -O3 --offload-arch=gfx950 tools/mfma_peak.hip -o /tmp/mfma_peak
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
@@ -41,9 +42,10 @@ __global__ __launch_bounds__(512, 2) void k32(float *out, int iters, float seed)
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
-int main()
+int main(int argc, char **argv)
 {
-    const int blocks = 256, threads = 512, iters = 4000, NACC = 16;
+    const int blocks = 256, threads = 512, NACC = 16;
+    const int iters = argc > 1 ? atoi(argv[1]) : 4000;      // 4000 ~ 1.7 ms; 1000000 ~ 0.43 s sustained
     double *d; hipMalloc(&d, ((size_t)blocks * 4 * threads + 16) * sizeof(double));   // sized for the largest launch below
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 3; ++rep) {
