@@ -376,15 +376,23 @@ int launch_gemm_nt(int64_t M, int64_t N, int64_t K, const void *A, int64_t lda, 
 // ===========================================================================
 // BN = 128: the square-ish work-horse.  BN = 64: the same pipeline on 256 x 64 tiles
 // for the skinny (N <= 64) products of the panel factorisation.
-constexpr int F_BM = 256;
-constexpr int F_NST = 3;
-template <int BN> struct FGeo {
-    static constexpr int ROWS = F_BM + BN;          // tile rows per stage: 384 / 320
-    static constexpr int STAGE = ROWS * G_ROWB;     // 49,152 / 40,960 B
-    static constexpr int SMEM = F_NST * STAGE;      // 147,456 / 122,880 B
-    static constexpr int PW = ROWS / 64;            // DMA pieces (1 KiB) per wave and stage: 6 / 5
+// BM = 256 (8 waves, 3 stages, one workgroup per CU) or BM = 128 (4 waves, 2 stages of
+// 32 KiB, TWO workgroups per CU: one's prologue / epilogue / barrier stalls fall under the
+// other's k-loop).
+template <int BN, int BM = 256> struct FGeo {
+    static constexpr int NW = BM / 32;              // waves: (BM / 64) x 2
+    static constexpr int NST = BM == 256 ? 3 : 2;   // LDS stages
+    static constexpr int ROWS = BM + BN;            // tile rows per stage: 384 / 320 / 256
+    static constexpr int STAGE = ROWS * G_ROWB;     // 49,152 / 40,960 / 32,768 B
+    static constexpr int SMEM = NST * STAGE;        // 147,456 / 122,880 / 65,536 B
+    static constexpr int PW = ROWS / (8 * NW);      // DMA pieces (1 KiB) per wave and stage: 6 / 5 / 8
     static constexpr int NTW = BN / 32;             // 16-column MFMA tiles per wave: 4 / 2
+    static constexpr int TPP = (1024 / BM) * 8;     // tiles per 1024 x 1024 patch: 32 / 64
 };
+template <int N> struct WaitVm;
+#define GPX_WAITVM(N) template <> struct WaitVm<N> { static __device__ __forceinline__ void go() { asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); } }
+GPX_WAITVM(0); GPX_WAITVM(5); GPX_WAITVM(6); GPX_WAITVM(8); GPX_WAITVM(10); GPX_WAITVM(12);
+#undef GPX_WAITVM
 
 // chunk swizzle of tile row r: a permutation of (r >> 1) & 7 chosen so that every
 // 16-lane group of a ds_read_b128 fragment read hits 16 distinct 16-B slots
@@ -402,13 +410,15 @@ __device__ __forceinline__ int f_swz(int r) { return (0x64753120u >> (4 * ((r >>
 struct GemmMap {
     int64_t boff, cbase, nb, pm1nb, brows;
     int np, a, b, R;
+    int csh;      // log2 of the tile columns per patch (3: 8 x BN = 1024 columns; fewer for narrow products,
+                  // so that no workgroup is launched only to find its tile outside the matrix)
     // start-up stagger: the first `stag_blocks` workgroups delay their start by
     // blockIdx * stag_cycles / stag_blocks shader cycles, so that the C read-modify-write
     // epilogues of the 256 CUs (which otherwise all fall together, stalling the chip on
     // one HBM burst per round of tiles) spread evenly over a tile time.
     int stag_blocks, stag_cycles;
     // diagnostic: when non-null, wave 0 of every workgroup stores 4 s_memtime stamps
-    // (start, first barrier passed, k-loop done, epilogue done) at stamps[4 * blockIdx]
+    // (start, first barrier passed, k-loop done, epilogue done) and 2 s_memrealtime stamps at stamps[6 * blockIdx]
     unsigned long long *stamps;
     int ablate;   // diagnostic (GPX_GEMM_ABLATE): 1 no barrier/vmcnt, 2 no DMA in loop, 4 no LDS reads in loop
     int vec_c;    // C allows 2-element vector accesses (ldc even, aligned base, N even)
@@ -423,8 +433,8 @@ typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
 // TAG only changes the symbol name: 1 = the block-cyclic trailing update of the
 // factorisation (gpx_d_syrk_bc), so that profilers list the dominant kernel separately
 // from the panel / covariance products that share its code.
-template <typename T, int BN, int TAG>
-__global__ __launch_bounds__(512, 2) void gemm_nt_fast_kernel(int64_t M, int64_t N, int64_t K,
+template <typename T, int BN, int TAG, int BM = 256>
+__global__ __launch_bounds__(BM * 2, 2) void gemm_nt_fast_kernel(int64_t M, int64_t N, int64_t K,
                                                               const T *__restrict__ A, int64_t lda,
                                                               const T *__restrict__ B, int64_t ldb,
                                                               T *__restrict__ C, int64_t ldc, T alpha,
@@ -434,12 +444,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_fast_kernel(int64_t M, int64_t
     typedef typename MF<T>::acc_t acc_t;
     constexpr int EPK = MF<T>::EPK;
     constexpr int SUB = EPK / 4;
-    constexpr int F_STAGE = FGeo<BN>::STAGE, PW = FGeo<BN>::PW, NTW = FGeo<BN>::NTW;
+    typedef FGeo<BN, BM> Geo;
+    constexpr int F_STAGE = Geo::STAGE, PW = Geo::PW, NTW = Geo::NTW, F_NST = Geo::NST;
+    constexpr int F_BM = BM;
 
     // ---- block -> tile (XCD-aware patch order) ----
     const int bid = blockIdx.x;
     const int xcd = bid & 7, loc = bid >> 3;
-    const int patch = (loc >> 5) * 8 + xcd, within = loc & 31;
+    constexpr int RSH = BM == 256 ? 2 : 3;                          // log2 of the tile rows per patch
+    const int tsh = RSH + fm.csh;
+    const int patch = (loc >> tsh) * 8 + xcd, within = loc & ((1 << tsh) - 1);
     if (patch >= fm.np) return;
     int pb_r, pb_c;
     if (fm.a == 0) {
@@ -455,8 +469,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_fast_kernel(int64_t M, int64_t
         while (pc > 0 && cum(pc) > patch) --pc;
         pb_c = pc; pb_r = fm.b + fm.a * pc + (patch - cum(pc));
     }
-    const int64_t bm0 = ((int64_t)pb_r * 4 + (within >> 3)) * F_BM;
-    const int64_t bn0 = ((int64_t)pb_c * 8 + (within & 7)) * BN;
+    const int64_t bm0 = ((int64_t)pb_r * (1024 / BM) + (within >> fm.csh)) * F_BM;
+    const int64_t bn0 = (((int64_t)pb_c << fm.csh) + (within & ((1 << fm.csh) - 1))) * BN;
     if (bm0 >= M || bn0 >= N) return;
     const int64_t cshift = ((fm.cbase + bn0) / fm.nb) * fm.pm1nb;   // same for the tile's 128 columns
     col0 += cshift;
@@ -469,8 +483,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_fast_kernel(int64_t M, int64_t
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: keep it scalar
     const int wr = wave >> 1, wc = wave & 1;
 
-    unsigned long long st0 = 0, st1 = 0, st2 = 0;
-    if (fm.stamps) st0 = __builtin_amdgcn_s_memtime();
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, rt0 = 0;
+    if (fm.stamps) { st0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
     if (bid < fm.stag_blocks) {
         const unsigned long long target = (unsigned long long)bid * (unsigned)fm.stag_cycles / (unsigned)fm.stag_blocks;
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();
@@ -509,7 +523,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_fast_kernel(int64_t M, int64_t
     {
         unsigned char *dst0 = smem + (wave * PW) * 1024;
 #pragma unroll
-        for (int st3 = 0; st3 < 3; ++st3) {
+        for (int st3 = 0; st3 < F_NST; ++st3) {
             const int inc = (st3 + 1 < nk) ? G_ROWB : 0;
 #pragma unroll
             for (int j = 0; j < PW; ++j) {
@@ -565,8 +579,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_fast_kernel(int64_t M, int64_t
     } while (0)
 
     // stage 0 landed (this wave's pieces), then everybody's
-    if (PW == 6) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else         asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    WaitVm<(F_NST - 1) * PW>::go();
     __builtin_amdgcn_s_barrier();
     if (fm.stamps) st1 = __builtin_amdgcn_s_memtime();
     {
@@ -581,7 +594,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_fast_kernel(int64_t M, int64_t
         int nstage = stage + 1; if (nstage >= F_NST) nstage = 0;
         const unsigned sn = (unsigned)(nstage * F_STAGE);
         const unsigned aa0 = a_base + sn + rd0, ab0 = b_base + sn + rd0;
-        const int inc = (kt + 4 < nk) ? G_ROWB : 0;       // slice kt+3 is fetched now; is there a kt+4?
+        const int inc = (kt + F_NST + 1 < nk) ? G_ROWB : 0;   // slice kt+NST is fetched now; is there one more?
 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // R0 of this stage is in
         __builtin_amdgcn_sched_barrier(0);
@@ -602,8 +615,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_fast_kernel(int64_t M, int64_t
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // R1 in: this wave is done reading the stage
         if (!(fm.ablate & 1)) {
-            if (PW == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else         asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            WaitVm<(F_NST - 2) * PW>::go();          // slice kt+1 landed (this wave's pieces), then everybody's
             __builtin_amdgcn_s_barrier();
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -642,22 +654,23 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_fast_kernel(int64_t M, int64_t
     if (fm.stamps && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned long long st3 = __builtin_amdgcn_s_memtime();
-        unsigned long long *o = fm.stamps + 4 * (size_t)bid;
+        unsigned long long *o = fm.stamps + 6 * (size_t)bid;
         o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3;
+        o[4] = rt0; o[5] = __builtin_amdgcn_s_memrealtime();      // 100 MHz reference: shader clock = d(memtime) / d(realtime)
     }
 }
 #undef GPX_DSR
 
-template <typename T, int BN = 128, int TAG = 0>
+template <typename T, int BN = 128, int TAG = 0, int BM = 256>
 static int launch_gemm_nt_fast(int64_t M, int64_t N, int64_t K, const void *A, int64_t lda,
                                const void *B, int64_t ldb, void *C, int64_t ldc, double alpha, int tri,
                                int64_t row0, int64_t col0, hipStream_t st, const GemmMap *map = nullptr,
                                double work = -1.0, int beta0 = 0)
 {
-    constexpr int F_SMEM = FGeo<BN>::SMEM;
+    constexpr int F_SMEM = FGeo<BN, BM>::SMEM;
     static bool attr_done = false;
     if (!attr_done) {
-        GPX_HIP(hipFuncSetAttribute((const void *)gemm_nt_fast_kernel<T, BN, TAG>,
+        GPX_HIP(hipFuncSetAttribute((const void *)gemm_nt_fast_kernel<T, BN, TAG, BM>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, F_SMEM));
         attr_done = true;
     }
@@ -666,9 +679,10 @@ static int launch_gemm_nt_fast(int64_t M, int64_t N, int64_t K, const void *A, i
         fm = *map;
     } else {
         fm.boff = 0; fm.cbase = 0; fm.nb = (int64_t)1 << 40; fm.pm1nb = 0; fm.brows = N;
-        const int64_t pbr = cdiv(M, 1024), pbc = cdiv(N, 8 * BN);
-        fm.a = 0; fm.b = 0;
+        fm.a = 0; fm.b = 0; fm.csh = 3;
         if (BN == 128 && tri == GPX_LOWER && col0 >= row0) { fm.a = 1; fm.b = (int)((col0 - row0) / 1024); }
+        else while (fm.csh > 0 && ((int64_t)BN << (fm.csh - 1)) >= N) --fm.csh;     // narrow product: narrow patches
+        const int64_t pbr = cdiv(M, 1024), pbc = cdiv(N, (int64_t)BN << fm.csh);
         fm.R = (int)pbr - fm.b;
         if (fm.R <= 0) return GPX_OK;                       // nothing at or below the diagonal
         int64_t np = 0;
@@ -702,13 +716,22 @@ static int launch_gemm_nt_fast(int64_t M, int64_t N, int64_t K, const void *A, i
             fm.stag_cycles = (int)std::min<int64_t>(tile_cycles * pct / 100, 4000000);
         }
     }
-    const int64_t blocks = cdiv(np, 8) * 8 * 32;
+    const int64_t blocks = (cdiv(np, 8) * 8 * (1024 / BM)) << fm.csh;
     ProfScope prof(TAG == 1 ? PC_GEMM : (BN == 128 ? PC_GEMM_PANEL : PC_GEMM_SKINNY),
                    work >= 0 ? work : 2.0 * (double)K * updated_elements(M, N, tri, row0, col0), st);
-    hipLaunchKernelGGL((gemm_nt_fast_kernel<T, BN, TAG>), dim3((unsigned)blocks), dim3(512), F_SMEM, st, M, N, K,
+    hipLaunchKernelGGL((gemm_nt_fast_kernel<T, BN, TAG, BM>), dim3((unsigned)blocks), dim3(BM * 2), F_SMEM, st, M, N, K,
                        (const T *)A, lda, (const T *)B, ldb, (T *)C, ldc, (T)alpha, tri, row0, col0, fm, beta0);
     GPX_LAUNCH_CHECK();
     return GPX_OK;
+}
+
+// block-tile height of the fast kernel (GPX_GEMM_BM = 128 | 256).  Default 128: two 4-wave
+// workgroups per CU -- measured at n = 65536 f64: trailing update 64.9 -> 66.4 TF/s in situ, fit
+// 1.466 -> 1.435 s; n = 32768 f32: 131 -> 128.5 ms; n = 8192: 19.2 -> 18.1 ms.
+static int fast_bm()
+{
+    static const int bm = getenv("GPX_GEMM_BM") ? atoi(getenv("GPX_GEMM_BM")) : 128;
+    return bm == 256 ? 256 : 128;
 }
 
 int gemm_nt(int dtype, int64_t M, int64_t N, int64_t K, const void *A, int64_t lda, const void *B,
@@ -721,12 +744,26 @@ int gemm_nt(int dtype, int64_t M, int64_t N, int64_t K, const void *A, int64_t l
     const bool fast = !no_fast && K % epk == 0 && lda % ch == 0 && ldb % ch == 0 &&
                       ((uintptr_t)A) % 16 == 0 && ((uintptr_t)B) % 16 == 0;
     if (fast) {
+        if (N <= 64 && fast_bm() == 128) {
+            if (dtype == GPX_F64)
+                return launch_gemm_nt_fast<double, 64, 0, 128>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0, col0,
+                                                               st, nullptr, -1.0, beta0);
+            return launch_gemm_nt_fast<float, 64, 0, 128>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0, col0, st,
+                                                          nullptr, -1.0, beta0);
+        }
         if (N <= 64) {
             if (dtype == GPX_F64)
                 return launch_gemm_nt_fast<double, 64>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0, col0,
                                                        st, nullptr, -1.0, beta0);
             return launch_gemm_nt_fast<float, 64>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0, col0, st,
                                                   nullptr, -1.0, beta0);
+        }
+        if (fast_bm() == 128) {
+            if (dtype == GPX_F64)
+                return launch_gemm_nt_fast<double, 128, 0, 128>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0,
+                                                                col0, st, nullptr, -1.0, beta0);
+            return launch_gemm_nt_fast<float, 128, 0, 128>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0, col0,
+                                                           st, nullptr, -1.0, beta0);
         }
         if (dtype == GPX_F64)
             return launch_gemm_nt_fast<double>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0, col0, st,
@@ -780,7 +817,7 @@ int syrk_bc(int dtype, int64_t n, int64_t row_begin, void *Cloc, int64_t ldc, in
         fm.brows = n - k0;
         const int64_t G0 = gcol(cl0);
         const int64_t pbr = cdiv(M, 1024), pbc = cdiv(Ncols, 1024);
-        fm.a = P;
+        fm.a = P; fm.csh = 3;
         fm.b = (int)std::max<int64_t>(0, (G0 - row_begin) / 1024);
         fm.R = (int)pbr - fm.b;
         if (fm.R <= 0) return GPX_OK;
@@ -792,6 +829,13 @@ int syrk_bc(int dtype, int64_t n, int64_t row_begin, void *Cloc, int64_t ldc, in
         }
         fm.np = (int)np;
         fm.stag_blocks = 0; fm.stag_cycles = 0; fm.stamps = nullptr; fm.ablate = 0;
+        if (fast_bm() == 128) {
+            if (dtype == GPX_F64)
+                return launch_gemm_nt_fast<double, 128, 1, 128>(M, Ncols, kb, A, ldp, Pb, ldp, C, ldc, -1.0, GPX_LOWER,
+                                                                row_begin, cl0 + (int64_t)rank * nb, st, &fm, work);
+            return launch_gemm_nt_fast<float, 128, 1, 128>(M, Ncols, kb, A, ldp, Pb, ldp, C, ldc, -1.0, GPX_LOWER,
+                                                           row_begin, cl0 + (int64_t)rank * nb, st, &fm, work);
+        }
         if (dtype == GPX_F64)
             return launch_gemm_nt_fast<double, 128, 1>(M, Ncols, kb, A, ldp, Pb, ldp, C, ldc, -1.0, GPX_LOWER,
                                                        row_begin, cl0 + (int64_t)rank * nb, st, &fm, work);

@@ -125,9 +125,11 @@ __global__ __launch_bounds__(256) void kmat_kernel(const T *__restrict__ x1, int
 {
     constexpr int VEC = Vec<T>::N;
     constexpr int TN = 64 * VEC;
+    constexpr int TNP = TN + VEC;                     // padded row of s2: the transposing stores below
+                                                      // (consecutive threads -> consecutive k) spread over the banks
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *s1 = reinterpret_cast<T *>(smem_raw);          // [KM_ROWS][d]
-    T *s2 = s1 + (size_t)KM_ROWS * d;                 // [d][TN]   (transposed: lanes contiguous)
+    T *s2 = s1 + (size_t)KM_ROWS * d;                 // [d][TNP]  (transposed: lanes contiguous)
 
     const int64_t row0 = (int64_t)blockIdx.y * KM_ROWS;
     const int64_t col0 = (int64_t)blockIdx.x * TN;
@@ -135,13 +137,20 @@ __global__ __launch_bounds__(256) void kmat_kernel(const T *__restrict__ x1, int
 
     const int tid = threadIdx.x;
     // stage the two point sets (coalesced: consecutive threads -> consecutive elements)
-    for (int idx = tid; idx < KM_ROWS * d; idx += 256) {
-        const int r = idx / d;
-        s1[idx] = (row0 + r < n) ? x1[(row0 + r) * d + (idx - r * d)] : (T)0;
-    }
-    for (int idx = tid; idx < TN * d; idx += 256) {
-        const int c = idx / d, k = idx - c * d;
-        s2[(size_t)k * TN + c] = (col0 + c < m) ? x2[(col0 + c) * d + k] : (T)0;
+    // (the tile's points are contiguous in memory: element idx of the tile is x[row0 * d + idx])
+    {
+        const int64_t lim1 = (n - row0) * d;
+        const T *g1 = x1 + row0 * d;
+        for (int idx = tid; idx < KM_ROWS * d; idx += 256) s1[idx] = (idx < lim1) ? g1[idx] : (T)0;
+        const int64_t lim2 = (m - col0) * d;
+        const T *g2 = x2 + col0 * d;
+        const int qd = 256 / d, rd = 256 - qd * d;    // idx += 256  <=>  (c, k) += (qd, rd) with carry
+        int c = tid / d, k = tid - c * d;
+        for (int idx = tid; idx < TN * d; idx += 256) {
+            s2[(size_t)k * TNP + c] = (idx < lim2) ? g2[idx] : (T)0;
+            c += qd; k += rd;
+            if (k >= d) { k -= d; ++c; }
+        }
     }
     __syncthreads();
 
@@ -169,7 +178,7 @@ __global__ __launch_bounds__(256) void kmat_kernel(const T *__restrict__ x1, int
             for (int k = 0; k < d; ++k) {
                 T b[VEC];
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) b[v] = s2[(size_t)k * TN + cbase + v];
+                for (int v = 0; v < VEC; ++v) b[v] = s2[(size_t)k * TNP + cbase + v];
 #pragma unroll
                 for (int r = 0; r < KM_RB; ++r) {
                     const T a = s1[(rloc + r) * d + k];
@@ -233,7 +242,7 @@ static int launch_kmat(const void *x1, int64_t n, const void *x2, int64_t m, int
         set_error("periodic derivative members need d == 1 (got %d)", d);
         return GPX_ERR_UNSUPPORTED;
     }
-    const size_t smem = ((size_t)KM_ROWS * d + (size_t)d * TN) * sizeof(T);
+    const size_t smem = ((size_t)KM_ROWS * d + (size_t)d * (TN + VEC)) * sizeof(T);
     if (smem > 96 * 1024) {
         set_error("kmat: d = %d too large for the LDS-staged tile (max 64 for f64)", d);
         return GPX_ERR_UNSUPPORTED;
@@ -277,49 +286,63 @@ static int launch_kmat(const void *x1, int64_t n, const void *x2, int64_t m, int
 
 // ---------------------------------------------------------------------------
 // fused posterior mean: out[i] = sum_j K(xo[i], x[j]) * alpha[j]   (gp/gp.py:597)
-// One workgroup owns MP test points; the training set streams through LDS in
-// chunks of 256 points; sums are kept in f64 and reduced in a fixed order
-// (deterministic: no atomics).
+// Workgroup (bx, by) owns MP test points and the by-th slice of the training set,
+// which streams through LDS in chunks of 256 points (one per thread, transposed and
+// padded so both the staging stores and the reads are conflict-free).  Sums are
+// kept in f64; a slice's partial sums go to `partial[by][i]` and a second launch
+// adds the slices in a fixed order (deterministic: no atomics).
 // ---------------------------------------------------------------------------
-constexpr int MP = 4;
+constexpr int MP = 8;
+constexpr int MCP = 257;           // padded chunk row
 
 template <typename T, int KIND>
 __global__ __launch_bounds__(256) void mean_kernel(const T *__restrict__ xo, int64_t m,
                                                    const T *__restrict__ x, int64_t n, int d,
                                                    KParams kp, const T *__restrict__ alpha,
+                                                   int64_t slice_len, double *__restrict__ partial,
                                                    T *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T *sx = reinterpret_cast<T *>(smem_raw);            // [d][256] chunk of x, transposed
-    T *so = sx + (size_t)d * 256;                       // [MP][d] test points
+    T *sx = reinterpret_cast<T *>(smem_raw);            // [d][MCP] chunk of x, transposed
+    T *so = sx + (size_t)d * MCP;                       // [MP][d] test points
     __shared__ double red[4][MP];
 
     const int tid = threadIdx.x;
     const int64_t p0 = (int64_t)blockIdx.x * MP;
-    for (int idx = tid; idx < MP * d; idx += 256) {
-        const int pp = idx / d;
-        so[idx] = (p0 + pp < m) ? xo[(p0 + pp) * d + (idx - pp * d)] : (T)0;
+    {
+        const int64_t lim = (m - p0) * d;
+        const T *g = xo + p0 * d;
+        for (int idx = tid; idx < MP * d; idx += 256) so[idx] = (idx < lim) ? g[idx] : (T)0;
     }
     double acc[MP];
 #pragma unroll
     for (int pp = 0; pp < MP; ++pp) acc[pp] = 0.0;
 
     const T c1 = (T)kp.c[0], c2 = (T)kp.c[1];
-    for (int64_t j0 = 0; j0 < n; j0 += 256) {
+    const int qd = 256 / d, rd = 256 - qd * d;          // idx += 256  <=>  (c, k) += (qd, rd) with carry
+    const int cst = tid / d, kst = tid - cst * d;
+    const int64_t jbeg = (int64_t)blockIdx.y * slice_len, jend = min(n, jbeg + slice_len);
+    for (int64_t j0 = jbeg; j0 < jend; j0 += 256) {
         __syncthreads();
-        for (int idx = tid; idx < 256 * d; idx += 256) {
-            const int c = idx / d, k = idx - c * d;
-            sx[(size_t)k * 256 + c] = (j0 + c < n) ? x[(j0 + c) * d + k] : (T)0;
+        {
+            const int64_t lim = (jend - j0) * d;
+            const T *g = x + j0 * d;
+            int c = cst, k = kst;
+            for (int idx = tid; idx < 256 * d; idx += 256) {
+                sx[(size_t)k * MCP + c] = (idx < lim) ? g[idx] : (T)0;
+                c += qd; k += rd;
+                if (k >= d) { k -= d; ++c; }
+            }
         }
         __syncthreads();
         const int64_t j = j0 + tid;
-        if (j < n) {
+        if (j < jend) {
             const T aj = alpha[j];
             T r[MP];
 #pragma unroll
             for (int pp = 0; pp < MP; ++pp) r[pp] = (T)0;
             for (int k = 0; k < d; ++k) {
-                const T b = sx[(size_t)k * 256 + tid];
+                const T b = sx[(size_t)k * MCP + tid];
 #pragma unroll
                 for (int pp = 0; pp < MP; ++pp) {
                     if (KIND == GPX_KERNEL_GAUSSIAN) {
@@ -353,34 +376,79 @@ __global__ __launch_bounds__(256) void mean_kernel(const T *__restrict__ xo, int
     }
     __syncthreads();
     if (tid < MP && p0 + tid < m) {
-        out[p0 + tid] = (T)(((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid]);
+        const double sum = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+        if (partial) partial[(int64_t)blockIdx.y * m + p0 + tid] = sum;
+        else out[p0 + tid] = (T)sum;
     }
+}
+
+template <typename T>
+__global__ void mean_reduce_kernel(const double *__restrict__ partial, int nslice, int64_t m, T *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    double sum = 0.0;
+    for (int y = 0; y < nslice; ++y) sum += partial[(int64_t)y * m + i];
+    out[i] = (T)sum;
+}
+
+// grow-only device scratch for the slice partial sums (one per host thread)
+struct MeanScratch { void *p = nullptr; size_t bytes = 0; int device = -1; };
+static thread_local MeanScratch g_mean_scr;
+static int mean_scratch(size_t bytes, void **out)
+{
+    int dev = 0;
+    GPX_HIP(hipGetDevice(&dev));
+    if (g_mean_scr.device != dev || g_mean_scr.bytes < bytes) {
+        if (g_mean_scr.p && g_mean_scr.device == dev) { GPX_HIP(hipDeviceSynchronize()); (void)hipFree(g_mean_scr.p); }
+        g_mean_scr.p = nullptr; g_mean_scr.bytes = 0; g_mean_scr.device = dev;
+        GPX_HIP(hipMalloc(&g_mean_scr.p, bytes));
+        g_mean_scr.bytes = bytes;
+    }
+    *out = g_mean_scr.p;
+    return GPX_OK;
 }
 
 template <typename T>
 static int launch_mean(int kernel, const void *xo, int64_t m, const void *x, int64_t n, int d,
                        const KParams &kp, const void *alpha, void *out, hipStream_t st)
 {
-    const size_t smem = ((size_t)d * 256 + (size_t)MP * d) * sizeof(T);
+    const size_t smem = ((size_t)d * MCP + (size_t)MP * d) * sizeof(T);
     if (smem > 96 * 1024) {
         set_error("mean: d = %d too large", d);
         return GPX_ERR_UNSUPPORTED;
     }
-    dim3 grid((unsigned)cdiv(m, MP)), block(256);
+    // enough workgroups to fill the chip: slices of the training set when m alone is too small
+    const int64_t gx = cdiv(m, MP);
+    int64_t nslice = std::max<int64_t>(1, std::min<int64_t>(cdiv(2048, gx), cdiv(n, 256)));
+    const int64_t slice_len = cdiv(cdiv(n, nslice), 256) * 256;
+    nslice = cdiv(n, slice_len);
+    double *partial = nullptr;
+    if (nslice > 1) {
+        void *scr = nullptr;
+        GPX_TRY(mean_scratch((size_t)nslice * m * sizeof(double), &scr));
+        partial = (double *)scr;
+    }
+    dim3 grid((unsigned)gx, (unsigned)nslice), block(256);
     ProfScope prof(PC_MEAN, (double)m * n, st);
     if (kernel == GPX_KERNEL_GAUSSIAN) {
         if (smem > 48 * 1024)
             GPX_HIP(hipFuncSetAttribute((const void *)mean_kernel<T, GPX_KERNEL_GAUSSIAN>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         hipLaunchKernelGGL((mean_kernel<T, GPX_KERNEL_GAUSSIAN>), grid, block, smem, st,
-                           (const T *)xo, m, (const T *)x, n, d, kp, (const T *)alpha, (T *)out);
+                           (const T *)xo, m, (const T *)x, n, d, kp, (const T *)alpha, slice_len, partial,
+                           (T *)out);
     } else {
         if (smem > 48 * 1024)
             GPX_HIP(hipFuncSetAttribute((const void *)mean_kernel<T, GPX_KERNEL_PERIODIC>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         hipLaunchKernelGGL((mean_kernel<T, GPX_KERNEL_PERIODIC>), grid, block, smem, st,
-                           (const T *)xo, m, (const T *)x, n, d, kp, (const T *)alpha, (T *)out);
+                           (const T *)xo, m, (const T *)x, n, d, kp, (const T *)alpha, slice_len, partial,
+                           (T *)out);
     }
+    if (partial)
+        hipLaunchKernelGGL((mean_reduce_kernel<T>), dim3((unsigned)cdiv(m, 256)), dim3(256), 0, st, partial,
+                           (int)nslice, m, (T *)out);
     GPX_LAUNCH_CHECK();
     return GPX_OK;
 }

@@ -29,6 +29,10 @@ def run(M, N, K, tri, reps=3, dtype=_lib.F64):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "k1024":       # the trailing updates of the n = 65536 factorisation
+        for M in (4096, 8192, 16384, 24576, 32768, 49152, 61440):
+            run(M, M, 1024, 1, reps=2)
+        sys.exit(0)
     for (M, K) in [(4096, 512), (8192, 512), (16384, 512), (32768, 512), (49152, 512)]:
         run(M, M, K, 1)
     for K in (64, 128, 256, 1024, 2048, 4096):
