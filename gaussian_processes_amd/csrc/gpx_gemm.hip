@@ -418,7 +418,7 @@ struct GemmMap {
     // one HBM burst per round of tiles) spread evenly over a tile time.
     int stag_blocks, stag_cycles;
     // diagnostic: when non-null, wave 0 of every workgroup stores 4 s_memtime stamps
-    // (start, first barrier passed, k-loop done, epilogue done) and 2 s_memrealtime stamps at stamps[6 * blockIdx]
+    // (start, first barrier passed, k-loop done, epilogue done) 2 s_memrealtime stamps and the hardware ids at stamps[8 * blockIdx]
     unsigned long long *stamps;
     int ablate;   // diagnostic (GPX_GEMM_ABLATE): 1 no barrier/vmcnt, 2 no DMA in loop, 4 no LDS reads in loop
     int vec_c;    // C allows 2-element vector accesses (ldc even, aligned base, N even)
@@ -478,6 +478,9 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_nt_fast_kernel(int64_t M, int6
     const int64_t brow0 = bn0 + fm.boff + cshift;                   // B-operand row of tile column 0
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // panel products (TAG 0) run beside the trailing update (TAG 1) of the other stream and are on
+    // the critical path of the next step: let their waves win the instruction arbiter
+    if (TAG == 0) __builtin_amdgcn_s_setprio(2);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: keep it scalar
@@ -654,9 +657,12 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_nt_fast_kernel(int64_t M, int6
     if (fm.stamps && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned long long st3 = __builtin_amdgcn_s_memtime();
-        unsigned long long *o = fm.stamps + 6 * (size_t)bid;
+        unsigned long long *o = fm.stamps + 8 * (size_t)bid;
         o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3;
         o[4] = rt0; o[5] = __builtin_amdgcn_s_memrealtime();      // 100 MHz reference: shader clock = d(memtime) / d(realtime)
+        // where it ran: HW_REG_HW_ID (cu / sh / se ...) and HW_REG_XCC_ID
+        o[6] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
+               (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
     }
 }
 #undef GPX_DSR
