@@ -210,13 +210,29 @@ def measure_single(args, lib, _lib, N, d, m, dtid, npdt, steps, warmup, local_ra
         g = prof["gemm_trailing"]
         achieved = g["work"] / (g["ms"] * 1e-3) / 1e12
         roofline = {"bound": "mfma",
-                    "kernel": "gpx::gemm_nt_fast_kernel<%s, 128, 1> (trailing SYRK updates of the factorisation)"
+                    "kernel": "gpx::gemm_nt_fast_kernel<%s, 128, 1, 128> (trailing SYRK updates of the factorisation)"
                               % ("double" if dtype_name == "f64" else "float"),
                     "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": None,
                     "launches_per_step": g["launches"] / steps,
                     "avg_launch_ms": round(g["ms"] / g["launches"], 4),
                     "flops_per_step": g["work"] / steps}
+        # HBM-side bytes per launch of that kernel: PMC counters cannot be read from inside this
+        # process, so the figure is the committed rocprofv3 --pmc measurement of THIS command and
+        # workload (two separate passes, FETCH_SIZE with the gfx950 x2 correction + WRITE_SIZE);
+        # null for any workload that was not profiled
+        if N == 65536 and d == 32 and dtype_name == "f64":
+            try:
+                pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc",
+                                        "traffic_n65536_v7.json")
+                with open(pmc_path) as f:
+                    pmc = json.load(f)
+                roofline["traffic"] = round(pmc["traffic_bytes_per_launch"])
+                roofline["traffic_unit"] = "bytes per launch (fetch corrected %.3e + write %.3e)" % (
+                    pmc["fetch_bytes_per_launch_corrected"], pmc["write_bytes_per_launch"])
+                roofline["traffic_source"] = "profiles/r01_pmc/traffic_n65536_v7.json (rocprofv3 --pmc, offline)"
+            except (OSError, KeyError, ValueError):
+                pass
     potrf_tflops = (N ** 3 / 3.0) / (stage_ms[1] * 1e-3) / 1e12 if stage_ms[1] > 0 else None
 
     result = {

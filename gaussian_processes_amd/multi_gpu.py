@@ -463,7 +463,7 @@ def bench_distributed(args, X, y, Xo, params, s, dtype_id):
         "whole_step_tflops_n3_over_3": round(tfl, 3),
         "whole_step_frac_of_peak_all_gpus": round(tfl / (peak * world), 4),
         "roofline": ({"bound": "mfma",
-                      "kernel": "gpx::gemm_nt_fast_kernel<T, 128, 1> (trailing SYRK updates) on rank 0",
+                      "kernel": "gpx::gemm_nt_fast_kernel<T, 128, 1, 128> (trailing SYRK updates) on rank 0",
                       "achieved": round(rank0_gemm["tflops"], 3), "peak": peak, "unit": "TFLOP/s",
                       "frac": round(rank0_gemm["tflops"] / peak, 4), "traffic": None,
                       "launches_per_step": rank0_gemm["launches_per_step"],
