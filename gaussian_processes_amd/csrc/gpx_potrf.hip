@@ -308,7 +308,8 @@ static int potrf_panel_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, i
         static const bool force_rows = getenv("GPX_POTRF_TRSM_ROWS") != nullptr;
         // measured: the inverse + MFMA route wins for short panels (N = 8192: -2.7 % per fit) and
         // loses for tall ones (N = 65536: +2 %, its 120 KiB tiles displace trailing-update workgroups)
-        const bool via_inverse = !force_rows && below > 0 && below <= 16384 && jb == IB &&
+        static const int64_t inv_max = getenv("GPX_POTRF_INV_MAX") ? atoll(getenv("GPX_POTRF_INV_MAX")) : 16384;
+        const bool via_inverse = !force_rows && below > 0 && below <= inv_max && jb == IB &&
                                  lda % (16 / (int64_t)sizeof(T)) == 0 &&
                                  ((uintptr_t)(A + (r0 + jb) * lda + c0)) % 16 == 0;
         T *inv = nullptr;

@@ -445,6 +445,67 @@ def test_potrf_panel_device_api_matches_full_factor():
     np.testing.assert_allclose(L, scipy.linalg.cholesky(A, lower=True), rtol=1e-9, atol=1e-11)
 
 
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("n,ncols,ld", [(1, 1, 1), (63, 63, 63), (64, 64, 64), (200, 200, 201), (511, 511, 512),
+                                        (513, 513, 520), (1400, 1400, 1408), (2100, 700, 704), (3000, 512, 512),
+                                        (900, 37, 37), (2600, 1029, 1031)])
+def test_trsv_device_api_vs_numpy(dtype, n, ncols, ld):
+    """gpx_d_trsv_lower (both directions, square) and gpx_d_trsv_lower_cols (trapezoid: forward solve
+    of the top triangle + reduction of the right-hand side below it) against numpy, over one, several
+    and ragged 512-column blocks, even and odd leading dimensions (vector / scalar load paths)."""
+    npdt, did, tol = (np.float64, _lib.F64, 1e-11) if dtype == "f64" else (np.float32, _lib.F32, 2e-4)
+    rng = np.random.RandomState(n * 7 + ncols)
+    Lh = rng.uniform(-1, 1, (n, ld)) / max(ncols, 1) ** 0.5
+    Lh[:, ncols:] = np.nan                           # beyond the panel: must never be read
+    for i in range(ncols):
+        Lh[i, i] = 1.0 + rng.rand()
+        Lh[i, i + 1:ncols] = np.nan                  # strict upper triangle: must never be read
+    y = rng.randn(n)
+    lib = _lib.load()
+    dL = DeviceBuffer.from_host(Lh.astype(npdt))
+    tri = np.tril(Lh[:ncols, :ncols]).astype(npdt).astype(np.float64)
+    below = np.nan_to_num(Lh[ncols:, :ncols]).astype(npdt).astype(np.float64)
+    z_ref = scipy.linalg.solve_triangular(tri, y[:ncols], lower=True)
+    # forward, trapezoid
+    db = DeviceBuffer.from_host(y.astype(npdt))
+    dz = DeviceBuffer((n,), npdt).zero()
+    _lib.check(lib.gpx_d_trsv_lower_cols(did, dL.ptr, n, ld, ncols, db.ptr, dz.ptr, None))
+    sync()
+    np.testing.assert_allclose(dz.to_host()[:ncols], z_ref, rtol=tol, atol=tol * np.abs(z_ref).max())
+    if n > ncols:
+        w_ref = y[ncols:] - below @ z_ref
+        np.testing.assert_allclose(db.to_host()[ncols:], w_ref, rtol=tol, atol=tol * max(1.0, np.abs(w_ref).max()))
+    if n == ncols:
+        # square: forward through gpx_d_trsv_lower, then the transposed solve
+        db = DeviceBuffer.from_host(y.astype(npdt))
+        dz2 = DeviceBuffer((n,), npdt).zero()
+        _lib.check(lib.gpx_d_trsv_lower(did, dL.ptr, n, ld, db.ptr, dz2.ptr, 0, None))
+        da = DeviceBuffer((n,), npdt).zero()
+        dzc = DeviceBuffer.from_host(dz2.to_host())
+        _lib.check(lib.gpx_d_trsv_lower(did, dL.ptr, n, ld, dzc.ptr, da.ptr, 1, None))
+        sync()
+        np.testing.assert_allclose(dz2.to_host(), z_ref, rtol=tol, atol=tol * np.abs(z_ref).max())
+        a_ref = scipy.linalg.solve_triangular(tri.T, dz2.to_host().astype(np.float64), lower=False)
+        np.testing.assert_allclose(da.to_host(), a_ref, rtol=tol, atol=tol * np.abs(a_ref).max())
+
+
+@pytest.mark.parametrize("n,m,d", [(100, 3, 1), (257, 8, 2), (5000, 9, 5), (9000, 1000, 8), (70000, 17, 3)])
+def test_fused_mean_device_api_vs_numpy(n, m, d):
+    """gpx_d_mean (test points x training-set slices, partial sums reduced in a fixed order) against
+    the oracle's kernel matrix times alpha."""
+    rng = np.random.RandomState(n + m)
+    x = rng.uniform(-3, 3, (n, d)); xo = rng.uniform(-3, 3, (m, d)); alpha = rng.randn(n)
+    params = np.array([1.3, 0.9])
+    lib = _lib.load()
+    dx, dxo, da = DeviceBuffer.from_host(x), DeviceBuffer.from_host(xo), DeviceBuffer.from_host(alpha)
+    out = DeviceBuffer((m,)).zero()
+    _lib.check(lib.gpx_d_mean(_lib.F64, _lib.KERNEL_GAUSSIAN, dxo.ptr, m, dx.ptr, n, d, _lib.dptr(params), da.ptr,
+                              out.ptr, None))
+    sync()
+    ref = orc.kernel_matrix("gaussian", "K", xo, x, params) @ alpha
+    np.testing.assert_allclose(out.to_host(), ref, rtol=1e-10, atol=1e-10 * np.abs(ref).max())
+
+
 # ------------------------------------------------ multi-process path on the real kernels --
 def test_distributed_single_rank_hip_ops_vs_oracle():
     from gaussian_processes_amd import multi_gpu
