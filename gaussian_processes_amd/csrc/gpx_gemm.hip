@@ -410,13 +410,14 @@ __device__ __forceinline__ int f_swz(int r) { return (0x64753120u >> (4 * ((r >>
 struct GemmMap {
     int64_t boff, cbase, nb, pm1nb, brows;
     int np, a, b, R;
+    // diagonal split (BM = 128, exactly aligned lower-triangular maps): blocks >= dbegin enumerate
+    // ONLY the 36 tiles at or below the diagonal of the ndiag diagonal patches (patch column pc,
+    // patch row bdiag + pc); the staircase above then starts one patch below the diagonal.  Without
+    // it 28 of the 64 workgroups of every diagonal patch return at once -- and still pass, in order,
+    // through the dispatcher in front of real tiles.
+    int dbegin, ndiag, bdiag;
     int csh;      // log2 of the tile columns per patch (3: 8 x BN = 1024 columns; fewer for narrow products,
                   // so that no workgroup is launched only to find its tile outside the matrix)
-    // start-up stagger: the first `stag_blocks` workgroups delay their start by
-    // blockIdx * stag_cycles / stag_blocks shader cycles, so that the C read-modify-write
-    // epilogues of the 256 CUs (which otherwise all fall together, stalling the chip on
-    // one HBM burst per round of tiles) spread evenly over a tile time.
-    int stag_blocks, stag_cycles;
     // diagnostic: when non-null, wave 0 of every workgroup stores 4 s_memtime stamps
     // (start, first barrier passed, k-loop done, epilogue done) 2 s_memrealtime stamps and the hardware ids at stamps[8 * blockIdx]
     unsigned long long *stamps;
@@ -453,10 +454,19 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_nt_fast_kernel(int64_t M, int6
     const int xcd = bid & 7, loc = bid >> 3;
     constexpr int RSH = BM == 256 ? 2 : 3;                          // log2 of the tile rows per patch
     const int tsh = RSH + fm.csh;
-    const int patch = (loc >> tsh) * 8 + xcd, within = loc & ((1 << tsh) - 1);
-    if (patch >= fm.np) return;
+    int patch = (loc >> tsh) * 8 + xcd, within = loc & ((1 << tsh) - 1);
     int pb_r, pb_c;
-    if (fm.a == 0) {
+    if (BM == 128 && bid >= fm.dbegin) {
+        const int b2 = bid - fm.dbegin;
+        const int loc2 = b2 >> 3, dp = (loc2 / 36) * 8 + (b2 & 7), t = loc2 % 36;
+        if (dp >= fm.ndiag) return;
+        int r = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);     // t = r (r + 1) / 2 + c, c <= r
+        if ((r + 1) * (r + 2) / 2 <= t) ++r;
+        if (r * (r + 1) / 2 > t) --r;
+        pb_c = dp; pb_r = fm.bdiag + dp; within = r * 8 + (t - r * (r + 1) / 2);
+    } else if (patch >= fm.np) {
+        return;
+    } else if (fm.a == 0) {
         pb_c = patch / fm.R; pb_r = fm.b + (patch - pb_c * fm.R);
     } else {
         // patches before column pc: cum(pc) = pc * R - a * pc * (pc - 1) / 2
@@ -488,11 +498,6 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_nt_fast_kernel(int64_t M, int6
 
     unsigned long long st0 = 0, st1 = 0, st2 = 0, rt0 = 0;
     if (fm.stamps) { st0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
-    if (bid < fm.stag_blocks) {
-        const unsigned long long target = (unsigned long long)bid * (unsigned)fm.stag_cycles / (unsigned)fm.stag_blocks;
-        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-        while (__builtin_amdgcn_s_memtime() - t0 < target) __builtin_amdgcn_s_sleep(16);
-    }
 
     // ---- DMA source pointers: wave w owns pieces PW*w .. PW*w + PW-1 (1 KiB = 8 rows each) of every stage ----
     const unsigned char *gsrc[PW];      // next 128-B k-slice to fetch, per DMA piece
@@ -699,8 +704,28 @@ static int launch_gemm_nt_fast(int64_t M, int64_t N, int64_t K, const void *A, i
         }
         fm.np = (int)np;
     }
+    fm.dbegin = 0x7fffffff; fm.ndiag = 0; fm.bdiag = 0;
+    int64_t dblocks = 0;
+    {
+        static const bool no_split = getenv("GPX_GEMM_NO_DSPLIT") != nullptr;
+        if (!no_split && BM == 128 && BN == 128 && tri == GPX_LOWER && fm.a == 1 && fm.csh == 3 && fm.pm1nb == 0 &&
+            col0 - row0 == (int64_t)fm.b * 1024 && fm.np > 0) {
+            const int64_t pbc = cdiv(N, 1024);
+            fm.bdiag = fm.b;
+            fm.ndiag = (int)std::min<int64_t>(pbc, fm.R);
+            fm.b += 1; fm.R -= 1;
+            int64_t npa = 0;
+            for (int64_t pc = 0; pc < pbc; ++pc) {
+                const int64_t cnt = fm.R - pc;
+                if (cnt <= 0) break;
+                npa += cnt;
+            }
+            fm.np = (int)npa;
+            dblocks = cdiv(fm.ndiag, 8) * 8 * 36;
+        }
+    }
     const int64_t np = fm.np;
-    if (np <= 0) return GPX_OK;
+    if (np <= 0 && dblocks == 0) return GPX_OK;
     {
         static const bool no_vec = getenv("GPX_GEMM_NO_VEC_C") != nullptr;
         fm.vec_c = (!no_vec && ldc % 2 == 0 && N % 2 == 0 && N >= 2 && ((uintptr_t)C) % (2 * sizeof(T)) == 0) ? 1 : 0;
@@ -709,20 +734,13 @@ static int launch_gemm_nt_fast(int64_t M, int64_t N, int64_t K, const void *A, i
         fm.atomic_c = atomic_c;
     }
     {
-        // stagger only when the launch runs for several rounds of tiles
-        static const int pct = getenv("GPX_GEMM_STAGGER") ? atoi(getenv("GPX_GEMM_STAGGER")) : 100;
-        const int64_t nkk = K / (128 / (int64_t)sizeof(T));
-        const int64_t tile_cycles = nkk * 8192 * (sizeof(T) == 8 ? 1 : 1) + 40000;
-        fm.stag_blocks = 0; fm.stag_cycles = 0;
         fm.stamps = g_gemm_stamps;
         static const int abl = getenv("GPX_GEMM_ABLATE") ? atoi(getenv("GPX_GEMM_ABLATE")) : 0;
         fm.ablate = abl;
-        if (pct > 0 && np * 32 >= 4 * 256) {
-            fm.stag_blocks = 256;
-            fm.stag_cycles = (int)std::min<int64_t>(tile_cycles * pct / 100, 4000000);
-        }
     }
-    const int64_t blocks = (cdiv(np, 8) * 8 * (1024 / BM)) << fm.csh;
+    const int64_t ablocks = (cdiv(np, 8) * 8 * (1024 / BM)) << fm.csh;
+    if (dblocks) fm.dbegin = (int)ablocks;
+    const int64_t blocks = ablocks + dblocks;
     ProfScope prof(TAG == 1 ? PC_GEMM : (BN == 128 ? PC_GEMM_PANEL : PC_GEMM_SKINNY),
                    work >= 0 ? work : 2.0 * (double)K * updated_elements(M, N, tri, row0, col0), st);
     hipLaunchKernelGGL((gemm_nt_fast_kernel<T, BN, TAG, BM>), dim3((unsigned)blocks), dim3(BM * 2), F_SMEM, st, M, N, K,
@@ -834,7 +852,7 @@ int syrk_bc(int dtype, int64_t n, int64_t row_begin, void *Cloc, int64_t ldc, in
             np += cnt;
         }
         fm.np = (int)np;
-        fm.stag_blocks = 0; fm.stag_cycles = 0; fm.stamps = nullptr; fm.ablate = 0;
+        fm.stamps = nullptr; fm.ablate = 0;
         if (fast_bm() == 128) {
             if (dtype == GPX_F64)
                 return launch_gemm_nt_fast<double, 128, 1, 128>(M, Ncols, kb, A, ldp, Pb, ldp, C, ldc, -1.0, GPX_LOWER,
