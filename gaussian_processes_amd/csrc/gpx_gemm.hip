@@ -691,8 +691,10 @@ static int launch_gemm_nt_fast(int64_t M, int64_t N, int64_t K, const void *A, i
     } else {
         fm.boff = 0; fm.cbase = 0; fm.nb = (int64_t)1 << 40; fm.pm1nb = 0; fm.brows = N;
         fm.a = 0; fm.b = 0; fm.csh = 3;
-        if (BN == 128 && tri == GPX_LOWER && col0 >= row0) { fm.a = 1; fm.b = (int)((col0 - row0) / 1024); }
-        else while (fm.csh > 0 && ((int64_t)BN << (fm.csh - 1)) >= N) --fm.csh;     // narrow product: narrow patches
+        // lower-triangular result: skip the patch rows above the diagonal; with more than one patch
+        // column the staircase (a = 1) drops one more patch row per column
+        if (BN == 128 && tri == GPX_LOWER && col0 >= row0) { fm.a = N > 1024 ? 1 : 0; fm.b = (int)((col0 - row0) / 1024); }
+        if (fm.a == 0) while (fm.csh > 0 && ((int64_t)BN << (fm.csh - 1)) >= N) --fm.csh;   // narrow product: narrow patches
         const int64_t pbr = cdiv(M, 1024), pbc = cdiv(N, (int64_t)BN << fm.csh);
         fm.R = (int)pbr - fm.b;
         if (fm.R <= 0) return GPX_OK;                       // nothing at or below the diagonal
