@@ -556,6 +556,9 @@ def test_mlii_batch_matches_oracle_and_reference_conventions():
     assert np.isnan(llh[6]) and np.isnan(llh[7])
     i, th, best = mlii.best_restart(X, y, thetas)
     assert i == int(np.argmax(llh[:6])) and best == llh[i]
+    # several handles at once (one host thread each): bit-identical to the sequential table
+    llh3 = mlii.log_lh_batch(X, y, thetas, concurrency=3)
+    np.testing.assert_array_equal(llh3, llh)
 
 
 @pytest.mark.parametrize("N,d", [(16389, 5), (17408 + 63, 2)])
