@@ -44,7 +44,7 @@ def parse_args():
     ap.add_argument("--problem-d", dest="d", type=int, default=32)
     ap.add_argument("--problem-m", dest="m", type=int, default=1000)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
-    ap.add_argument("--cpu-sample-n", type=int, default=6144)
+    ap.add_argument("--cpu-sample-n", type=int, default=12288)    # 15-20 s of host work on the GPU box
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip per-launch HIP-event profiling")
     ap.add_argument("--no-secondary", action="store_true", help="skip the N=8192 (configs[1]) side measurement")
