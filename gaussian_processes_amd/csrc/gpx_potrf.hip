@@ -409,7 +409,12 @@ static int trailing_stream(int reserve, hipStream_t *out)
     const int ncu = prop.multiProcessorCount;
     std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
     for (int i = reserve; i < ncu; ++i) mask[i / 32] |= 1u << (i % 32);
-    GPX_HIP(hipExtStreamCreateWithCUMask(&g_la.t, (uint32_t)mask.size(), mask.data()));
+    if (hipExtStreamCreateWithCUMask(&g_la.t, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+        (void)hipGetLastError();                                // masks unsupported here: share the chip as for large n
+        g_la.t = nullptr; g_la.reserved = 0;
+        *out = nullptr;
+        return GPX_OK;
+    }
     g_la.reserved = reserve;
     *out = g_la.t;
     return GPX_OK;
@@ -451,8 +456,12 @@ int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t
     hipStream_t user = st;
     const int reserve = reserve_cus(n);
     if (reserve > 0) {
-        GPX_TRY(trailing_stream(reserve, &st));                 // the updates go to the masked stream
-        GPX_HIP(hipStreamWaitEvent(st, e, 0));
+        hipStream_t masked = nullptr;
+        GPX_TRY(trailing_stream(reserve, &masked));             // the updates go to the masked stream
+        if (masked) {
+            st = masked;
+            GPX_HIP(hipStreamWaitEvent(st, e, 0));
+        }
     }
     GPX_TRY(potrf_panel(dtype, A, lda, n, 0, 0, std::min(nb, n), info_dev, q));
     GPX_TRY(g_la.get(&ep));
