@@ -224,13 +224,13 @@ def measure_single(args, lib, _lib, N, d, m, dtid, npdt, steps, warmup, local_ra
         if N == 65536 and d == 32 and dtype_name == "f64":
             try:
                 pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc",
-                                        "traffic_n65536_v7.json")
+                                        "traffic_n65536_v8.json")
                 with open(pmc_path) as f:
                     pmc = json.load(f)
                 roofline["traffic"] = round(pmc["traffic_bytes_per_launch"])
                 roofline["traffic_unit"] = "bytes per launch (fetch corrected %.3e + write %.3e)" % (
                     pmc["fetch_bytes_per_launch_corrected"], pmc["write_bytes_per_launch"])
-                roofline["traffic_source"] = "profiles/r01_pmc/traffic_n65536_v7.json (rocprofv3 --pmc, offline)"
+                roofline["traffic_source"] = "profiles/r01_pmc/traffic_n65536_v8.json (rocprofv3 --pmc, offline)"
             except (OSError, KeyError, ValueError):
                 pass
     potrf_tflops = (N ** 3 / 3.0) / (stage_ms[1] * 1e-3) / 1e12 if stage_ms[1] > 0 else None
