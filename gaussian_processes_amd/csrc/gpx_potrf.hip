@@ -268,9 +268,13 @@ static int64_t outer_block(int64_t n)
         int64_t v = atoll(env);
         if (v >= IB && v % IB == 0) return v;
     }
+    // measured per factorisation (v8): n = 8192: 128 / 256 / 512 -> 12.6 / 11.5 / 12.5 ms; n = 16384:
+    // 256 / 512 -> 42.4 / 40.8; n = 24576: 256 / 512 / 1024 -> 106 / 98 / 102; n = 32768: 228 / 203 / 204;
+    // n = 65536: 512 / 1024 -> 1445 / 1416 ms
     if (n <= 2048) return 128;
-    if (n <= 16384) return 256;
-    return 1024;     // measured at n = 65536: 1024 -> 1.58 s, 512 -> 1.65 s, 256 -> 2.0 s per fit
+    if (n <= 12288) return 256;
+    if (n <= 32768) return 512;
+    return 1024;
 }
 
 // one 64 x 64 scratch block per host thread and device for the leaf's inverse (leaves of a
