@@ -22,16 +22,22 @@ namespace gpx {
 constexpr int IB = 64;
 constexpr int IBP = IB + 1;   // LDS pitch (elements): conflict-free column walks
 
-// ---- (b) diagonal block: unblocked right-looking Cholesky, register resident ----
+// ---- (b) diagonal block: right-looking Cholesky in 4-column steps, register resident ----
 // 256 threads hold the 64 x 64 block as 16 x 16 register tiles of 4 x 4 (thread
-// (tr, tc) owns rows 4tr.., columns 4tc..).  Column j of the running matrix goes
-// through a double-buffered 64-entry LDS vector: one barrier per column.  Scaling
-// uses the reciprocal of the pivot's square root, as LAPACK's dpotf2 does.
+// (tr, tc) owns rows 4tr.., columns 4tc..).  Step jt of 16, two barriers:
+//   A  thread (jt, jt) factors its own 4 x 4 tile (four dependent rsqrt chains: the
+//      critical path of the kernel) and publishes it with the reciprocal pivots;
+//   B  the 15 - jt threads below it in tile column jt solve their tiles against it
+//      (P <- P L_dd^-T) and publish the 4 finished columns of L;
+//   C  every tile below and to the right gets its rank-4 update from LDS.
+// (The unblocked form -- one pivot, one barrier per column -- took 24 us per block.)
+// Scaling uses the reciprocal of the pivot's square root, as LAPACK's dpotf2 does.
 // Blocks smaller than 64 are padded with the identity (pivot 1, no effect).
 // When `inv` is non-null the same sweep also carries X = L^-1 (forward elimination of
-// the identity: row j of X is scaled by 1/L[j][j] and subtracted, times L[i][j], from
-// the rows below) and stores it as a dense 64 x 64 row-major block: the row substitution
-// below the leaf then becomes one small MFMA product X_rows * inv(L)^T.
+// the identity: in step jt the four rows of X are solved against the diagonal tile and
+// then subtracted, times L, from the rows below) and stores it as a dense 64 x 64
+// row-major block: the row substitution below the leaf then becomes one small MFMA
+// product X_rows * inv(L)^T.
 __device__ __forceinline__ double fast_rsqrt(double p)
 {
     double y = __builtin_amdgcn_rsq(p);
@@ -51,8 +57,10 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(T *__restrict__ blk, in
                                                          int jb, int *__restrict__ info, T *__restrict__ inv)
 {
     // blk: the jb x jb diagonal block; j0: its global (0-based) index, for `info`
-    __shared__ T colbuf[2][IB];
-    __shared__ T rowbuf[2][IB];
+    __shared__ T sD[4][4];            // factored diagonal tile of the step (lower part)
+    __shared__ T sR[4];               // its reciprocal pivots
+    __shared__ T pan[IB][4];          // the step's 4 finished columns of L, rows below the diagonal tile
+    __shared__ T xrow[4][IB];         // INV: the step's 4 finished rows of X
     // this one workgroup is the critical path of the whole panel and usually shares its CU with
     // trailing-update workgroups of the other stream: take the instruction arbiter's top priority
     __builtin_amdgcn_s_setprio(3);
@@ -73,91 +81,106 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(T *__restrict__ blk, in
     for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int c = 0; c < 4; ++c) x[r][c] = (4 * tr + r == 4 * tc + c) ? (T)1 : (T)0;
-    if (tc == 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) colbuf[0][4 * tr + r] = a[r][0];
-    }
-    if (tr == 0) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) rowbuf[0][4 * tc + c] = x[0][c];
-    }
-    __syncthreads();
-    int cur = 0;
+
 #pragma unroll 1
     for (int jt = 0; jt < IB / 4; ++jt) {
-#pragma unroll
-        for (int jo = 0; jo < 4; ++jo) {
-            const int j = 4 * jt + jo;
-            const T piv = colbuf[cur][j];
-            if (j < jb && !(piv > (T)0)) {               // also catches NaN
-                if (tid == 0 && *info == 0) *info = (int)(j0 + j + 1);
-            }
-            // 1/sqrt(piv) by v_rsq + two Newton steps (error ~1 ulp), then sqrt(piv) = piv * rinv:
-            // a third of the dependent-instruction chain of sqrt() followed by a division,
-            // and this chain is the critical path of every column
-            const T rinv = fast_rsqrt(piv);
-            const T ljj = piv * rinv;
-            // scaled column j, zeroed outside the trailing part (rows / columns <= j): the
-            // rank-1 update below then needs no per-element mask
-            T li[4], lc[4];
+        // ---- A: the diagonal tile ----
+        if (tr == jt && tc == jt) {
+            T rk[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const T vi = colbuf[cur][4 * tr + k] * rinv;
-                const T vc = colbuf[cur][4 * tc + k] * rinv;
-                li[k] = (4 * tr + k > j) ? vi : (T)0;
-                lc[k] = (4 * tc + k > j) ? vc : (T)0;
+                const T piv = a[k][k];
+                if (4 * jt + k < jb && !(piv > (T)0)) {              // also catches NaN
+                    if (*info == 0) *info = (int)(j0 + 4 * jt + k + 1);
+                }
+                // 1/sqrt(piv) by v_rsq + Newton steps (error ~1 ulp), sqrt(piv) = piv * rinv
+                const T rinv = fast_rsqrt(piv);
+                rk[k] = rinv;
+                a[k][k] = piv * rinv;
+#pragma unroll
+                for (int r = k + 1; r < 4; ++r) a[r][k] *= rinv;
+#pragma unroll
+                for (int c = k + 1; c < 4; ++c)
+#pragma unroll
+                    for (int r = c; r < 4; ++r) a[r][c] = fma(-a[r][k], a[c][k], a[r][c]);
             }
-            if (tc == jt) {                                // owners of column j: store the final L values
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sR[r] = rk[r];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) sD[r][c] = (c <= r) ? a[r][c] : (T)0;
+            }
+        }
+        __syncthreads();
+        // ---- B: tiles below the diagonal tile: P <- P L_dd^-T (forward over the 4 columns) ----
+        if (tc == jt && tr > jt) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = 4 * tr + r;
-                    if (row > j) a[r][jo] = li[r];
-                    else if (row == j) a[r][jo] = ljj;
+                    T v = a[r][c];
+#pragma unroll
+                    for (int k = 0; k < c; ++k) v = fma(-a[r][k], sD[c][k], v);
+                    a[r][c] = v * sR[c];
                 }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) a[r][c] = fma(-li[r], lc[c], a[r][c]);
-            if (INV) {
-                T xs[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) xs[k] = rowbuf[cur][4 * tc + k] * rinv;
-                if (tr == jt) {                            // owners of row j of X: it is final now
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) x[jo][c] = xs[c];
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) x[r][c] = fma(-li[r], xs[c], x[r][c]);
-                const int jn2 = j + 1;
-                if (jn2 < IB && tr == (jn2 >> 2)) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        T v = x[0][c];
-                        if ((jn2 & 3) == 1) v = x[1][c];
-                        if ((jn2 & 3) == 2) v = x[2][c];
-                        if ((jn2 & 3) == 3) v = x[3][c];
-                        rowbuf[cur ^ 1][4 * tc + c] = v;
-                    }
-                }
-            }
-            // publish column j + 1 for the next step
-            const int jn = j + 1;
-            if (jn < IB && tc == (jn >> 2)) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    T v = a[r][0];
-                    if ((jn & 3) == 1) v = a[r][1];
-                    if ((jn & 3) == 2) v = a[r][2];
-                    if ((jn & 3) == 3) v = a[r][3];
-                    colbuf[cur ^ 1][4 * tr + r] = v;
-                }
-            }
-            __syncthreads();
-            cur ^= 1;
+                for (int c = 0; c < 4; ++c) pan[4 * tr + r][c] = a[r][c];
         }
+        if (INV && tr == jt) {
+            // rows 4jt.. of X: X_d <- L_dd^-1 X_d (forward over the 4 rows), final
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    T v = x[r][c];
+#pragma unroll
+                    for (int k = 0; k < r; ++k) v = fma(-sD[r][k], x[k][c], v);
+                    x[r][c] = v * sR[r];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) xrow[r][4 * tc + c] = x[r][c];
+        }
+        __syncthreads();
+        // ---- C: rank-4 update of everything below ----
+        if (tr > jt) {
+            T lr[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) lr[r][k] = pan[4 * tr + r][k];
+            if (tc > jt) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    T lc[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) lc[k] = pan[4 * tc + c][k];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) a[r][c] = fma(-lr[r][k], lc[k], a[r][c]);
+                }
+            }
+            if (INV) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    T xs[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) xs[k] = xrow[k][4 * tc + c];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) x[r][c] = fma(-lr[r][k], xs[k], x[r][c]);
+                }
+            }
+        }
+        // (no barrier: the next step's A touches only its own registers and sD / sR, which
+        //  nobody reads in C; pan / xrow are rewritten only after the next step's first barrier)
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r)
