@@ -24,6 +24,13 @@
  *   - "device" entry points (gpx_d_*) take DEVICE pointers and a hipStream_t
  *     passed as void* (NULL = the null stream); they enqueue work and return.
  *     Device matrices must have ld % 16 == 0 and 16-byte aligned bases.
+ *     Threading: the library keeps its scratch blocks, the look-ahead side
+ *     stream and its event pool PER HOST THREAD.  gpx_d_potrf, gpx_d_potrf_panel,
+ *     gpx_d_trsv_lower*, gpx_d_mean issued from one host thread must therefore
+ *     not be in flight on two streams at once (synchronise before switching
+ *     streams, or drive each stream from its own host thread); handles
+ *     (gpx_gp_*) synchronise their stream before they return and are safe to
+ *     use concurrently from different host threads.
  *   - "host" entry points (gpx_gaussian_c_*, gpx_periodic_c_*, gpx_gp_c_*,
  *     gpx_cholesky, gpx_cho_solve ...) take HOST pointers with the reference's
  *     exact argument meaning, run on the current device and return when the
