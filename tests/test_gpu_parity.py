@@ -581,6 +581,25 @@ def test_ragged_sizes_above_the_nb1024_threshold(N, d):
                                rtol=1e-9, atol=1e-11)
 
 
+@pytest.mark.parametrize("N,d", [(2049, 2), (4097, 3), (12289 + 70, 2)])
+def test_sizes_at_the_outer_block_boundaries(N, d):
+    """n just above 2048 / 4096 / 12288: the outer block switches 128 -> 256 -> 512, the CU-masked
+    update stream is on below 12288 and off above, and every size leaves a ragged last block column.
+    Checked by size-independent properties (K alpha = y on sampled rows, log_lh identity from L)."""
+    X, y, Xo = orc.synth_inputs(N, d, 16)
+    h, w, s = 1.0, 0.5 * np.sqrt(d), 1.0
+    g = gp.GP(gp.GaussianKernel(h, w), X, y, s=s)
+    alpha = g.inv_Kxx_y
+    rows = np.unique(np.array([0, 1, 63, 64, 255, 256, 511, 512, 1023, 1024, 2047, 2048, N // 2, N - 2, N - 1]))
+    Krows = orc.kernel_matrix("gaussian", "K", X[rows], X, (h, w))
+    Krows[np.arange(rows.size), rows] += s * s
+    np.testing.assert_allclose(Krows @ alpha, y[rows], rtol=1e-9, atol=1e-10)
+    L = g.Lxx
+    np.testing.assert_allclose(L[rows] @ L.T, Krows, rtol=1e-11, atol=1e-12)
+    logdet = 2 * np.log(np.diag(L)).sum()
+    np.testing.assert_allclose(g.log_lh, -0.5 * y @ alpha - 0.5 * logdet - 0.5 * N * np.log(2 * np.pi), rtol=1e-12)
+
+
 def test_device_gradient_vs_oracle_and_finite_differences():
     # SURVEY 8(f) rank 2: dloglh_dtheta computed on the device (K^-1 stays in HBM)
     N, d = 700, 3
