@@ -15,6 +15,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
+def pytest_sessionstart(session):
+    """A fresh checkout has no built artefacts (they are git-ignored): build the HIP library and the
+    oracle's C restatement once, exactly as __graft_entry__.build() does.  hipcc cross-compiles
+    without a GPU; if it is absent the tests that need the library fail loudly on their own."""
+    so = os.path.join(ROOT, "gaussian_processes_amd", "libgpx.so")
+    if not os.path.exists(so):
+        try:
+            import __graft_entry__
+            __graft_entry__.build()
+        except Exception as exc:       # report, do not hide: the dependent tests will fail with the real reason
+            sys.stderr.write("conftest: building libgpx.so failed: %r\n" % (exc,))
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name))
 
