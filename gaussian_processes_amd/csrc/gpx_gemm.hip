@@ -363,22 +363,22 @@ int launch_gemm_nt(int64_t M, int64_t N, int64_t K, const void *A, int64_t lda, 
 
 // ===========================================================================
 // Fast path: K % (128 B) == 0, 16-B aligned operands.
-//   block tile 256 x 128, 512 threads = 8 waves (4 x 2), wave tile 64 x 64;
-//   operands go HBM/L2 -> LDS directly (global_load_lds_dwordx4, no VGPR
-//   staging), 3 LDS stages of 48 KiB (384 rows x 128 B), two k-steps in flight,
-//   one raw s_barrier per k-step with a counted vmcnt (never 0 in the loop);
-//   LDS rows are unpadded (the DMA writes 1 KiB = 8 rows contiguously), bank
-//   conflicts of the ds_read_b128 fragment reads are removed by an XOR swizzle
-//   applied to the per-lane GLOBAL source chunk and again on the read;
-//   tiles are walked in 4 x 8 patches (1024 x 1024 elements) and patch p is
-//   given to the blocks with blockIdx % 8 == p % 8, so that the 32 blocks that
-//   run together on one XCD share 4 A-panels and 8 B-panels in that XCD's L2.
+//   wave tile 64 x 64 (4 x 4 MFMA tiles); block tile BM x BN with BM / 64 x 2 waves:
+//     BM = 128 (default): 128 x 128 (128 x 64 for the skinny panel products), 4 waves,
+//       2 LDS stages of 32 KiB, TWO workgroups per CU -- one's prologue, epilogue and
+//       barrier stalls fall under the other's k-loop;
+//     BM = 256 (GPX_GEMM_BM=256): 256 x 128, 8 waves, 3 stages of 48 KiB, one workgroup
+//       per CU, two k-steps in flight;
+//   operands go HBM/L2 -> LDS directly (global_load_lds_dwordx4, no VGPR staging), one
+//   raw s_barrier per k-step with a counted vmcnt;
+//   LDS rows are unpadded (the DMA writes 1 KiB = 8 rows contiguously), bank conflicts
+//   of the ds_read_b128 fragment reads are removed by an XOR swizzle applied to the
+//   per-lane GLOBAL source chunk and again on the read;
+//   tiles are walked in 1024 x 1024 patches (8 x 8 tiles of 128 x 128) and patch p is
+//   given to the blocks with blockIdx % 8 == p % 8, so that the 64 workgroups that run
+//   together on one XCD (2 per CU) are one patch and share 8 A- and 8 B-slices in that
+//   XCD's L2.
 // ===========================================================================
-// BN = 128: the square-ish work-horse.  BN = 64: the same pipeline on 256 x 64 tiles
-// for the skinny (N <= 64) products of the panel factorisation.
-// BM = 256 (8 waves, 3 stages, one workgroup per CU) or BM = 128 (4 waves, 2 stages of
-// 32 KiB, TWO workgroups per CU: one's prologue / epilogue / barrier stalls fall under the
-// other's k-loop).
 template <int BN, int BM = 256> struct FGeo {
     static constexpr int NW = BM / 32;              // waves: (BM / 64) x 2
     static constexpr int NST = BM == 256 ? 3 : 2;   // LDS stages
