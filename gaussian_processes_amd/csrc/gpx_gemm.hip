@@ -5,22 +5,23 @@
 // scipy.linalg.cholesky, gp/gp.py:294), the left-looking panel updates, and the
 // TRSM/SYRK updates of the posterior covariance (gp/gp.py:622-625).
 //
-// Shape: both operands are row-major with the reduction index contiguous
-// ("NT"): C[i, j] += alpha * sum_k A[i, k] * B[j, k]  (alpha = -1 in the factorisation).  A lower Cholesky on row-major
-// storage only ever needs this form.
+// Shape: both operands are row-major with the reduction index contiguous ("NT"):
+// C[i, j] += alpha * sum_k A[i, k] * B[j, k]  (alpha = -1 in the factorisation).
+// A lower Cholesky on row-major storage only ever needs this form.
 //
 // Roofline: fp64 MFMA (v_mfma_f64_16x16x4_f64: 2048 flop per wave-instruction).
-// Algorithmic flops per launch = 2*M*N*K (M*N*K... halved for the lower-only
-// SYRK form, where tiles strictly above the diagonal are skipped).
+// Algorithmic flops per launch = 2*K per updated element of C (all M*N of them, or
+// only those at or below the diagonal in the lower-only SYRK form).
 //
-// Tiling: workgroup = 256 threads = 4 waves (2 x 2); block tile 128 x 128; each
-// wave owns 64 x 64 = 4 x 4 MFMA tiles (128 accumulator VGPRs in fp64).  A
-// k-step is 128 bytes of every operand row (16 doubles / 32 floats): one full
-// cache line per row from HBM/L2, staged global -> registers -> LDS with the
-// next k-step's loads in flight under the current step's 64 (128 for fp32)
-// MFMAs, double-buffered LDS, one barrier per k-step.  The MFMA reduction index
-// is permuted so that every lane reads 32 contiguous bytes of its row from LDS
-// (2 x ds_read_b128) per k-step: lane (i, q) holds k = q*S + s for sub-step s.
+// Two kernels.  gemm_nt_kernel (generic shapes: K tail, unaligned operands): workgroup
+// = 256 threads = 4 waves (2 x 2), block tile 128 x 128, wave tile 64 x 64 = 4 x 4 MFMA
+// tiles (128 accumulator VGPRs in fp64); a k-step is 128 bytes of every operand row
+// (16 doubles / 32 floats), staged global -> registers -> LDS with the next k-step's
+// loads in flight under the current step's MFMAs, double-buffered LDS, one barrier
+// per k-step.  gemm_nt_fast_kernel (everything the factorisation launches): the same
+// wave tile fed by LDS-DMA, see the block comment at "Fast path".  In both the MFMA
+// reduction index is permuted so that every lane reads 32 contiguous bytes of its row
+// from LDS (2 x ds_read_b128) per k-step: lane (i, q) holds k = q*S + s for sub-step s.
 #include "gpx_common.h"
 
 namespace gpx {

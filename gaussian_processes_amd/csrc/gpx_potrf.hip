@@ -10,8 +10,9 @@
 //   for each block column k0 (width kb <= nb)                      -- right-looking
 //     panel: recursive halving down to 64 columns (see potrf_panel_t)
 //       (a) A[j0:, j0:j0+64] -= A[j0:, k0:j0] * A[j0:j0+64, k0:j0]^T    MFMA gemm_nt
-//       (b) factor the 64 x 64 diagonal block in LDS (one workgroup)
-//       (c) rows below: A[r, j0:j0+64] <- A[r, j0:j0+64] * Ljj^-T       (one lane per row)
+//       (b) factor the 64 x 64 diagonal block in registers (one workgroup, 4-column steps)
+//       (c) rows below: A[r, j0:j0+64] <- A[r, j0:j0+64] * Ljj^-T       (one lane per row, or for
+//           short panels a fused 64 x 64 inverse + one MFMA product)
 //     trailing update A[k0+kb:, k0+kb:] -= P * P^T, P = A[k0+kb:, k0:k0+kb]  MFMA gemm_nt, lower
 // >= 97 % of the flops at N = 65536 are in the trailing update (K = nb deep).
 #include "gpx_common.h"
