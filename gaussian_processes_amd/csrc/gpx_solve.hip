@@ -535,7 +535,8 @@ int trsm_right_lt(int dtype, const void *L, int64_t n, int64_t ldl, void *X, int
 {
     if (n <= 0 || m <= 0) return GPX_OK;
     const size_t es = esize(dtype);
-    const int64_t NB = n >= 8192 ? 512 : 256;
+    static const int64_t nb_env = getenv("GPX_TRSM_NB") ? atoll(getenv("GPX_TRSM_NB")) : 0;
+    const int64_t NB = nb_env > 0 ? nb_env : (n >= 8192 ? 512 : 256);
     auto Lp = [&](int64_t r, int64_t c) { return (const char *)L + (r * ldl + c) * es; };
     auto Xp = [&](int64_t c) { return (char *)X + c * es; };
     for (int64_t k0 = 0; k0 < n; k0 += NB) {
