@@ -196,10 +196,35 @@ class TorchComm(object):
         self.to_tensor = to_tensor or (lambda a: a)
         # rehearsal switch: issue the collectives even in a world of one rank
         self.always = bool(os.environ.get("GPX_FORCE_COLLECTIVES"))
+        # panel broadcast algorithm: "bcast" (one collective, default) or "sag" (scatter + all-gather)
+        self.bcast_mode = os.environ.get("GPX_DIST_BCAST", "bcast")
+        self.sag_min = int(os.environ.get("GPX_DIST_SAG_MIN", str(1 << 20)))     # elements
 
     def broadcast(self, arr, start, count, src):
-        if (self.world > 1 or self.always) and count > 0:
-            self.dist.broadcast(self.to_tensor(arr).view(-1)[start:start + count], src=src)
+        if not ((self.world > 1 or self.always) and count > 0):
+            return
+        flat = self.to_tensor(arr).view(-1)[start:start + count]
+        if self.bcast_mode == "sag" and self.world > 2 and count % self.world == 0 and count >= self.sag_min:
+            # scatter + all-gather: the root sends a different 1/P of the payload to every peer
+            # (P - 1 point-to-point links at once), then every rank forwards its piece to all others.
+            # On a fully connected xGMI node each step moves 1/P of the bytes per link instead of the
+            # whole payload over a ring.  Opt-in (GPX_DIST_BCAST=sag) until measured on a real node.
+            dist = self.dist
+            chunk = count // self.world
+            mine = flat[self.rank * chunk:(self.rank + 1) * chunk]
+            if self.rank == src:
+                ops = [dist.P2POp(dist.isend, flat[p * chunk:(p + 1) * chunk], p)
+                       for p in range(self.world) if p != src]
+            else:
+                ops = [dist.P2POp(dist.irecv, mine, src)]
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+            if dist.get_backend() == "nccl":
+                dist.all_gather_into_tensor(flat, mine)          # in place: `mine` is rank's slice of `flat`
+            else:
+                dist.all_gather([flat[p * chunk:(p + 1) * chunk] for p in range(self.world)], mine)
+            return
+        self.dist.broadcast(flat, src=src)
 
     def all_reduce_sum(self, arr, start, count):
         if (self.world > 1 or self.always) and count > 0:

@@ -47,6 +47,15 @@ def test_gloo_world_matches_oracle(tmp_path, world, N, nb):
     _check(res, N, 2, 33)
 
 
+def test_gloo_world4_scatter_allgather_panel_broadcast(tmp_path, monkeypatch):
+    # the opt-in panel broadcast (root scatters 1/P to every peer, then all-gather) must give the same
+    # factorisation: 4 ranks, every broadcast (panels and the solve's block vectors) through it
+    monkeypatch.setenv("GPX_DIST_BCAST", "sag")
+    monkeypatch.setenv("GPX_DIST_SAG_MIN", "1")
+    res = run_world(4, "gloo", False, 1024, 2, 128, 20, str(tmp_path))
+    _check(res, 1024, 2, 20)
+
+
 def test_info_reduction_and_minus_inf():
     # a failed panel (LAPACK-style info > 0) must surface as info_host and log_lh = -inf
     N, d = 300, 2
