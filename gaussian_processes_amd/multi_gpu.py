@@ -66,15 +66,21 @@ class BlockCyclic(object):
         return None
 
 
-def default_nb(n):
+def default_nb(n, world=8):
+    """Block-column width.  Few ranks (the update per rank outlasts the owner's chain of column
+    update + panel + pack + broadcast): the single-GPU choice, 1024 for large n.  More ranks: 512 --
+    the chain is the critical path and twice as many, half as long steps keep every rank's share of
+    the update even."""
     env = os.environ.get("GPX_POTRF_NB")
     if env:
         return int(env)
     if n <= 2048:
         return 128
-    if n <= 16384:
+    if n <= 12288:
         return 256
-    return 512
+    if n <= 32768 or world > 2:
+        return 512
+    return 1024
 
 
 # ------------------------------------------------------------------- HIP ops --
@@ -264,7 +270,7 @@ class DistributedGP(object):
     def __init__(self, ops, comm, n, d, kernel_id=_lib.KERNEL_GAUSSIAN, nb=None):
         self.ops, self.comm = ops, comm
         self.n, self.d, self.kernel_id = int(n), int(d), kernel_id
-        self.lay = BlockCyclic(n, nb or default_nb(n), comm.world, comm.rank)
+        self.lay = BlockCyclic(n, nb or default_nb(n, comm.world), comm.world, comm.rank)
         lay = self.lay
         self.A = ops.empty((lay.n, lay.ld))
         self.pbuf = [ops.empty((lay.n, lay.nb)), ops.empty((lay.n, lay.nb))]
