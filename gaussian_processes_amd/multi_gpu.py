@@ -211,24 +211,27 @@ class TorchComm(object):
             return
         flat = self.to_tensor(arr).view(-1)[start:start + count]
         if self.bcast_mode == "sag" and self.world > 2 and count % self.world == 0 and count >= self.sag_min:
-            # scatter + all-gather: the root sends a different 1/P of the payload to every peer
-            # (P - 1 point-to-point links at once), then every rank forwards its piece to all others.
-            # On a fully connected xGMI node each step moves 1/P of the bytes per link instead of the
-            # whole payload over a ring.  Opt-in (GPX_DIST_BCAST=sag) until measured on a real node.
+            # scatter + direct all-gather, point-to-point only: (1) the root sends a different 1/P of
+            # the payload to every peer, (2) every rank sends its piece straight to every other rank.
+            # On a fully connected xGMI node each phase moves 1/P of the bytes over every link at once,
+            # where a ring collective pushes the whole payload through one link after the other.
+            # Opt-in (GPX_DIST_BCAST=sag) until measured on a real node.
             dist = self.dist
             chunk = count // self.world
-            mine = flat[self.rank * chunk:(self.rank + 1) * chunk]
+            piece = lambda p: flat[p * chunk:(p + 1) * chunk]
             if self.rank == src:
-                ops = [dist.P2POp(dist.isend, flat[p * chunk:(p + 1) * chunk], p)
-                       for p in range(self.world) if p != src]
+                ops = [dist.P2POp(dist.isend, piece(p), p) for p in range(self.world) if p != src]
             else:
-                ops = [dist.P2POp(dist.irecv, mine, src)]
+                ops = [dist.P2POp(dist.irecv, piece(self.rank), src)]
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
-            if dist.get_backend() == "nccl":
-                dist.all_gather_into_tensor(flat, mine)          # in place: `mine` is rank's slice of `flat`
-            else:
-                dist.all_gather([flat[p * chunk:(p + 1) * chunk] for p in range(self.world)], mine)
+            ops = [dist.P2POp(dist.isend, piece(self.rank), p)
+                   for p in range(self.world) if p != self.rank and p != src]
+            if self.rank != src:
+                ops += [dist.P2POp(dist.irecv, piece(q), q) for q in range(self.world) if q != self.rank]
+            if ops:
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
             return
         self.dist.broadcast(flat, src=src)
 
