@@ -67,7 +67,8 @@ int make_kparams(int kernel, int member, const double *params, double diag_add, 
 // C = beta * C + alpha * A * B^T with beta = 1 (default) or 0 (beta0 != 0: C is not read)
 int gemm_nt(int dtype, int64_t M, int64_t N, int64_t K, const void *A, int64_t lda, const void *B,
             int64_t ldb, void *C, int64_t ldc, double alpha, int tri, int64_t row0, int64_t col0,
-            hipStream_t st, int beta0 = 0);
+            hipStream_t st, int beta0 = 0, int ktri = 0);
+// (ktri != 0: A == B is upper triangular in (row, k) and M == N == K -- the k-loop of tile row i skips k < i)
 // X[r, 0:jb] <- X[r, 0:jb] * Ljj^-T for rows r in [0, rows); Ljj = jb x jb lower block
 int trsm_rows(int dtype, void *X, int64_t ldx, int64_t rows, const void *Ljj, int64_t ldl, int jb,
               hipStream_t st);
@@ -81,7 +82,7 @@ int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t
 int trsv_lower(int dtype, const void *L, int64_t n, int64_t ldl, void *b, void *x, int transpose,
                hipStream_t st);
 int trsm_right_lt(int dtype, const void *L, int64_t n, int64_t ldl, void *X, int64_t m, int64_t ldx,
-                  hipStream_t st);
+                  hipStream_t st, int x_upper = 0);
 int logdet_chol(int dtype, const void *L, int64_t n, int64_t ldl, double *out_dev, hipStream_t st);
 int dot(int dtype, const void *a, const void *b, int64_t n, double *out_dev, hipStream_t st);
 int tril(int dtype, void *A, int64_t n, int64_t lda, hipStream_t st);

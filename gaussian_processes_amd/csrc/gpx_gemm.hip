@@ -417,6 +417,9 @@ struct GemmMap {
     // it 28 of the 64 workgroups of every diagonal patch return at once -- and still pass, in order,
     // through the dispatcher in front of real tiles.
     int dbegin, ndiag, bdiag;
+    // ktri: both operands are UPPER triangular in their own (row, k) index space (X = L^-T): the
+    // product of tile rows bm0.. needs only k >= bm0, the k-loop starts there (K = M = N products)
+    int ktri;
     int csh;      // log2 of the tile columns per patch (3: 8 x BN = 1024 columns; fewer for narrow products,
                   // so that no workgroup is launched only to find its tile outside the matrix)
     // diagnostic: when non-null, wave 0 of every workgroup stores 4 s_memtime stamps
@@ -500,6 +503,8 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_nt_fast_kernel(int64_t M, int6
     unsigned long long st0 = 0, st1 = 0, st2 = 0, rt0 = 0;
     if (fm.stamps) { st0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
 
+    // ktri: rows >= bm0 of an upper-triangular operand are zero for k < bm0 (bm0 is a multiple of EPK)
+    const int kskip = fm.ktri ? (int)(min(bm0, K - EPK) / EPK) : 0;
     // ---- DMA source pointers: wave w owns pieces PW*w .. PW*w + PW-1 (1 KiB = 8 rows each) of every stage ----
     const unsigned char *gsrc[PW];      // next 128-B k-slice to fetch, per DMA piece
     {
@@ -510,10 +515,10 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_nt_fast_kernel(int64_t M, int6
             const int g = c ^ f_swz(tr);                       // global 16-B chunk held by LDS chunk c
             if (tr < F_BM) {
                 const int64_t r = min(bm0 + tr, M - 1);
-                gsrc[j] = reinterpret_cast<const unsigned char *>(A + r * lda) + g * 16;
+                gsrc[j] = reinterpret_cast<const unsigned char *>(A + r * lda) + g * 16 + kskip * (int64_t)G_ROWB;
             } else {
                 const int64_t r = min(brow0 + (tr - F_BM), fm.brows - 1);
-                gsrc[j] = reinterpret_cast<const unsigned char *>(B + r * ldb) + g * 16;
+                gsrc[j] = reinterpret_cast<const unsigned char *>(B + r * ldb) + g * 16 + kskip * (int64_t)G_ROWB;
             }
         }
     }
@@ -525,8 +530,7 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_nt_fast_kernel(int64_t M, int6
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[i][j][r] = (T)0;
 
-    const int nk = (int)(K / EPK);
-    // three stages in flight before the first wait
+    const int nk = (int)(K / EPK) - kskip;
     // three stages in flight before the first wait; when K has fewer than three slices the
     // extra stages re-fetch the last slice (never read)
     {
@@ -677,7 +681,7 @@ template <typename T, int BN = 128, int TAG = 0, int BM = 256>
 static int launch_gemm_nt_fast(int64_t M, int64_t N, int64_t K, const void *A, int64_t lda,
                                const void *B, int64_t ldb, void *C, int64_t ldc, double alpha, int tri,
                                int64_t row0, int64_t col0, hipStream_t st, const GemmMap *map = nullptr,
-                               double work = -1.0, int beta0 = 0)
+                               double work = -1.0, int beta0 = 0, int ktri = 0)
 {
     constexpr int F_SMEM = FGeo<BN, BM>::SMEM;
     static bool attr_done = false;
@@ -708,6 +712,7 @@ static int launch_gemm_nt_fast(int64_t M, int64_t N, int64_t K, const void *A, i
         fm.np = (int)np;
     }
     fm.dbegin = 0x7fffffff; fm.ndiag = 0; fm.bdiag = 0;
+    fm.ktri = (ktri && M == N && N == K) ? 1 : 0;
     int64_t dblocks = 0;
     {
         static const bool no_split = getenv("GPX_GEMM_NO_DSPLIT") != nullptr;
@@ -763,7 +768,7 @@ static int fast_bm()
 
 int gemm_nt(int dtype, int64_t M, int64_t N, int64_t K, const void *A, int64_t lda, const void *B,
             int64_t ldb, void *C, int64_t ldc, double alpha, int tri, int64_t row0, int64_t col0,
-            hipStream_t st, int beta0)
+            hipStream_t st, int beta0, int ktri)
 {
     if (M <= 0 || N <= 0 || K <= 0) return GPX_OK;
     static const bool no_fast = getenv("GPX_GEMM_NO_FAST") != nullptr;
@@ -788,9 +793,9 @@ int gemm_nt(int dtype, int64_t M, int64_t N, int64_t K, const void *A, int64_t l
         if (fast_bm() == 128) {
             if (dtype == GPX_F64)
                 return launch_gemm_nt_fast<double, 128, 0, 128>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0,
-                                                                col0, st, nullptr, -1.0, beta0);
+                                                                col0, st, nullptr, -1.0, beta0, ktri);
             return launch_gemm_nt_fast<float, 128, 0, 128>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0, col0,
-                                                           st, nullptr, -1.0, beta0);
+                                                           st, nullptr, -1.0, beta0, ktri);
         }
         if (dtype == GPX_F64)
             return launch_gemm_nt_fast<double>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0, col0, st,

@@ -427,8 +427,8 @@ int gpx_gp_get_inv_Kxx(gpx_gp_t *g, double *out, int64_t ld)
     GPX_LAUNCH_CHECK();
     GPX_HIP(hipMemsetAsync(C.p, 0, (size_t)n * lda * es, g->st));
     // X = I L^-T = L^-T ; K^-1 = L^-T L^-1 = X X^T   (gp/gp.py:311-312)
-    GPX_TRY(trsm_right_lt(g->dtype, g->A, n, lda, X.p, n, lda, g->st));
-    GPX_TRY(gemm_nt(g->dtype, n, n, n, X.p, lda, X.p, lda, C.p, lda, 1.0, GPX_FULL, 0, 0, g->st));
+    GPX_TRY(trsm_right_lt(g->dtype, g->A, n, lda, X.p, n, lda, g->st, 1));
+    GPX_TRY(gemm_nt(g->dtype, n, n, n, X.p, lda, X.p, lda, C.p, lda, 1.0, GPX_FULL, 0, 0, g->st, 0, 1));
     return download_f64(g->dtype, out, ld, C.p, lda, n, n, 0, g->st);
 }
 
@@ -460,8 +460,8 @@ int gpx_gp_dloglh_dtheta(gpx_gp_t *g, double *out)
     else hipLaunchKernelGGL((eye_kernel<float>), grid, block, 0, g->st, (float *)X.p, n, lda);
     GPX_LAUNCH_CHECK();
     GPX_HIP(hipMemsetAsync(W.p, 0, (size_t)n * lda * es, g->st));
-    GPX_TRY(trsm_right_lt(g->dtype, g->A, n, lda, X.p, n, lda, g->st));
-    GPX_TRY(gemm_nt(g->dtype, n, n, n, X.p, lda, X.p, lda, W.p, lda, 1.0, GPX_LOWER, 0, 0, g->st));
+    GPX_TRY(trsm_right_lt(g->dtype, g->A, n, lda, X.p, n, lda, g->st, 1));
+    GPX_TRY(gemm_nt(g->dtype, n, n, n, X.p, lda, X.p, lda, W.p, lda, 1.0, GPX_LOWER, 0, 0, g->st, 0, 1));
     double p4[4];
     GPX_TRY(dloglh_reduce(g->dtype, g->kernel, g->x, n, g->d, g->params, g->alpha, W.p, lda, (double *)part.p,
                           p4, g->st));

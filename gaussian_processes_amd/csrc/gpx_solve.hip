@@ -530,8 +530,11 @@ int panel_gemv_t(int dtype, const void *Lp, int64_t ldl, int64_t rows, int64_t n
 // which keeps all CUs busy even for few right-hand sides (m ~ 1000 test points); a
 // left-looking sweep would launch m/256 x 2 tiles per step.  Inside a block: 64-wide
 // substitutions by trsm_rows (shared with the Cholesky panel) with small MFMA updates.
+// x_upper: X is upper triangular on entry (the identity, when L^-T itself is wanted): rows beyond
+// the current block are still zero in its columns, so every step works on the leading k0 + kb rows
+// only -- a third of the flops.
 int trsm_right_lt(int dtype, const void *L, int64_t n, int64_t ldl, void *X, int64_t m, int64_t ldx,
-                  hipStream_t st)
+                  hipStream_t st, int x_upper)
 {
     if (n <= 0 || m <= 0) return GPX_OK;
     const size_t es = esize(dtype);
@@ -541,16 +544,17 @@ int trsm_right_lt(int dtype, const void *L, int64_t n, int64_t ldl, void *X, int
     auto Xp = [&](int64_t c) { return (char *)X + c * es; };
     for (int64_t k0 = 0; k0 < n; k0 += NB) {
         const int64_t kb = std::min(NB, n - k0);
+        const int64_t me = x_upper ? std::min(m, k0 + kb) : m;        // rows that can be non-zero here
         for (int64_t j0 = k0; j0 < k0 + kb; j0 += SB) {
             const int jb = (int)std::min<int64_t>(SB, k0 + kb - j0);
             if (j0 > k0)
-                GPX_TRY(gemm_nt(dtype, m, jb, j0 - k0, Xp(k0), ldx, Lp(j0, k0), ldl, Xp(j0), ldx, -1.0,
+                GPX_TRY(gemm_nt(dtype, me, jb, j0 - k0, Xp(k0), ldx, Lp(j0, k0), ldl, Xp(j0), ldx, -1.0,
                                 GPX_FULL, 0, 0, st));
-            GPX_TRY(trsm_rows(dtype, Xp(j0), ldx, m, Lp(j0, j0), ldl, jb, st));
+            GPX_TRY(trsm_rows(dtype, Xp(j0), ldx, me, Lp(j0, j0), ldl, jb, st));
         }
         const int64_t r = k0 + kb;
         if (r < n)
-            GPX_TRY(gemm_nt(dtype, m, n - r, kb, Xp(k0), ldx, Lp(r, k0), ldl, Xp(r), ldx, -1.0, GPX_FULL, 0, 0,
+            GPX_TRY(gemm_nt(dtype, me, n - r, kb, Xp(k0), ldx, Lp(r, k0), ldl, Xp(r), ldx, -1.0, GPX_FULL, 0, 0,
                             st));
     }
     return GPX_OK;
