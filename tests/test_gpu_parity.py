@@ -619,6 +619,16 @@ def test_device_gradient_vs_oracle_and_finite_differences():
         g0.params = p0; g1.params = p1
         fd[i] = (g1.log_lh - g0.log_lh) / (2 * eps)
     np.testing.assert_allclose(grad, fd, rtol=1e-5, atol=1e-6)
+    # a size that takes the aligned MFMA route: X = L^-T built on the leading rows only, W = X X^T with
+    # the k-loop of every tile row starting at its own row (both skip the structural zeros of X)
+    N2, d2 = 1536, 2
+    X2, y2, _ = orc.synth_inputs(N2, d2, 4)
+    g2 = gp.GP(gp.GaussianKernel(1.1, 0.45 * np.sqrt(d2)), X2, y2, s=0.8)
+    o2 = orc.OracleGP("gaussian", (1.1, 0.45 * np.sqrt(d2)), X2, y2, 0.8)
+    np.testing.assert_allclose(g2.dloglh_dtheta, o2.dloglh_dtheta, rtol=1e-7, atol=1e-9)
+    Ki = g2.inv_Kxx
+    np.testing.assert_allclose(Ki, o2.inv_Kxx, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(Ki, Ki.T, rtol=0, atol=1e-12)
     # 1-D periodic
     x1 = np.sort(np.random.RandomState(3).uniform(-5, 5, 300))
     y1 = np.sin(x1)
