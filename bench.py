@@ -48,6 +48,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip per-launch HIP-event profiling")
     ap.add_argument("--no-secondary", action="store_true", help="skip the N=8192 (configs[1]) side measurement")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rendezvous only (gloo, no GPU work): proves that `bench.py --gpus P` starts P ranks")
     return ap.parse_args()
 
 
@@ -61,6 +63,27 @@ def synth(N, d, m, npdt):
     y = np.sin(X.sum(1) / np.sqrt(d)) + 0.1 * rng.randn(N)
     Xo = np.random.RandomState(1).uniform(-10, 10, (m, d))
     return X.astype(npdt), y.astype(npdt), Xo.astype(npdt)
+
+
+def sampled_row_residual(X, y, alpha, h, w, s, nrows=16):
+    """max_i |K[r_i, :] alpha - y[r_i]| / max|y| on `nrows` sampled rows, K rebuilt here in float64
+    numpy from the kernel's definition (gaussian_c.pyx:27-35, r^2 summed over the d inputs):
+    a size-independent end-to-end check of build + factor + both solves on the timed workload."""
+    X = np.asarray(X, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    N = X.shape[0]
+    rows = np.unique(np.concatenate([[0, 1, N // 2, N - 2, N - 1],
+                                     np.random.RandomState(7).randint(0, N, max(0, nrows - 5))]))
+    c1 = -0.5 / (w * w)
+    c2 = 0.5 * np.sqrt(2.0 / np.pi) * h * h / w
+    res = 0.0
+    for r in rows:
+        d2 = ((X - X[r]) ** 2).sum(1)
+        e = c1 * d2
+        k = np.where(e < -705.6238298100243, 0.0, c2 * np.exp(e))
+        k[r] += s * s
+        res = max(res, abs(float(k @ alpha) - float(y[r])))
+    return res / max(1e-300, float(np.abs(y).max())), int(rows.size)
 
 
 def cpu_baseline(N, d, m, sample_n):
@@ -100,15 +123,61 @@ def cpu_baseline(N, d, m, sample_n):
     }
 
 
+def self_launch(nproc):
+    """Start `nproc` ranks of this script under torch.distributed.run (one per GPU, rendezvous on
+    127.0.0.1), relay rank 0's JSON line, return the launcher's exit code."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // nproc)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True)
+    line = None
+    for out in proc.stdout:
+        out = out.rstrip("\n")
+        if out.startswith("{") and '"metric"' in out:
+            line = out
+        elif out:
+            sys.stderr.write(out + "\n")                   # anything else a rank printed: keep stdout to one line
+    rc = proc.wait()
+    if line is not None:
+        print(line)
+        sys.stdout.flush()
+    elif rc == 0:
+        sys.stderr.write("bench.py: the ranks exited without printing a result line\n")
+        rc = 1
+    return rc
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus P`: become the launcher.  Nothing has touched the GPU yet
+        # (no library loaded, no torch.cuda call), the ranks are CHILD processes, never an exec.
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs the torch.distributed launcher (WORLD_SIZE=%d)"
-                             % (args.gpus, world))
+        raise SystemExit("--gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+    if args.launch_check:
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t)
+        dist.barrier()
+        if rank == 0:
+            print(json.dumps({"metric": "launch check (no GPU work)", "value": None, "n_gpus": world,
+                              "launch_check": True, "rank_sum": float(t.item())}))
+        dist.destroy_process_group()
+        return
     from gaussian_processes_amd import _lib
     from gaussian_processes_amd.device import DeviceBuffer, Event, sync
     lib = _lib.load()
@@ -203,6 +272,12 @@ def measure_single(args, lib, _lib, N, d, m, dtid, npdt, steps, warmup, local_ra
     info = ctypes.c_int(0)
     _lib.check(lib.gpx_gp_info(handle, ctypes.byref(info)))
     assert info.value == 0 and np.isfinite(llh) and np.isfinite(mean_host).all()
+    # the timed result itself is checked: K alpha = y on sampled rows, outside the timed region
+    alpha_host = np.empty(N, dtype=np.float64)
+    _lib.check(lib.gpx_gp_get_alpha(handle, _lib.dptr(alpha_host)))
+    residual, nres = sampled_row_residual(X, y, alpha_host, h, w, s)
+    res_tol = 1e-9 if dtype_name == "f64" else 2e-3
+    assert residual < res_tol, "sampled-row residual %.3e exceeds %.1e" % (residual, res_tol)
 
     peak = FP64_MFMA_PEAK_TFLOPS if dtype_name == "f64" else FP32_MFMA_PEAK_TFLOPS
     roofline = None
@@ -249,6 +324,8 @@ def measure_single(args, lib, _lib, N, d, m, dtid, npdt, steps, warmup, local_ra
         "potrf_tflops": round(potrf_tflops, 3) if potrf_tflops else None,
         "potrf_frac_of_peak": round(potrf_tflops / peak, 4) if potrf_tflops else None,
         "log_lh": llh,
+        "check": {"sampled_rows": nres, "max_abs_residual_K_alpha_minus_y_over_max_y": residual,
+                  "tolerance": res_tol},
         "roofline": roofline,
         "kernels": {k: {"launches_per_step": v["launches"] / steps,
                         "ms_per_step": round(v["ms"] / steps, 3)} for k, v in prof.items()},

@@ -46,12 +46,32 @@ static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 enum ProfClass { PC_KMAT = 0, PC_GEMM = 1, PC_POTRF_DIAG = 2, PC_TRSM_ROWS = 3, PC_TRSV = 4,
                  PC_MEAN = 5, PC_REDUCE = 6, PC_GEMM_SKINNY = 7, PC_GEMM_GENERIC = 8, PC_GEMM_PANEL = 9, PC_COUNT = 10 };
 extern bool g_prof_on;
-void prof_begin(int cls, double work, hipStream_t st);
-void prof_end(hipStream_t st);
+// the registry is shared by all host threads (mutex inside); a scope ends its OWN record
+int  prof_begin(int cls, double work, hipStream_t st);    // record index, -1 when nothing was recorded
+void prof_end(int rec, hipStream_t st);
 struct ProfScope {
-    hipStream_t st; bool on;
-    ProfScope(int cls, double work, hipStream_t s) : st(s), on(g_prof_on) { if (on) prof_begin(cls, work, st); }
-    ~ProfScope() { if (on) prof_end(st); }
+    hipStream_t st; int rec;
+    ProfScope(int cls, double work, hipStream_t s) : st(s), rec(g_prof_on ? prof_begin(cls, work, s) : -1) {}
+    ~ProfScope() { if (rec >= 0) prof_end(rec, st); }
+};
+
+// hipFuncAttributeMaxDynamicSharedMemorySize, once per (kernel, device); thread-safe
+int set_max_lds(const void *fn, int bytes);
+
+// Makes `device` current for the calling host thread and restores the previous one on scope
+// exit (HIP's current device is per host thread; handles remember the device they live on).
+struct DeviceGuard {
+    int prev = -1; bool switched = false; int rc = GPX_OK;
+    explicit DeviceGuard(int device)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }
+        if (device >= 0 && device != prev) {
+            hipError_t e = hipSetDevice(device);
+            if (e != hipSuccess) rc = hip_fail(e, "hipSetDevice", __FILE__, __LINE__);
+            else switched = true;
+        }
+    }
+    ~DeviceGuard() { if (switched && prev >= 0) (void)hipSetDevice(prev); }
 };
 
 // parameters of a kernel-matrix member, precomputed on the host in f64
@@ -74,7 +94,7 @@ int trsm_rows(int dtype, void *X, int64_t ldx, int64_t rows, const void *Ljj, in
               hipStream_t st);
 int syrk_bc(int dtype, int64_t n, int64_t row_begin, void *Cloc, int64_t ldc, int64_t cl0, int64_t cl1,
             const void *Pb, int64_t ldp, int64_t k0, int64_t kb, int64_t nb, int P, int rank,
-            hipStream_t st);
+            hipStream_t st, const int *abort_flag = nullptr);
 // factor rows [r0, n) x columns [c0, c0 + kb) of A whose diagonal block sits at (r0, c0)
 int potrf_panel(int dtype, void *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int64_t kb,
                 int *info_dev, hipStream_t st);

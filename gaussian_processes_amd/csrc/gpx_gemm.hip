@@ -347,12 +347,7 @@ int launch_gemm_nt(int64_t M, int64_t N, int64_t K, const void *A, int64_t lda, 
                    int64_t col0, hipStream_t st)
 {
     if (M <= 0 || N <= 0 || K <= 0) return GPX_OK;
-    static bool attr_done = false;
-    if (!attr_done) {
-        GPX_HIP(hipFuncSetAttribute((const void *)gemm_nt_kernel<T>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, G_SMEM));
-        attr_done = true;
-    }
+    GPX_TRY(set_max_lds((const void *)gemm_nt_kernel<T>, G_SMEM));
     dim3 grid((unsigned)cdiv(N, GB_N), (unsigned)cdiv(M, GB_M)), block(256);
     ProfScope prof(PC_GEMM_GENERIC, 2.0 * (double)K * updated_elements(M, N, tri, row0, col0), st);
     hipLaunchKernelGGL((gemm_nt_kernel<T>), grid, block, G_SMEM, st, M, N, K, (const T *)A, lda,
@@ -428,6 +423,10 @@ struct GemmMap {
     int ablate;   // diagnostic (GPX_GEMM_ABLATE): 1 no barrier/vmcnt, 2 no DMA in loop, 4 no LDS reads in loop
     int vec_c;    // C allows 2-element vector accesses (ldc even, aligned base, N even)
     int atomic_c; // epilogue by no-return atomic adds (GPX_GEMM_ATOMIC_C)
+    // the factorisation's `info`: once a pivot has failed the factor is garbage whatever the remaining
+    // updates do, so every workgroup of a trailing update returns at once (a non-PD theta in an ML-II
+    // sweep then costs the launches, not the flops)
+    const int *abort_flag;
 };
 static unsigned long long *g_gemm_stamps = nullptr;
 
@@ -454,6 +453,8 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_nt_fast_kernel(int64_t M, int6
     constexpr int F_BM = BM;
 
     // ---- block -> tile (XCD-aware patch order) ----
+    // requested now, looked at after the prologue's DMA is under way (its latency hides there)
+    const int aborted = fm.abort_flag ? *fm.abort_flag : 0;
     const int bid = blockIdx.x;
     const int xcd = bid & 7, loc = bid >> 3;
     constexpr int RSH = BM == 256 ? 2 : 3;                          // log2 of the tile rows per patch
@@ -594,6 +595,10 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_nt_fast_kernel(int64_t M, int6
     // stage 0 landed (this wave's pieces), then everybody's
     WaitVm<(F_NST - 1) * PW>::go();
     __builtin_amdgcn_s_barrier();
+    if (aborted) {                                   // uniform over the grid: see GemmMap::abort_flag
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
     if (fm.stamps) st1 = __builtin_amdgcn_s_memtime();
     {
         const unsigned aa0 = a_base + rd0, ab0 = b_base + rd0;
@@ -684,17 +689,13 @@ static int launch_gemm_nt_fast(int64_t M, int64_t N, int64_t K, const void *A, i
                                double work = -1.0, int beta0 = 0, int ktri = 0)
 {
     constexpr int F_SMEM = FGeo<BN, BM>::SMEM;
-    static bool attr_done = false;
-    if (!attr_done) {
-        GPX_HIP(hipFuncSetAttribute((const void *)gemm_nt_fast_kernel<T, BN, TAG, BM>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, F_SMEM));
-        attr_done = true;
-    }
+    GPX_TRY(set_max_lds((const void *)gemm_nt_fast_kernel<T, BN, TAG, BM>, F_SMEM));
     GemmMap fm;
     if (map) {
         fm = *map;
     } else {
         fm.boff = 0; fm.cbase = 0; fm.nb = (int64_t)1 << 40; fm.pm1nb = 0; fm.brows = N;
+        fm.abort_flag = nullptr;
         fm.a = 0; fm.b = 0; fm.csh = 3;
         // lower-triangular result: skip the patch rows above the diagonal; with more than one patch
         // column the staircase (a = 1) drops one more patch row per column
@@ -821,7 +822,7 @@ int gemm_nt(int dtype, int64_t M, int64_t N, int64_t K, const void *A, int64_t l
 // ---------------------------------------------------------------------------
 int syrk_bc(int dtype, int64_t n, int64_t row_begin, void *Cloc, int64_t ldc, int64_t cl0, int64_t cl1,
             const void *Pb, int64_t ldp, int64_t k0, int64_t kb, int64_t nb, int P, int rank,
-            hipStream_t st)
+            hipStream_t st, const int *abort_flag)
 {
     const int64_t M = n - row_begin, Ncols = cl1 - cl0;
     if (M <= 0 || Ncols <= 0 || kb <= 0) return GPX_OK;
@@ -861,6 +862,7 @@ int syrk_bc(int dtype, int64_t n, int64_t row_begin, void *Cloc, int64_t ldc, in
         }
         fm.np = (int)np;
         fm.stamps = nullptr; fm.ablate = 0;
+        fm.abort_flag = abort_flag;
         if (fast_bm() == 128) {
             if (dtype == GPX_F64)
                 return launch_gemm_nt_fast<double, 128, 1, 128>(M, Ncols, kb, A, ldp, Pb, ldp, C, ldc, -1.0, GPX_LOWER,

@@ -14,6 +14,7 @@
 #include <vector>
 
 struct gpx_gp {
+    int device;        // the HIP device the handle lives on; every entry point makes it current
     int dtype, kernel, d, nparams;
     int64_t n, lda;
     void *x, *y, *A, *alpha, *t0, *t1;
@@ -119,6 +120,12 @@ int kmat(int dtype, int kernel, int member, const void *x1, int64_t n, const voi
 
 static int nparams_of(int kernel) { return kernel == GPX_KERNEL_PERIODIC ? 3 : 2; }
 
+// every gpx_gp_* entry: the handle's device becomes current for the duration of the call
+#define GP_ENTER(g)                                                          \
+    GPX_ARG((g) != nullptr, "gp is NULL");                                   \
+    gpx::DeviceGuard guard__((g)->device);                                   \
+    if (guard__.rc != GPX_OK) return guard__.rc
+
 }  // namespace gpx
 
 using namespace gpx;
@@ -137,6 +144,7 @@ int gpx_gp_create(gpx_gp_t **out, int dtype, int kernel, int64_t n, int d)
     gpx_gp *g = new gpx_gp();
     memset(g, 0, sizeof(*g));
     g->dtype = dtype; g->kernel = kernel; g->n = n; g->d = d;
+    if (hipGetDevice(&g->device) != hipSuccess) { (void)hipGetLastError(); g->device = 0; }
     g->nparams = nparams_of(kernel);
     g->lda = round_up(n, 16);
     const size_t es = esize(dtype);
@@ -171,6 +179,7 @@ int gpx_gp_create(gpx_gp_t **out, int dtype, int kernel, int64_t n, int d)
 int gpx_gp_destroy(gpx_gp_t *g)
 {
     if (!g) return GPX_OK;
+    gpx::DeviceGuard guard__(g->device);
     if (g->st) (void)hipStreamSynchronize(g->st);
     void *bufs[] = {g->x, g->y, g->A, g->alpha, g->t0, g->t1, g->scal};
     for (void *b : bufs) if (b) (void)hipFree(b);
@@ -182,6 +191,7 @@ int gpx_gp_destroy(gpx_gp_t *g)
 
 int gpx_gp_set_data(gpx_gp_t *g, const double *x, const double *y)
 {
+    GP_ENTER(g);
     GPX_ARG(g && x && y, "NULL argument");
     GPX_TRY(upload_f64(g->dtype, g->x, x, g->n * g->d, g->st));
     GPX_TRY(upload_f64(g->dtype, g->y, y, g->n, g->st));
@@ -191,16 +201,19 @@ int gpx_gp_set_data(gpx_gp_t *g, const double *x, const double *y)
 
 int gpx_gp_set_data_device(gpx_gp_t *g, const void *x_dev, const void *y_dev)
 {
+    GP_ENTER(g);
     GPX_ARG(g && x_dev && y_dev, "NULL argument");
     const size_t es = esize(g->dtype);
     GPX_HIP(hipMemcpyAsync(g->x, x_dev, (size_t)g->n * g->d * es, hipMemcpyDeviceToDevice, g->st));
     GPX_HIP(hipMemcpyAsync(g->y, y_dev, (size_t)g->n * es, hipMemcpyDeviceToDevice, g->st));
+    GPX_HIP(hipStreamSynchronize(g->st));      // the caller may free or overwrite the sources on return
     g->have_data = true; g->fitted = false;
     return GPX_OK;
 }
 
 int gpx_gp_set_params(gpx_gp_t *g, const double *params, double s)
 {
+    GP_ENTER(g);
     GPX_ARG(g && params, "NULL argument");
     GPX_ARG(s >= 0, "invalid value for s");                    // gp/gp.py:192-193
     for (int i = 0; i < g->nparams; ++i) g->params[i] = params[i];
@@ -211,6 +224,7 @@ int gpx_gp_set_params(gpx_gp_t *g, const double *params, double s)
 
 int gpx_gp_set_K(gpx_gp_t *g, const double *Kxx, int64_t ld)
 {
+    GP_ENTER(g);
     GPX_ARG(g && Kxx && ld >= g->n, "bad arguments");
     const int64_t n = g->n;
     if (g->dtype == GPX_F64) {
@@ -234,6 +248,7 @@ int gpx_gp_set_K(gpx_gp_t *g, const double *Kxx, int64_t ld)
 
 int gpx_gp_fit(gpx_gp_t *g, int *info)
 {
+    GP_ENTER(g);
     GPX_ARG(g, "gp is NULL");
     GPX_ARG(g->have_data && (g->have_params || g->have_K),
             "set_data and set_params (or set_K) must be called before fit");
@@ -269,6 +284,7 @@ int gpx_gp_fit(gpx_gp_t *g, int *info)
 
 static int gp_scalars(gpx_gp_t *g, double *logdet, double *yta, int *info)
 {
+    GP_ENTER(g);
     GPX_ARG(g && g->fitted, "gp is not fitted");
     double h[4];
     GPX_HIP(hipMemcpyAsync(h, g->scal, sizeof(h), hipMemcpyDeviceToHost, g->st));
@@ -307,6 +323,7 @@ int gpx_gp_info(gpx_gp_t *g, int *info)
 
 int gpx_gp_mean(gpx_gp_t *g, const double *xo, int64_t m, double *out)
 {
+    GP_ENTER(g);
     GPX_ARG(g && g->fitted, "gp is not fitted");
     GPX_ARG(m >= 0 && (m == 0 || (xo && out)), "bad arguments");
     if (m == 0) return GPX_OK;
@@ -322,6 +339,7 @@ int gpx_gp_mean(gpx_gp_t *g, const double *xo, int64_t m, double *out)
 
 int gpx_gp_cov(gpx_gp_t *g, const double *xo, int64_t m, double *out)
 {
+    GP_ENTER(g);
     GPX_ARG(g && g->fitted, "gp is not fitted");
     GPX_ARG(m >= 0 && (m == 0 || (xo && out)), "bad arguments");
     if (m == 0) return GPX_OK;
@@ -344,6 +362,7 @@ int gpx_gp_cov(gpx_gp_t *g, const double *xo, int64_t m, double *out)
 
 int gpx_gp_mean_from_K(gpx_gp_t *g, const double *Kxox, int64_t m, double *out)
 {
+    GP_ENTER(g);
     GPX_ARG(g && g->fitted, "gp is not fitted");
     GPX_ARG(m >= 0 && (m == 0 || (Kxox && out)), "bad arguments");
     if (m == 0) return GPX_OK;
@@ -366,6 +385,7 @@ int gpx_gp_mean_from_K(gpx_gp_t *g, const double *Kxox, int64_t m, double *out)
 
 int gpx_gp_cov_from_K(gpx_gp_t *g, const double *Kxox, const double *Kxoxo, int64_t m, double *out)
 {
+    GP_ENTER(g);
     GPX_ARG(g && g->fitted, "gp is not fitted");
     GPX_ARG(m >= 0 && (m == 0 || (Kxox && Kxoxo && out)), "bad arguments");
     if (m == 0) return GPX_OK;
@@ -392,6 +412,7 @@ int gpx_gp_cov_from_K(gpx_gp_t *g, const double *Kxox, const double *Kxoxo, int6
 
 int gpx_gp_get_Kxx(gpx_gp_t *g, double *out, int64_t ld)
 {
+    GP_ENTER(g);
     GPX_ARG(g && g->have_data && g->have_params && out && ld >= g->n, "bad arguments");
     const size_t es = esize(g->dtype);
     DevBuf K;
@@ -403,18 +424,21 @@ int gpx_gp_get_Kxx(gpx_gp_t *g, double *out, int64_t ld)
 
 int gpx_gp_get_Lxx(gpx_gp_t *g, double *out, int64_t ld)
 {
+    GP_ENTER(g);
     GPX_ARG(g && g->fitted && out && ld >= g->n, "bad arguments");
     return download_f64(g->dtype, out, ld, g->A, g->lda, g->n, g->n, 1, g->st);
 }
 
 int gpx_gp_get_alpha(gpx_gp_t *g, double *out)
 {
+    GP_ENTER(g);
     GPX_ARG(g && g->fitted && out, "bad arguments");
     return download_f64(g->dtype, out, 1, g->alpha, 1, g->n, 1, 0, g->st);
 }
 
 int gpx_gp_get_inv_Kxx(gpx_gp_t *g, double *out, int64_t ld)
 {
+    GP_ENTER(g);
     GPX_ARG(g && g->fitted && out && ld >= g->n, "bad arguments");
     const size_t es = esize(g->dtype);
     const int64_t n = g->n, lda = g->lda;
@@ -438,6 +462,7 @@ int gpx_gp_get_inv_Kxx(gpx_gp_t *g, double *out, int64_t ld)
 // reduces (alpha alpha^T - W) against the kernel derivatives evaluated on the fly.
 int gpx_gp_dloglh_dtheta(gpx_gp_t *g, double *out)
 {
+    GP_ENTER(g);
     GPX_ARG(g && g->fitted && out, "bad arguments");
     const size_t es = esize(g->dtype);
     const int64_t n = g->n, lda = g->lda;
@@ -476,6 +501,7 @@ int gpx_gp_dloglh_dtheta(gpx_gp_t *g, double *out)
 
 int gpx_gp_last_timing(gpx_gp_t *g, float *ms5)
 {
+    GP_ENTER(g);
     GPX_ARG(g && g->fitted && ms5, "bad arguments");
     GPX_HIP(hipEventSynchronize(g->ev[4]));
     for (int i = 0; i < 4; ++i) GPX_HIP(hipEventElapsedTime(&ms5[i], g->ev[i], g->ev[i + 1]));

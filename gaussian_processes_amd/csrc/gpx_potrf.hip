@@ -67,6 +67,11 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(T *__restrict__ blk, in
     __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x;
     const int tr = tid >> 4, tc = tid & 15;
+    // an earlier block already failed: the factor is garbage from there on, do not spend the chain on it
+    __shared__ int s_abort;
+    if (tid == 0) s_abort = *info;
+    __syncthreads();
+    if (s_abort != 0) return;
     T a[4][4];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -471,7 +476,7 @@ int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t
         for (int64_t k0 = 0; k0 < n; k0 += nb) {
             const int64_t kb = std::min(nb, n - k0), r = k0 + kb;
             GPX_TRY(potrf_panel(dtype, A, lda, n, k0, k0, kb, info_dev, st));
-            if (r < n) GPX_TRY(syrk_bc(dtype, n, r, A, lda, r, n, at(k0, k0), lda, k0, kb, nb, 1, 0, st));
+            if (r < n) GPX_TRY(syrk_bc(dtype, n, r, A, lda, r, n, at(k0, k0), lda, k0, kb, nb, 1, 0, st, info_dev));
         }
         return GPX_OK;
     }
@@ -500,7 +505,7 @@ int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t
         if (r >= n) break;
         const int64_t kb1 = std::min(nb, n - r);
         // block column k + 1 first, so that its panel can start ...
-        GPX_TRY(syrk_bc(dtype, n, r, A, lda, r, r + kb1, at(k0, k0), lda, k0, kb, nb, 1, 0, st));
+        GPX_TRY(syrk_bc(dtype, n, r, A, lda, r, r + kb1, at(k0, k0), lda, k0, kb, nb, 1, 0, st, info_dev));
         GPX_TRY(g_la.get(&e));
         GPX_HIP(hipEventRecord(e, st));
         GPX_HIP(hipStreamWaitEvent(q, e, 0));
@@ -509,7 +514,7 @@ int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t
         GPX_HIP(hipEventRecord(ep, q));
         // ... while the rest of the trailing matrix is updated underneath it
         if (r + kb1 < n)
-            GPX_TRY(syrk_bc(dtype, n, r, A, lda, r + kb1, n, at(k0, k0), lda, k0, kb, nb, 1, 0, st));
+            GPX_TRY(syrk_bc(dtype, n, r, A, lda, r + kb1, n, at(k0, k0), lda, k0, kb, nb, 1, 0, st, info_dev));
     }
     if (st != user) {
         GPX_TRY(g_la.get(&e));

@@ -1,6 +1,9 @@
 // gpx_runtime.hip -- device / memory / stream / event plumbing of the C ABI.
 #include "gpx_common.h"
 #include <stdarg.h>
+#include <mutex>
+#include <set>
+#include <utility>
 #include <vector>
 
 namespace gpx {
@@ -40,31 +43,65 @@ int ensure_device()
 }
 
 // ---- profiling registry -----------------------------------------------------
+// One registry for all host threads (mlii drives one handle per thread): every access is
+// under g_prof_mu, a scope ends the record it began (by index), and the registry is capped so a
+// forgotten gpx_prof_enable(1) cannot grow without bound.
 bool g_prof_on = false;
 struct ProfRec { int cls; double work; hipEvent_t a, b; };
 static std::vector<ProfRec> g_prof;
+static std::mutex g_prof_mu;
+static const size_t PROF_CAP = 1u << 20;
 
-void prof_begin(int cls, double work, hipStream_t st)
+int prof_begin(int cls, double work, hipStream_t st)
 {
     ProfRec r;
     r.cls = cls; r.work = work; r.a = nullptr; r.b = nullptr;
-    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        if (g_prof.size() >= PROF_CAP) return -1;
+    }
+    if (hipEventCreate(&r.a) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    if (hipEventCreate(&r.b) != hipSuccess) { (void)hipGetLastError(); (void)hipEventDestroy(r.a); return -1; }
     (void)hipEventRecord(r.a, st);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof.push_back(r);
+    return (int)g_prof.size() - 1;
 }
 
-void prof_end(hipStream_t st)
+void prof_end(int rec, hipStream_t st)
 {
-    if (!g_prof.empty() && g_prof.back().b) (void)hipEventRecord(g_prof.back().b, st);
+    hipEvent_t b = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        if (rec >= 0 && (size_t)rec < g_prof.size()) b = g_prof[rec].b;   // cleared meanwhile: nothing to end
+    }
+    if (b) (void)hipEventRecord(b, st);
 }
 
 static void prof_clear()
 {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto &r : g_prof) {
         if (r.a) (void)hipEventDestroy(r.a);
         if (r.b) (void)hipEventDestroy(r.b);
     }
     g_prof.clear();
+}
+
+// ---- per-(kernel, device) launch attributes -------------------------------------
+static std::mutex g_attr_mu;
+static std::set<std::pair<const void *, int>> g_attr_done;
+
+int set_max_lds(const void *fn, int bytes)
+{
+    int dev = 0;
+    GPX_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_attr_mu);
+    const auto key = std::make_pair(fn, dev);
+    if (g_attr_done.count(key)) return GPX_OK;
+    GPX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    g_attr_done.insert(key);
+    return GPX_OK;
 }
 
 }  // namespace gpx
@@ -270,6 +307,7 @@ int gpx_prof_read(int cls, double *launches, double *total_ms, double *total_wor
     GPX_TRY(ensure_device());
     GPX_HIP(hipDeviceSynchronize());
     double n = 0, ms = 0, w = 0;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto &r : g_prof) {
         if (r.cls != cls || !r.a || !r.b) continue;
         float t = 0.f;

@@ -113,9 +113,13 @@ class GP(object):
 
     # ---- state: exactly the reference's five entries (gp/gp.py:78-92) ----
     def __getstate__(self):
-        return {"K": self.K, "_x": self._x, "_y": self._y, "_s": self._s,
-                "_memoized": self._memoized,
-                "_gpx": {"dtype": self._dtype, "device": self._device}}
+        state = {"K": self.K, "_x": self._x, "_y": self._y, "_s": self._s,
+                 "_memoized": self._memoized}
+        # the two extensions ride along only when they are in use: a GP built the reference's way
+        # (float64, default device) pickles to exactly the reference's five keys
+        if self._dtype != _lib.F64 or self._device is not None:
+            state["_gpx"] = {"dtype": self._dtype, "device": self._device}
+        return state
 
     def __setstate__(self, state):
         self.K = state["K"]

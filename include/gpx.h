@@ -28,9 +28,12 @@
  *     stream and its event pool PER HOST THREAD.  gpx_d_potrf, gpx_d_potrf_panel,
  *     gpx_d_trsv_lower*, gpx_d_mean issued from one host thread must therefore
  *     not be in flight on two streams at once (synchronise before switching
- *     streams, or drive each stream from its own host thread); handles
- *     (gpx_gp_*) synchronise their stream before they return and are safe to
- *     use concurrently from different host threads.
+ *     streams, or drive each stream from its own host thread).  Handles
+ *     (gpx_gp_*) remember the device they were created on and make it current
+ *     for the duration of every call (the caller's current device is restored);
+ *     they synchronise their stream before they return -- the one exception is
+ *     gpx_gp_fit(gp, NULL), which only enqueues -- and different handles are
+ *     safe to use concurrently from different host threads.
  *   - "host" entry points (gpx_gaussian_c_*, gpx_periodic_c_*, gpx_gp_c_*,
  *     gpx_cholesky, gpx_cho_solve ...) take HOST pointers with the reference's
  *     exact argument meaning, run on the current device and return when the
@@ -237,7 +240,10 @@ int gpx_gp_create(gpx_gp_t **gp, int dtype, int kernel, int64_t n, int d);
 int gpx_gp_destroy(gpx_gp_t *gp);
 /* x: (n, d) HOST float64; y: (n,) HOST float64 (converted to dtype on upload) */
 int gpx_gp_set_data(gpx_gp_t *gp, const double *x, const double *y);
-/* same, from DEVICE buffers already in the handle's dtype */
+/* same, from DEVICE buffers (on the handle's device) already in the handle's dtype.  The
+ * copies run on the handle's own non-blocking stream: whatever produced x_dev / y_dev must
+ * have completed (synchronise the producing stream first).  Returns after the copies are
+ * done, so the sources may be freed or overwritten at once. */
 int gpx_gp_set_data_device(gpx_gp_t *gp, const void *x_dev, const void *y_dev);
 /* params = (h, w[, p]); s = noise standard deviation (gp/gp.py:190-197) */
 int gpx_gp_set_params(gpx_gp_t *gp, const double *params, double s);
@@ -245,9 +251,9 @@ int gpx_gp_set_params(gpx_gp_t *gp, const double *params, double s);
  * the host evaluates its own K(x, x) + s^2 I (gp/gp.py:263-266) and hands the
  * full (n, n) HOST float64 matrix over; gpx_gp_fit then skips the kernel build. */
 int gpx_gp_set_K(gpx_gp_t *gp, const double *Kxx, int64_t ld);
-/* kernel build (lower) -> potrf -> alpha -> logdet, y^T alpha.  Asynchronous on
- * the handle's stream; *info (HOST, may be NULL) is filled after a sync only
- * when non-NULL. */
+/* kernel build (lower) -> potrf -> alpha -> logdet, y^T alpha.  info != NULL: *info (HOST)
+ * is filled and the call returns after the fit has completed.  info == NULL: the fit is only
+ * ENQUEUED on the handle's stream (asynchronous); the next gpx_gp_* getter synchronises. */
 int gpx_gp_fit(gpx_gp_t *gp, int *info);
 /* log marginal likelihood with the reference's conventions (gp/gp.py:360-367,
  * gp_c.pyx:17-31): -inf when the factorisation failed or logdet < MIN. */

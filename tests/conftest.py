@@ -16,16 +16,16 @@ def pytest_configure(config):
 
 
 def pytest_sessionstart(session):
-    """A fresh checkout has no built artefacts (they are git-ignored): build the HIP library and the
-    oracle's C restatement once, exactly as __graft_entry__.build() does.  hipcc cross-compiles
-    without a GPU; if it is absent the tests that need the library fail loudly on their own."""
-    so = os.path.join(ROOT, "gaussian_processes_amd", "libgpx.so")
-    if not os.path.exists(so):
-        try:
-            import __graft_entry__
-            __graft_entry__.build()
-        except Exception as exc:       # report, do not hide: the dependent tests will fail with the real reason
-            sys.stderr.write("conftest: building libgpx.so failed: %r\n" % (exc,))
+    """Build the HIP library and the oracle's C restatement exactly as __graft_entry__.build() does.
+    hipcc cross-compiles without a GPU; if it is absent the tests that need the library fail loudly
+    on their own."""
+    # always: make's dependencies make it a no-op when the library is current, and an edited .hip file
+    # can never be tested against a stale libgpx.so (the library is git-ignored)
+    try:
+        import __graft_entry__
+        __graft_entry__.build()
+    except Exception as exc:           # report loudly; the dependent tests then fail with the real reason
+        sys.stderr.write("\n*** conftest: building libgpx.so / the oracle FAILED: %r ***\n" % (exc,))
 
 
 def load_golden(name):

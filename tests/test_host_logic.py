@@ -169,3 +169,48 @@ def test_nd_inputs_accepted():
     assert g._n == 10 and g._d == 3
     with pytest.raises(ValueError):
         gp.GP(gp.GaussianKernel(1, 1), X, np.zeros((10, 3)), s=1)
+
+
+# ---- bench.py as the driver calls it: `python bench.py --gpus P` must start P ranks itself ----
+def _run_bench(*argv):
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), env=env,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+
+
+def test_bench_self_launches_ranks_from_a_plain_invocation():
+    import json
+    r = _run_bench("--gpus", "2", "--launch-check")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout                      # exactly ONE JSON line on stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["launch_check"] is True and out["rank_sum"] == 3.0
+
+
+def test_bench_self_launch_propagates_a_rank_failure():
+    # without a GPU the ranks refuse to run (no CPU fallback): the launcher must exit non-zero
+    # and print no result line
+    from gaussian_processes_amd import _lib
+    if _lib.device_count() >= 1:
+        pytest.skip("a GPU is present: the ranks would run")
+    r = _run_bench("--gpus", "2", "--problem-n", "512", "--no-cpu-baseline")
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_pickled_state_has_exactly_the_reference_keys():
+    # gp/gp.py:78-92: K, _x, _y, _s, _memoized -- nothing else for a GP built the reference's way
+    g = make_gp()
+    assert sorted(g.__getstate__()) == ["K", "_memoized", "_s", "_x", "_y"]
+    g2 = pickle.loads(pickle.dumps(g))
+    assert g2._dtype == g._dtype and g2._device is None
+    # the opt-in extensions (fp32 device path, explicit device) survive a round trip
+    x, y = make_xy()
+    g32 = gp.GP(gp.GaussianKernel(1, 1), x, y, s=1, dtype="float32", device=0)
+    g3 = pickle.loads(pickle.dumps(g32))
+    assert g3._dtype == _lib.F32 and g3._device == 0
