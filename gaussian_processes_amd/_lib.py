@@ -102,6 +102,7 @@ _SIGNATURES = {
     "gpx_gp_get_alpha": (c_int, [c_void_p, c_double_p]),
     "gpx_gp_get_inv_Kxx": (c_int, [c_void_p, c_double_p, c_int64]),
     "gpx_gp_dloglh_dtheta": (c_int, [c_void_p, c_double_p]),
+    "gpx_gp_fit_batch": (c_int, [c_void_p, c_double_p, c_int64, c_double_p, c_int_p]),
     "gpx_gp_last_timing": (c_int, [c_void_p, POINTER(c_float)]),
     "gpx_gp_device_ptrs": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int64), POINTER(c_void_p),
                                    POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p)]),

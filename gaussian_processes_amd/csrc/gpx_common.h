@@ -83,28 +83,34 @@ struct KParams {
 };
 int make_kparams(int kernel, int member, const double *params, double diag_add, KParams *out);
 
+// Batched launches: `count` matrices of identical shape; element strides between consecutive
+// matrices for the A / B / C operands of a product (one stride for everything else).
+struct Batch { int count; int64_t sA, sB, sC; };
+
 // internal (non-ABI) helpers shared between translation units
 // C = beta * C + alpha * A * B^T with beta = 1 (default) or 0 (beta0 != 0: C is not read)
 int gemm_nt(int dtype, int64_t M, int64_t N, int64_t K, const void *A, int64_t lda, const void *B,
             int64_t ldb, void *C, int64_t ldc, double alpha, int tri, int64_t row0, int64_t col0,
-            hipStream_t st, int beta0 = 0, int ktri = 0);
+            hipStream_t st, int beta0 = 0, int ktri = 0, const Batch *bt = nullptr);
 // (ktri != 0: A == B is upper triangular in (row, k) and M == N == K -- the k-loop of tile row i skips k < i)
 // X[r, 0:jb] <- X[r, 0:jb] * Ljj^-T for rows r in [0, rows); Ljj = jb x jb lower block
 int trsm_rows(int dtype, void *X, int64_t ldx, int64_t rows, const void *Ljj, int64_t ldl, int jb,
-              hipStream_t st);
+              hipStream_t st, const Batch *bt = nullptr);   // bt: sA = stride of X, sB = stride of Ljj
 int syrk_bc(int dtype, int64_t n, int64_t row_begin, void *Cloc, int64_t ldc, int64_t cl0, int64_t cl1,
             const void *Pb, int64_t ldp, int64_t k0, int64_t kb, int64_t nb, int P, int rank,
-            hipStream_t st, const int *abort_flag = nullptr);
+            hipStream_t st, const int *abort_flag = nullptr, const Batch *bt = nullptr);
 // factor rows [r0, n) x columns [c0, c0 + kb) of A whose diagonal block sits at (r0, c0)
 int potrf_panel(int dtype, void *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int64_t kb,
-                int *info_dev, hipStream_t st);
-int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t st);
+                int *info_dev, hipStream_t st, const Batch *bt = nullptr);
+int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t st, const Batch *bt = nullptr);
 int trsv_lower(int dtype, const void *L, int64_t n, int64_t ldl, void *b, void *x, int transpose,
-               hipStream_t st);
+               hipStream_t st, const Batch *bt = nullptr);   // bt: sA = stride of L, sB = stride of b / x
 int trsm_right_lt(int dtype, const void *L, int64_t n, int64_t ldl, void *X, int64_t m, int64_t ldx,
                   hipStream_t st, int x_upper = 0);
-int logdet_chol(int dtype, const void *L, int64_t n, int64_t ldl, double *out_dev, hipStream_t st);
-int dot(int dtype, const void *a, const void *b, int64_t n, double *out_dev, hipStream_t st);
+int logdet_chol(int dtype, const void *L, int64_t n, int64_t ldl, double *out_dev, hipStream_t st, int count = 1,
+                int64_t sL = 0, int64_t so = 0);
+int dot(int dtype, const void *a, const void *b, int64_t n, double *out_dev, hipStream_t st, int count = 1,
+        int64_t sa = 0, int64_t sb = 0, int64_t so = 0);
 int tril(int dtype, void *A, int64_t n, int64_t lda, hipStream_t st);
 int dloglh_reduce(int dtype, int kernel, const void *x, int64_t n, int d, const double *params,
                   const void *alpha, const void *W, int64_t ldw, double *partial_dev, double *out4,

@@ -233,13 +233,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(int64_t M, int64_t N, i
                                                          const T *__restrict__ A, int64_t lda,
                                                          const T *__restrict__ B, int64_t ldb,
                                                          T *__restrict__ C, int64_t ldc, T alpha,
-                                                         int tri, int64_t row0, int64_t col0)
+                                                         int tri, int64_t row0, int64_t col0, Batch bt)
 {
     typedef typename MF<T>::acc_t acc_t;
     constexpr int EPK = MF<T>::EPK;
     constexpr int CH = MF<T>::CH;
     constexpr int SUB = EPK / 4;        // MFMA sub-steps per k-step; also elements per lane per row
 
+    A += (int64_t)blockIdx.z * bt.sA; B += (int64_t)blockIdx.z * bt.sB; C += (int64_t)blockIdx.z * bt.sC;
     const int64_t bm0 = (int64_t)blockIdx.y * GB_M;
     const int64_t bn0 = (int64_t)blockIdx.x * GB_N;
     if (tri == GPX_LOWER && col0 + bn0 > row0 + bm0 + GB_M - 1) return;
@@ -344,14 +345,14 @@ static double updated_elements(int64_t M, int64_t N, int tri, int64_t row0, int6
 template <typename T>
 int launch_gemm_nt(int64_t M, int64_t N, int64_t K, const void *A, int64_t lda, const void *B,
                    int64_t ldb, void *C, int64_t ldc, double alpha, int tri, int64_t row0,
-                   int64_t col0, hipStream_t st)
+                   int64_t col0, hipStream_t st, const Batch &bt)
 {
     if (M <= 0 || N <= 0 || K <= 0) return GPX_OK;
     GPX_TRY(set_max_lds((const void *)gemm_nt_kernel<T>, G_SMEM));
-    dim3 grid((unsigned)cdiv(N, GB_N), (unsigned)cdiv(M, GB_M)), block(256);
-    ProfScope prof(PC_GEMM_GENERIC, 2.0 * (double)K * updated_elements(M, N, tri, row0, col0), st);
+    dim3 grid((unsigned)cdiv(N, GB_N), (unsigned)cdiv(M, GB_M), (unsigned)bt.count), block(256);
+    ProfScope prof(PC_GEMM_GENERIC, 2.0 * (double)K * updated_elements(M, N, tri, row0, col0) * bt.count, st);
     hipLaunchKernelGGL((gemm_nt_kernel<T>), grid, block, G_SMEM, st, M, N, K, (const T *)A, lda,
-                       (const T *)B, ldb, (T *)C, ldc, (T)alpha, tri, row0, col0);
+                       (const T *)B, ldb, (T *)C, ldc, (T)alpha, tri, row0, col0, bt);
     GPX_LAUNCH_CHECK();
     return GPX_OK;
 }
@@ -427,6 +428,9 @@ struct GemmMap {
     // updates do, so every workgroup of a trailing update returns at once (a non-PD theta in an ML-II
     // sweep then costs the launches, not the flops)
     const int *abort_flag;
+    // batched launches (blockIdx.y = matrix index): element strides between consecutive matrices
+    int64_t sA, sB, sC;
+    int sflag;    // stride of abort_flag (one info word per matrix)
 };
 static unsigned long long *g_gemm_stamps = nullptr;
 
@@ -454,7 +458,8 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_nt_fast_kernel(int64_t M, int6
 
     // ---- block -> tile (XCD-aware patch order) ----
     // requested now, looked at after the prologue's DMA is under way (its latency hides there)
-    const int aborted = fm.abort_flag ? *fm.abort_flag : 0;
+    const int aborted = fm.abort_flag ? fm.abort_flag[(int64_t)blockIdx.y * fm.sflag] : 0;
+    A += (int64_t)blockIdx.y * fm.sA; B += (int64_t)blockIdx.y * fm.sB; C += (int64_t)blockIdx.y * fm.sC;
     const int bid = blockIdx.x;
     const int xcd = bid & 7, loc = bid >> 3;
     constexpr int RSH = BM == 256 ? 2 : 3;                          // log2 of the tile rows per patch
@@ -686,7 +691,7 @@ template <typename T, int BN = 128, int TAG = 0, int BM = 256>
 static int launch_gemm_nt_fast(int64_t M, int64_t N, int64_t K, const void *A, int64_t lda,
                                const void *B, int64_t ldb, void *C, int64_t ldc, double alpha, int tri,
                                int64_t row0, int64_t col0, hipStream_t st, const GemmMap *map = nullptr,
-                               double work = -1.0, int beta0 = 0, int ktri = 0)
+                               double work = -1.0, int beta0 = 0, int ktri = 0, const Batch *bt = nullptr)
 {
     constexpr int F_SMEM = FGeo<BN, BM>::SMEM;
     GPX_TRY(set_max_lds((const void *)gemm_nt_fast_kernel<T, BN, TAG, BM>, F_SMEM));
@@ -712,6 +717,8 @@ static int launch_gemm_nt_fast(int64_t M, int64_t N, int64_t K, const void *A, i
         }
         fm.np = (int)np;
     }
+    const int nbatch = bt ? bt->count : 1;
+    fm.sA = bt ? bt->sA : 0; fm.sB = bt ? bt->sB : 0; fm.sC = bt ? bt->sC : 0;
     fm.dbegin = 0x7fffffff; fm.ndiag = 0; fm.bdiag = 0;
     fm.ktri = (ktri && M == N && N == K) ? 1 : 0;
     int64_t dblocks = 0;
@@ -751,8 +758,8 @@ static int launch_gemm_nt_fast(int64_t M, int64_t N, int64_t K, const void *A, i
     if (dblocks) fm.dbegin = (int)ablocks;
     const int64_t blocks = ablocks + dblocks;
     ProfScope prof(TAG == 1 ? PC_GEMM : (BN == 128 ? PC_GEMM_PANEL : PC_GEMM_SKINNY),
-                   work >= 0 ? work : 2.0 * (double)K * updated_elements(M, N, tri, row0, col0), st);
-    hipLaunchKernelGGL((gemm_nt_fast_kernel<T, BN, TAG, BM>), dim3((unsigned)blocks), dim3(BM * 2), F_SMEM, st, M, N, K,
+                   (work >= 0 ? work : 2.0 * (double)K * updated_elements(M, N, tri, row0, col0)) * nbatch, st);
+    hipLaunchKernelGGL((gemm_nt_fast_kernel<T, BN, TAG, BM>), dim3((unsigned)blocks, (unsigned)nbatch), dim3(BM * 2), F_SMEM, st, M, N, K,
                        (const T *)A, lda, (const T *)B, ldb, (T *)C, ldc, (T)alpha, tri, row0, col0, fm, beta0);
     GPX_LAUNCH_CHECK();
     return GPX_OK;
@@ -769,7 +776,7 @@ static int fast_bm()
 
 int gemm_nt(int dtype, int64_t M, int64_t N, int64_t K, const void *A, int64_t lda, const void *B,
             int64_t ldb, void *C, int64_t ldc, double alpha, int tri, int64_t row0, int64_t col0,
-            hipStream_t st, int beta0, int ktri)
+            hipStream_t st, int beta0, int ktri, const Batch *bt)
 {
     if (M <= 0 || N <= 0 || K <= 0) return GPX_OK;
     static const bool no_fast = getenv("GPX_GEMM_NO_FAST") != nullptr;
@@ -780,34 +787,35 @@ int gemm_nt(int dtype, int64_t M, int64_t N, int64_t K, const void *A, int64_t l
         if (N <= 64 && fast_bm() == 128) {
             if (dtype == GPX_F64)
                 return launch_gemm_nt_fast<double, 64, 0, 128>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0, col0,
-                                                               st, nullptr, -1.0, beta0);
+                                                               st, nullptr, -1.0, beta0, 0, bt);
             return launch_gemm_nt_fast<float, 64, 0, 128>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0, col0, st,
-                                                          nullptr, -1.0, beta0);
+                                                          nullptr, -1.0, beta0, 0, bt);
         }
         if (N <= 64) {
             if (dtype == GPX_F64)
                 return launch_gemm_nt_fast<double, 64>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0, col0,
-                                                       st, nullptr, -1.0, beta0);
+                                                       st, nullptr, -1.0, beta0, 0, bt);
             return launch_gemm_nt_fast<float, 64>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0, col0, st,
-                                                  nullptr, -1.0, beta0);
+                                                  nullptr, -1.0, beta0, 0, bt);
         }
         if (fast_bm() == 128) {
             if (dtype == GPX_F64)
                 return launch_gemm_nt_fast<double, 128, 0, 128>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0,
-                                                                col0, st, nullptr, -1.0, beta0, ktri);
+                                                                col0, st, nullptr, -1.0, beta0, ktri, bt);
             return launch_gemm_nt_fast<float, 128, 0, 128>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0, col0,
-                                                           st, nullptr, -1.0, beta0, ktri);
+                                                           st, nullptr, -1.0, beta0, ktri, bt);
         }
         if (dtype == GPX_F64)
             return launch_gemm_nt_fast<double>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0, col0, st,
-                                               nullptr, -1.0, beta0);
+                                               nullptr, -1.0, beta0, 0, bt);
         return launch_gemm_nt_fast<float>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0, col0, st, nullptr,
-                                          -1.0, beta0);
+                                          -1.0, beta0, 0, bt);
     }
     if (beta0) { set_error("gemm_nt: beta = 0 needs the aligned fast path"); return GPX_ERR_UNSUPPORTED; }
+    Batch one; one.count = 1; one.sA = one.sB = one.sC = 0;
     if (dtype == GPX_F64)
-        return launch_gemm_nt<double>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0, col0, st);
-    return launch_gemm_nt<float>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0, col0, st);
+        return launch_gemm_nt<double>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0, col0, st, bt ? *bt : one);
+    return launch_gemm_nt<float>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0, col0, st, bt ? *bt : one);
 }
 
 
@@ -822,7 +830,7 @@ int gemm_nt(int dtype, int64_t M, int64_t N, int64_t K, const void *A, int64_t l
 // ---------------------------------------------------------------------------
 int syrk_bc(int dtype, int64_t n, int64_t row_begin, void *Cloc, int64_t ldc, int64_t cl0, int64_t cl1,
             const void *Pb, int64_t ldp, int64_t k0, int64_t kb, int64_t nb, int P, int rank,
-            hipStream_t st, const int *abort_flag)
+            hipStream_t st, const int *abort_flag, const Batch *bt)
 {
     const int64_t M = n - row_begin, Ncols = cl1 - cl0;
     if (M <= 0 || Ncols <= 0 || kb <= 0) return GPX_OK;
@@ -862,19 +870,19 @@ int syrk_bc(int dtype, int64_t n, int64_t row_begin, void *Cloc, int64_t ldc, in
         }
         fm.np = (int)np;
         fm.stamps = nullptr; fm.ablate = 0;
-        fm.abort_flag = abort_flag;
+        fm.abort_flag = abort_flag; fm.sflag = bt ? 1 : 0;
         if (fast_bm() == 128) {
             if (dtype == GPX_F64)
                 return launch_gemm_nt_fast<double, 128, 1, 128>(M, Ncols, kb, A, ldp, Pb, ldp, C, ldc, -1.0, GPX_LOWER,
-                                                                row_begin, cl0 + (int64_t)rank * nb, st, &fm, work);
+                                                                row_begin, cl0 + (int64_t)rank * nb, st, &fm, work, 0, 0, bt);
             return launch_gemm_nt_fast<float, 128, 1, 128>(M, Ncols, kb, A, ldp, Pb, ldp, C, ldc, -1.0, GPX_LOWER,
-                                                           row_begin, cl0 + (int64_t)rank * nb, st, &fm, work);
+                                                           row_begin, cl0 + (int64_t)rank * nb, st, &fm, work, 0, 0, bt);
         }
         if (dtype == GPX_F64)
             return launch_gemm_nt_fast<double, 128, 1>(M, Ncols, kb, A, ldp, Pb, ldp, C, ldc, -1.0, GPX_LOWER,
-                                                       row_begin, cl0 + (int64_t)rank * nb, st, &fm, work);
+                                                       row_begin, cl0 + (int64_t)rank * nb, st, &fm, work, 0, 0, bt);
         return launch_gemm_nt_fast<float, 128, 1>(M, Ncols, kb, A, ldp, Pb, ldp, C, ldc, -1.0, GPX_LOWER,
-                                                  row_begin, cl0 + (int64_t)rank * nb, st, &fm, work);
+                                                  row_begin, cl0 + (int64_t)rank * nb, st, &fm, work, 0, 0, bt);
     }
     // generic route: one launch per local block column
     for (int64_t c = cl0; c < cl1;) {
@@ -883,7 +891,7 @@ int syrk_bc(int dtype, int64_t n, int64_t row_begin, void *Cloc, int64_t ldc, in
         if (rb < n)
             GPX_TRY(gemm_nt(dtype, n - rb, w, kb, (const char *)Pb + (rb - k0) * ldp * es, ldp,
                             (const char *)Pb + (g - k0) * ldp * es, ldp,
-                            (char *)Cloc + (rb * ldc + c) * es, ldc, -1.0, GPX_LOWER, rb, g, st));
+                            (char *)Cloc + (rb * ldc + c) * es, ldc, -1.0, GPX_LOWER, rb, g, st, 0, 0, bt));
         c += w;
     }
     return GPX_OK;

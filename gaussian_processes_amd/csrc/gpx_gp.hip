@@ -11,6 +11,7 @@
 //   t0,t1  (n,)    solve scratch
 //   scal   3 doubles (logdet, y^T alpha, spare) + 1 int (potrf info)
 #include "gpx_common.h"
+#include <cmath>
 #include <vector>
 
 struct gpx_gp {
@@ -496,6 +497,77 @@ int gpx_gp_dloglh_dtheta(gpx_gp_t *g, double *out)
     GPX_HIP(hipStreamSynchronize(g->st));
     for (int i = 0; i < g->nparams; ++i) out[i] = 0.5 * p4[i];
     out[g->nparams] = g->s * (ata - p4[3]);            // dK/ds = 2 s I  (gp_c.pyx:46)
+    return GPX_OK;
+}
+
+// Batched ML-II step (BASELINE config 5; the reference's inner step "set params -> read log_lh",
+// gp/gp.py:216-223,337-367, for a whole table of restarts): the kernel matrices of up to `B` parameter
+// rows live in HBM side by side and are factored in LOCK-STEP -- every launch of the factorisation and
+// of the solves covers all of them (grid dimension y / x = matrix index), so the chain of small
+// dependent launches that bounds ONE n = 8192 factorisation is paid once per batch and the chip stays
+// filled by the trailing updates of all matrices.  Chunked when B matrices do not fit in free HBM.
+int gpx_gp_fit_batch(gpx_gp_t *g, const double *thetas, int64_t B, double *log_lh, int *info)
+{
+    GP_ENTER(g);
+    GPX_ARG(g->have_data, "set_data must be called before fit_batch");
+    GPX_ARG(B >= 0 && (B == 0 || (thetas && log_lh)), "bad arguments");
+    if (B == 0) return GPX_OK;
+    const int64_t n = g->n, lda = g->lda;
+    const size_t es = esize(g->dtype);
+    const int np = g->nparams;
+    const size_t per = (size_t)n * lda * es;
+    size_t freeb = 0, totalb = 0;
+    GPX_HIP(hipMemGetInfo(&freeb, &totalb));
+    int64_t Bc = (int64_t)((double)freeb * 0.85 / (double)(per + 4 * (size_t)n * es + 64));
+    if (const char *env = getenv("GPX_BATCH_MAX")) Bc = std::min<int64_t>(Bc, std::max<int64_t>(1, atoll(env)));
+    Bc = std::max<int64_t>(1, std::min<int64_t>(Bc, B));
+    if ((double)per > (double)freeb * 0.85) { set_error("fit_batch: not even one more n x n matrix fits in HBM"); return GPX_ERR_NOMEM; }
+    DevBuf Ab, t0, t1, al, sc, inf;
+    GPX_TRY(Ab.alloc((size_t)Bc * per));
+    GPX_TRY(t0.alloc((size_t)Bc * n * es));
+    GPX_TRY(t1.alloc((size_t)Bc * n * es));
+    GPX_TRY(al.alloc((size_t)Bc * n * es));
+    GPX_TRY(sc.alloc((size_t)Bc * 2 * sizeof(double)));
+    GPX_TRY(inf.alloc((size_t)Bc * sizeof(int)));
+    hipStream_t st = g->st;
+    const int64_t sM = n * lda;
+    std::vector<double> hs((size_t)Bc * 2);
+    std::vector<int> hi((size_t)Bc), valid((size_t)Bc);
+    const double eps = 2.220446049250313e-16;            // gp/kernels/gaussian.py:62-69: parameter < EPS is invalid
+    for (int64_t b0 = 0; b0 < B; b0 += Bc) {
+        const int cnt = (int)std::min<int64_t>(Bc, B - b0);
+        for (int i = 0; i < cnt; ++i) {
+            const double *th = thetas + (b0 + i) * (np + 1);
+            bool ok = th[np] >= 0 && std::isfinite(th[np]);
+            for (int k = 0; k < np; ++k) ok = ok && std::isfinite(th[k]) && !(th[k] < eps);
+            valid[i] = ok;
+            const double safe[3] = {1.0, 1.0, 1.0};      // an invalid row still takes part in the lock-step
+            const double *prm = ok ? th : safe;
+            const double s = ok ? th[np] : 1.0;
+            GPX_TRY(kmat(g->dtype, g->kernel, GPX_K, g->x, n, g->x, n, g->d, prm, s * s, GPX_LOWER,
+                         (char *)Ab.p + (size_t)i * per, lda, st));
+            GPX_HIP(hipMemcpyAsync((char *)t0.p + (size_t)i * n * es, g->y, (size_t)n * es, hipMemcpyDeviceToDevice, st));
+        }
+        Batch bm; bm.count = cnt; bm.sA = bm.sB = bm.sC = sM;
+        GPX_TRY(potrf(g->dtype, Ab.p, n, lda, (int *)inf.p, st, cnt > 1 ? &bm : nullptr));
+        Batch bs; bs.count = cnt; bs.sA = sM; bs.sB = n; bs.sC = 0;
+        GPX_TRY(trsv_lower(g->dtype, Ab.p, n, lda, t0.p, t1.p, 0, st, &bs));
+        GPX_TRY(trsv_lower(g->dtype, Ab.p, n, lda, t1.p, al.p, 1, st, &bs));
+        GPX_TRY(logdet_chol(g->dtype, Ab.p, n, lda, (double *)sc.p, st, cnt, sM, 2));
+        GPX_TRY(dot(g->dtype, g->y, al.p, n, (double *)sc.p + 1, st, cnt, 0, n, 2));
+        GPX_HIP(hipMemcpyAsync(hs.data(), sc.p, (size_t)cnt * 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+        GPX_HIP(hipMemcpyAsync(hi.data(), inf.p, (size_t)cnt * sizeof(int), hipMemcpyDeviceToHost, st));
+        GPX_HIP(hipStreamSynchronize(st));
+        for (int i = 0; i < cnt; ++i) {
+            const double logdet = hs[2 * i], yta = hs[2 * i + 1];
+            double v;
+            if (!valid[i]) v = NAN;                               // the reference raises ValueError for this row
+            else if (hi[i] != 0 || !(logdet >= GPX_MIN_LOG)) v = -INFINITY;     // gp/gp.py:362-365, gp_c.pyx:22-29
+            else v = -0.5 * yta - 0.5 * logdet - 0.5 * (double)n * log(2 * M_PI);
+            log_lh[b0 + i] = v;
+            if (info) info[b0 + i] = valid[i] ? hi[i] : -1;
+        }
+    }
     return GPX_OK;
 }
 

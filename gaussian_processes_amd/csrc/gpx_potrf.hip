@@ -55,8 +55,13 @@ __device__ __forceinline__ float fast_rsqrt(float p)
 
 template <typename T, bool INV>
 __global__ __launch_bounds__(256) void potrf_diag_kernel(T *__restrict__ blk, int64_t lda, int64_t j0,
-                                                         int jb, int *__restrict__ info, T *__restrict__ inv)
+                                                         int jb, int *__restrict__ info, T *__restrict__ inv,
+                                                         int64_t sblk)
 {
+    // batched launches: workgroup b factors the block of matrix b (stride sblk), own info word and inverse
+    blk += (int64_t)blockIdx.x * sblk;
+    info += blockIdx.x;
+    if (INV) inv += (int64_t)blockIdx.x * (IB * IB);
     // blk: the jb x jb diagonal block; j0: its global (0-based) index, for `info`
     __shared__ T sD[4][4];            // factored diagonal tile of the step (lower part)
     __shared__ T sR[4];               // its reciprocal pivots
@@ -202,8 +207,11 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(T *__restrict__ blk, in
 // Forward substitution along the row: x_c = (a_c - sum_{t<c} x_t L[c,t]) / L[c,c].
 template <typename T, bool FULL64>
 __global__ __launch_bounds__(256) void trsm_rows_kernel(T *__restrict__ X, int64_t ldx, int64_t rows,
-                                                        const T *__restrict__ Ljj, int64_t ldl, int jb)
+                                                        const T *__restrict__ Ljj, int64_t ldl, int jb,
+                                                        int64_t sX, int64_t sLjj)
 {
+    X += (int64_t)blockIdx.y * sX;
+    Ljj += (int64_t)blockIdx.y * sLjj;
     __shared__ T sL[IB * IBP];
     const int tid = threadIdx.x;
     for (int idx = tid; idx < jb * jb; idx += 256) {
@@ -248,27 +256,28 @@ __global__ __launch_bounds__(256) void trsm_rows_kernel(T *__restrict__ X, int64
 
 template <typename T>
 static int launch_trsm_rows(void *X, int64_t ldx, int64_t rows, const void *Ljj, int64_t ldl, int jb,
-                            hipStream_t st)
+                            hipStream_t st, const Batch *bt)
 {
     if (rows <= 0 || jb <= 0) return GPX_OK;
-    dim3 grid((unsigned)cdiv(rows, 256)), block(256);
+    dim3 grid((unsigned)cdiv(rows, 256), (unsigned)(bt ? bt->count : 1)), block(256);
+    const int64_t sX = bt ? bt->sA : 0, sL = bt ? bt->sB : 0;
     const bool vec_ok = (jb == IB) && (ldx % (16 / (int64_t)sizeof(T)) == 0) && (((uintptr_t)X) % 16 == 0);
-    ProfScope prof(PC_TRSM_ROWS, (double)rows * jb * jb, st);
+    ProfScope prof(PC_TRSM_ROWS, (double)rows * jb * jb * grid.y, st);
     if (vec_ok)
         hipLaunchKernelGGL((trsm_rows_kernel<T, true>), grid, block, 0, st, (T *)X, ldx, rows,
-                           (const T *)Ljj, ldl, jb);
+                           (const T *)Ljj, ldl, jb, sX, sL);
     else
         hipLaunchKernelGGL((trsm_rows_kernel<T, false>), grid, block, 0, st, (T *)X, ldx, rows,
-                           (const T *)Ljj, ldl, jb);
+                           (const T *)Ljj, ldl, jb, sX, sL);
     GPX_LAUNCH_CHECK();
     return GPX_OK;
 }
 
 int trsm_rows(int dtype, void *X, int64_t ldx, int64_t rows, const void *Ljj, int64_t ldl, int jb,
-              hipStream_t st)
+              hipStream_t st, const Batch *bt)
 {
-    if (dtype == GPX_F64) return launch_trsm_rows<double>(X, ldx, rows, Ljj, ldl, jb, st);
-    return launch_trsm_rows<float>(X, ldx, rows, Ljj, ldl, jb, st);
+    if (dtype == GPX_F64) return launch_trsm_rows<double>(X, ldx, rows, Ljj, ldl, jb, st, bt);
+    return launch_trsm_rows<float>(X, ldx, rows, Ljj, ldl, jb, st, bt);
 }
 
 template <typename T>
@@ -332,8 +341,10 @@ static int leaf_scratch(size_t bytes, void **out)
 // row substitution below it.
 template <typename T>
 static int potrf_panel_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int64_t kb, int *info_dev,
-                         hipStream_t st, int dtype)
+                         hipStream_t st, int dtype, const Batch *bt)
 {
+    const int nbatch = bt ? bt->count : 1;
+    const int64_t sM = bt ? bt->sA : 0;              // stride between the matrices of a batch
     if (kb <= IB) {
         const int jb = (int)kb;
         T *D = A + r0 * lda + c0;
@@ -348,41 +359,44 @@ static int potrf_panel_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, i
         T *inv = nullptr;
         if (via_inverse) {
             void *p = nullptr;
-            GPX_TRY(leaf_scratch(IB * IB * sizeof(T), &p));
+            GPX_TRY(leaf_scratch((size_t)nbatch * IB * IB * sizeof(T), &p));
             inv = (T *)p;
         }
         {
-            ProfScope prof(PC_POTRF_DIAG, (double)jb * jb * jb / 3.0, st);
+            ProfScope prof(PC_POTRF_DIAG, (double)jb * jb * jb / 3.0 * nbatch, st);
             if (inv)
-                hipLaunchKernelGGL((potrf_diag_kernel<T, true>), dim3(1), dim3(256), 0, st, D, lda, r0, jb, info_dev,
-                                   inv);
+                hipLaunchKernelGGL((potrf_diag_kernel<T, true>), dim3(nbatch), dim3(256), 0, st, D, lda, r0, jb,
+                                   info_dev, inv, sM);
             else
-                hipLaunchKernelGGL((potrf_diag_kernel<T, false>), dim3(1), dim3(256), 0, st, D, lda, r0, jb,
-                                   info_dev, inv);
+                hipLaunchKernelGGL((potrf_diag_kernel<T, false>), dim3(nbatch), dim3(256), 0, st, D, lda, r0, jb,
+                                   info_dev, inv, sM);
         }
         GPX_LAUNCH_CHECK();
         if (via_inverse) {
             // rows below: X <- X * inv(L_jj)^T, in place (each tile reads all 64 columns of its own
             // rows before its epilogue stores them; no other tile touches those rows)
             T *Xb = A + (r0 + jb) * lda + c0;
-            GPX_TRY(gemm_nt(dtype, below, jb, jb, Xb, lda, inv, IB, Xb, lda, 1.0, GPX_FULL, 0, 0, st, 1));
+            Batch bi; bi.count = nbatch; bi.sA = sM; bi.sB = IB * IB; bi.sC = sM;
+            GPX_TRY(gemm_nt(dtype, below, jb, jb, Xb, lda, inv, IB, Xb, lda, 1.0, GPX_FULL, 0, 0, st, 1, 0,
+                            bt ? &bi : nullptr));
         } else if (below > 0) {
-            GPX_TRY(trsm_rows(dtype, A + (r0 + jb) * lda + c0, lda, below, D, lda, jb, st));
+            Batch br; br.count = nbatch; br.sA = sM; br.sB = sM; br.sC = 0;
+            GPX_TRY(trsm_rows(dtype, A + (r0 + jb) * lda + c0, lda, below, D, lda, jb, st, bt ? &br : nullptr));
         }
         return GPX_OK;
     }
     const int64_t h = ((kb / IB + 1) / 2) * IB;          // left half, a multiple of 64
-    GPX_TRY(potrf_panel_t<T>(A, lda, n, r0, c0, h, info_dev, st, dtype));
+    GPX_TRY(potrf_panel_t<T>(A, lda, n, r0, c0, h, info_dev, st, dtype, bt));
     T *R = A + (r0 + h) * lda + c0;                       // rows below the left half's diagonal block
-    GPX_TRY(gemm_nt(dtype, n - (r0 + h), kb - h, h, R, lda, R, lda, R + h, lda, -1.0, GPX_LOWER, 0, 0, st));
-    return potrf_panel_t<T>(A, lda, n, r0 + h, c0 + h, kb - h, info_dev, st, dtype);
+    GPX_TRY(gemm_nt(dtype, n - (r0 + h), kb - h, h, R, lda, R, lda, R + h, lda, -1.0, GPX_LOWER, 0, 0, st, 0, 0, bt));
+    return potrf_panel_t<T>(A, lda, n, r0 + h, c0 + h, kb - h, info_dev, st, dtype, bt);
 }
 
 int potrf_panel(int dtype, void *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int64_t kb,
-                int *info_dev, hipStream_t st)
+                int *info_dev, hipStream_t st, const Batch *bt)
 {
-    if (dtype == GPX_F64) return potrf_panel_t<double>((double *)A, lda, n, r0, c0, kb, info_dev, st, dtype);
-    return potrf_panel_t<float>((float *)A, lda, n, r0, c0, kb, info_dev, st, dtype);
+    if (dtype == GPX_F64) return potrf_panel_t<double>((double *)A, lda, n, r0, c0, kb, info_dev, st, dtype, bt);
+    return potrf_panel_t<float>((float *)A, lda, n, r0, c0, kb, info_dev, st, dtype, bt);
 }
 
 // side stream + event pool for the look-ahead (one set per host thread and device)
@@ -463,20 +477,22 @@ static int reserve_cus(int64_t n)
 // Right-looking blocked Cholesky with one-panel look-ahead: while the main stream
 // applies panel k to the block columns beyond k + 1, the side stream already
 // factors panel k + 1 (whose block column was updated first).
-int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t st)
+// bt != null: bt->count matrices sA elements apart are factored in lock-step (every launch covers all of
+// them; info_dev then holds one word per matrix).
+int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t st, const Batch *bt)
 {
-    GPX_HIP(hipMemsetAsync(info_dev, 0, sizeof(int), st));
+    GPX_HIP(hipMemsetAsync(info_dev, 0, sizeof(int) * (bt ? bt->count : 1), st));
     const int64_t nb = outer_block(n);
     const int64_t nblk = cdiv(n, nb);
     const size_t es = esize(dtype);
     static const bool no_la = getenv("GPX_POTRF_NO_LOOKAHEAD") != nullptr;
-    if (nblk <= 1) return potrf_panel(dtype, A, lda, n, 0, 0, n, info_dev, st);
+    if (nblk <= 1) return potrf_panel(dtype, A, lda, n, 0, 0, n, info_dev, st, bt);
     auto at = [&](int64_t r, int64_t c) { return (char *)A + (r * lda + c) * es; };
     if (no_la) {
         for (int64_t k0 = 0; k0 < n; k0 += nb) {
             const int64_t kb = std::min(nb, n - k0), r = k0 + kb;
-            GPX_TRY(potrf_panel(dtype, A, lda, n, k0, k0, kb, info_dev, st));
-            if (r < n) GPX_TRY(syrk_bc(dtype, n, r, A, lda, r, n, at(k0, k0), lda, k0, kb, nb, 1, 0, st, info_dev));
+            GPX_TRY(potrf_panel(dtype, A, lda, n, k0, k0, kb, info_dev, st, bt));
+            if (r < n) GPX_TRY(syrk_bc(dtype, n, r, A, lda, r, n, at(k0, k0), lda, k0, kb, nb, 1, 0, st, info_dev, bt));
         }
         return GPX_OK;
     }
@@ -487,7 +503,7 @@ int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t
     GPX_HIP(hipEventRecord(e, st));
     GPX_HIP(hipStreamWaitEvent(q, e, 0));
     hipStream_t user = st;
-    const int reserve = reserve_cus(n);
+    const int reserve = bt ? 0 : reserve_cus(n);     // a batch fills the chip: nothing to reserve
     if (reserve > 0) {
         hipStream_t masked = nullptr;
         GPX_TRY(trailing_stream(reserve, &masked));             // the updates go to the masked stream
@@ -496,7 +512,7 @@ int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t
             GPX_HIP(hipStreamWaitEvent(st, e, 0));
         }
     }
-    GPX_TRY(potrf_panel(dtype, A, lda, n, 0, 0, std::min(nb, n), info_dev, q));
+    GPX_TRY(potrf_panel(dtype, A, lda, n, 0, 0, std::min(nb, n), info_dev, q, bt));
     GPX_TRY(g_la.get(&ep));
     GPX_HIP(hipEventRecord(ep, q));
     for (int64_t k0 = 0; k0 < n; k0 += nb) {
@@ -505,16 +521,16 @@ int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t
         if (r >= n) break;
         const int64_t kb1 = std::min(nb, n - r);
         // block column k + 1 first, so that its panel can start ...
-        GPX_TRY(syrk_bc(dtype, n, r, A, lda, r, r + kb1, at(k0, k0), lda, k0, kb, nb, 1, 0, st, info_dev));
+        GPX_TRY(syrk_bc(dtype, n, r, A, lda, r, r + kb1, at(k0, k0), lda, k0, kb, nb, 1, 0, st, info_dev, bt));
         GPX_TRY(g_la.get(&e));
         GPX_HIP(hipEventRecord(e, st));
         GPX_HIP(hipStreamWaitEvent(q, e, 0));
-        GPX_TRY(potrf_panel(dtype, A, lda, n, r, r, kb1, info_dev, q));
+        GPX_TRY(potrf_panel(dtype, A, lda, n, r, r, kb1, info_dev, q, bt));
         GPX_TRY(g_la.get(&ep));
         GPX_HIP(hipEventRecord(ep, q));
         // ... while the rest of the trailing matrix is updated underneath it
         if (r + kb1 < n)
-            GPX_TRY(syrk_bc(dtype, n, r, A, lda, r + kb1, n, at(k0, k0), lda, k0, kb, nb, 1, 0, st, info_dev));
+            GPX_TRY(syrk_bc(dtype, n, r, A, lda, r + kb1, n, at(k0, k0), lda, k0, kb, nb, 1, 0, st, info_dev, bt));
     }
     if (st != user) {
         GPX_TRY(g_la.get(&e));

@@ -25,8 +25,10 @@ constexpr int SBP = SB + 1;
 // (a = X^T v).
 template <typename T, bool FWD>
 __global__ __launch_bounds__(64) void trinv64_kernel(const T *__restrict__ L, int64_t ldl, int64_t ncols,
-                                                     T *__restrict__ Linv)
+                                                     T *__restrict__ Linv, int64_t bsL, int64_t bsLinv)
 {
+    L += (int64_t)blockIdx.y * bsL;                  // batched: matrix blockIdx.y
+    Linv += (int64_t)blockIdx.y * bsLinv;
     __shared__ T sL[SB * SBP];
     __shared__ T sX[SB * SBP];
     const int c = threadIdx.x;
@@ -205,8 +207,11 @@ template <typename T>
 __global__ __launch_bounds__(TBT) void trsv_fwd_fused(const T *__restrict__ L, int64_t ldl,
                                                       const T *__restrict__ Linv, T *__restrict__ b,
                                                       T *__restrict__ x, int64_t n, int64_t k0, int jb,
-                                                      int64_t p0, int pjb, int64_t far0, int aligned_i, int ablate)
+                                                      int64_t p0, int pjb, int64_t far0, int aligned_i, int ablate,
+                                                      int64_t bsL, int64_t bsLinv, int64_t bsv)
 {
+    L += (int64_t)blockIdx.y * bsL; Linv += (int64_t)blockIdx.y * bsLinv;    // batched: system blockIdx.y
+    b += (int64_t)blockIdx.y * bsv; x += (int64_t)blockIdx.y * bsv;
     __shared__ T szp[TB + 2];       // far workgroups: solution of block p, zero padded
     __shared__ T sv[TB];            // workgroup 0: right-hand side of the block being solved
     __shared__ T szb[TB];           // workgroup 0: solution of the block so far
@@ -302,8 +307,11 @@ template <typename T, int CW>
 __global__ __launch_bounds__(TBT) void trsv_bwd_fused(const T *__restrict__ L, int64_t ldl,
                                                       const T *__restrict__ Linv, T *__restrict__ b,
                                                       T *__restrict__ x, int64_t k0, int jb, int64_t q0,
-                                                      int qjb, int64_t c0, int64_t c1, int aligned_i, int ablate)
+                                                      int qjb, int64_t c0, int64_t c1, int aligned_i, int ablate,
+                                                      int64_t bsL, int64_t bsLinv, int64_t bsv)
 {
+    L += (int64_t)blockIdx.y * bsL; Linv += (int64_t)blockIdx.y * bsLinv;
+    b += (int64_t)blockIdx.y * bsv; x += (int64_t)blockIdx.y * bsv;
     __shared__ T sa[TB];            // far workgroups: solution of block q
     __shared__ T sv[TB];
     __shared__ T sz[SB];
@@ -403,16 +411,20 @@ __global__ __launch_bounds__(TBT) void trsv_bwd_fused(const T *__restrict__ L, i
 
 template <typename T>
 static int trsv_t(const T *L, int64_t n, int64_t ldl, T *b, T *x, int transpose, hipStream_t st,
-                  int64_t ncols = -1)
+                  int64_t ncols = -1, const Batch *bt = nullptr)
 {
+    // bt: bt->count systems solved by the same launches; sA = stride of L, sB = stride of b and x
+    const unsigned nbt = (unsigned)(bt ? bt->count : 1);
+    const int64_t sL = bt ? bt->sA : 0, sv = bt ? bt->sB : 0;
     // ncols < n (forward only): the matrix is a trapezoid -- an ncols x ncols lower
     // triangle on top of (n - ncols) further rows; x[0:ncols] is solved and the
     // remaining right-hand side b[ncols:n] is reduced by L[ncols:n, 0:ncols] x.
     if (ncols < 0 || ncols > n) ncols = n;
-    ProfScope prof(PC_TRSV, ((double)n * ncols - 0.5 * (double)ncols * (ncols - 1)) * sizeof(T), st);
+    ProfScope prof(PC_TRSV, ((double)n * ncols - 0.5 * (double)ncols * (ncols - 1)) * sizeof(T) * nbt, st);
     const int64_t nblk = cdiv(ncols, SB);
+    const int64_t sLinv = nblk * SB * SB;
     void *scr = nullptr;
-    GPX_TRY(scratch((size_t)nblk * SB * SB * sizeof(T), &scr));
+    GPX_TRY(scratch((size_t)nbt * sLinv * sizeof(T), &scr));
     T *Linv = (T *)scr;
     const int aligned = (((uintptr_t)L) % (2 * sizeof(T)) == 0) && (ldl % 2 == 0);
     static const int ablate = getenv("GPX_TRSV_ABLATE") ? atoi(getenv("GPX_TRSV_ABLATE")) : 0;   // timing diagnostics only
@@ -422,31 +434,34 @@ static int trsv_t(const T *L, int64_t n, int64_t ldl, T *b, T *x, int transpose,
     // solution into this block's rows/columns, spread over 8-16 workgroups; (F) workgroup 0
     // solves the block while the other workgroups stream the previous block's far panel.
     if (!transpose) {
-        hipLaunchKernelGGL((trinv64_kernel<T, true>), dim3((unsigned)nblk), dim3(64), 0, st, L, ldl, ncols, Linv);
+        hipLaunchKernelGGL((trinv64_kernel<T, true>), dim3((unsigned)nblk, nbt), dim3(64), 0, st, L, ldl, ncols, Linv,
+                           sL, sLinv);
         for (int64_t blk = 0; blk < nb; ++blk) {
             const int64_t k0 = blk * TB, p0 = std::max<int64_t>(blk - 1, 0) * TB;
             const int jb = width(blk), pjb = blk > 0 ? TB : 0;
             if (blk > 0)
-                hipLaunchKernelGGL((trsv_fwd_fused<T>), dim3((unsigned)(1 + cdiv(jb, 64))), dim3(TBT), 0, st, L, ldl,
-                                   Linv, b, x, k0 + jb, k0, 0, p0, pjb, k0, aligned, ablate);
+                hipLaunchKernelGGL((trsv_fwd_fused<T>), dim3((unsigned)(1 + cdiv(jb, 64)), nbt), dim3(TBT), 0, st, L, ldl,
+                                   Linv, b, x, k0 + jb, k0, 0, p0, pjb, k0, aligned, ablate, sL, sLinv, sv);
             const int64_t far = blk > 0 ? n - (k0 + jb) : 0;
-            hipLaunchKernelGGL((trsv_fwd_fused<T>), dim3((unsigned)(1 + cdiv(far, 64))), dim3(TBT), 0, st, L, ldl,
-                               Linv, b, x, n, k0, jb, p0, pjb, k0 + jb, aligned, ablate);
+            hipLaunchKernelGGL((trsv_fwd_fused<T>), dim3((unsigned)(1 + cdiv(far, 64)), nbt), dim3(TBT), 0, st, L, ldl,
+                               Linv, b, x, n, k0, jb, p0, pjb, k0 + jb, aligned, ablate, sL, sLinv, sv);
         }
         if (n > ncols)          // trapezoid: the last block's panel below the triangle
-            hipLaunchKernelGGL((trsv_fwd_fused<T>), dim3((unsigned)(1 + cdiv(n - ncols, 64))), dim3(TBT), 0, st, L,
-                               ldl, Linv, b, x, n, ncols, 0, (nb - 1) * TB, width(nb - 1), ncols, aligned, ablate);
+            hipLaunchKernelGGL((trsv_fwd_fused<T>), dim3((unsigned)(1 + cdiv(n - ncols, 64)), nbt), dim3(TBT), 0, st, L,
+                               ldl, Linv, b, x, n, ncols, 0, (nb - 1) * TB, width(nb - 1), ncols, aligned, ablate,
+                               sL, sLinv, sv);
     } else {
-        hipLaunchKernelGGL((trinv64_kernel<T, false>), dim3((unsigned)nblk), dim3(64), 0, st, L, ldl, ncols, Linv);
+        hipLaunchKernelGGL((trinv64_kernel<T, false>), dim3((unsigned)nblk, nbt), dim3(64), 0, st, L, ldl, ncols, Linv,
+                           sL, sLinv);
         for (int64_t blk = nb - 1; blk >= 0; --blk) {
             const int64_t k0 = blk * TB, q0 = k0 + TB;
             const int jb = width(blk), qjb = blk + 1 < nb ? width(blk + 1) : 0;
             if (qjb > 0)
-                hipLaunchKernelGGL((trsv_bwd_fused<T, 32>), dim3((unsigned)(1 + cdiv(jb, 32))), dim3(TBT), 0, st, L,
-                                   ldl, Linv, b, x, k0, 0, q0, qjb, k0, k0 + jb, aligned, ablate);
-            hipLaunchKernelGGL((trsv_bwd_fused<T, 128>), dim3((unsigned)(1 + (qjb > 0 ? cdiv(k0, 128) : 0))),
+                hipLaunchKernelGGL((trsv_bwd_fused<T, 32>), dim3((unsigned)(1 + cdiv(jb, 32)), nbt), dim3(TBT), 0, st, L,
+                                   ldl, Linv, b, x, k0, 0, q0, qjb, k0, k0 + jb, aligned, ablate, sL, sLinv, sv);
+            hipLaunchKernelGGL((trsv_bwd_fused<T, 128>), dim3((unsigned)(1 + (qjb > 0 ? cdiv(k0, 128) : 0)), nbt),
                                dim3(TBT), 0, st, L, ldl, Linv, b, x, k0, jb, q0, qjb, (int64_t)0, k0, aligned,
-                               ablate);
+                               ablate, sL, sLinv, sv);
         }
     }
     GPX_LAUNCH_CHECK();
@@ -454,11 +469,12 @@ static int trsv_t(const T *L, int64_t n, int64_t ldl, T *b, T *x, int transpose,
 }
 
 int trsv_lower(int dtype, const void *L, int64_t n, int64_t ldl, void *b, void *x, int transpose,
-               hipStream_t st)
+               hipStream_t st, const Batch *bt)
 {
     if (n <= 0) return GPX_OK;
-    if (dtype == GPX_F64) return trsv_t<double>((const double *)L, n, ldl, (double *)b, (double *)x, transpose, st);
-    return trsv_t<float>((const float *)L, n, ldl, (float *)b, (float *)x, transpose, st);
+    if (dtype == GPX_F64)
+        return trsv_t<double>((const double *)L, n, ldl, (double *)b, (double *)x, transpose, st, -1, bt);
+    return trsv_t<float>((const float *)L, n, ldl, (float *)b, (float *)x, transpose, st, -1, bt);
 }
 
 int trsv_lower_cols(int dtype, const void *L, int64_t n, int64_t ldl, int64_t ncols, void *b, void *x,
@@ -563,8 +579,13 @@ int trsm_right_lt(int dtype, const void *L, int64_t n, int64_t ldl, void *X, int
 // ---- reductions (single workgroup, fixed order => deterministic) ----------
 template <typename T, int MODE>   // MODE 0: sum a[i]*b[i]   1: 2*sum log a[i*stride]
 __global__ __launch_bounds__(1024) void reduce_kernel(const T *__restrict__ a, const T *__restrict__ b,
-                                                      int64_t n, int64_t stride, double *__restrict__ out)
+                                                      int64_t n, int64_t stride, double *__restrict__ out,
+                                                      int64_t sa, int64_t sb, int64_t so)
 {
+    // batched: workgroup blockIdx.x reduces vector pair blockIdx.x into out[blockIdx.x * so]
+    a += (int64_t)blockIdx.x * sa;
+    if (MODE == 0) b += (int64_t)blockIdx.x * sb;
+    out += (int64_t)blockIdx.x * so;
     __shared__ double red[16];
     const int tid = threadIdx.x;
     double acc = 0.0;
@@ -582,26 +603,30 @@ __global__ __launch_bounds__(1024) void reduce_kernel(const T *__restrict__ a, c
     }
 }
 
-int logdet_chol(int dtype, const void *L, int64_t n, int64_t ldl, double *out_dev, hipStream_t st)
+// count > 1: matrix i at L + i * sL, result in out_dev[i * so]
+int logdet_chol(int dtype, const void *L, int64_t n, int64_t ldl, double *out_dev, hipStream_t st, int count,
+                int64_t sL, int64_t so)
 {
     if (dtype == GPX_F64)
-        hipLaunchKernelGGL((reduce_kernel<double, 1>), dim3(1), dim3(1024), 0, st, (const double *)L,
-                           (const double *)nullptr, n, ldl + 1, out_dev);
+        hipLaunchKernelGGL((reduce_kernel<double, 1>), dim3(count), dim3(1024), 0, st, (const double *)L,
+                           (const double *)nullptr, n, ldl + 1, out_dev, sL, (int64_t)0, so);
     else
-        hipLaunchKernelGGL((reduce_kernel<float, 1>), dim3(1), dim3(1024), 0, st, (const float *)L,
-                           (const float *)nullptr, n, ldl + 1, out_dev);
+        hipLaunchKernelGGL((reduce_kernel<float, 1>), dim3(count), dim3(1024), 0, st, (const float *)L,
+                           (const float *)nullptr, n, ldl + 1, out_dev, sL, (int64_t)0, so);
     GPX_LAUNCH_CHECK();
     return GPX_OK;
 }
 
-int dot(int dtype, const void *a, const void *b, int64_t n, double *out_dev, hipStream_t st)
+// count > 1: pair i is (a + i * sa, b + i * sb), result in out_dev[i * so]
+int dot(int dtype, const void *a, const void *b, int64_t n, double *out_dev, hipStream_t st, int count, int64_t sa,
+        int64_t sb, int64_t so)
 {
     if (dtype == GPX_F64)
-        hipLaunchKernelGGL((reduce_kernel<double, 0>), dim3(1), dim3(1024), 0, st, (const double *)a,
-                           (const double *)b, n, 1, out_dev);
+        hipLaunchKernelGGL((reduce_kernel<double, 0>), dim3(count), dim3(1024), 0, st, (const double *)a,
+                           (const double *)b, n, 1, out_dev, sa, sb, so);
     else
-        hipLaunchKernelGGL((reduce_kernel<float, 0>), dim3(1), dim3(1024), 0, st, (const float *)a,
-                           (const float *)b, n, 1, out_dev);
+        hipLaunchKernelGGL((reduce_kernel<float, 0>), dim3(count), dim3(1024), 0, st, (const float *)a,
+                           (const float *)b, n, 1, out_dev, sa, sb, so);
     GPX_LAUNCH_CHECK();
     return GPX_OK;
 }

@@ -3,8 +3,11 @@
 The reference has no optimiser (``fit_MLII`` was removed in 1.0.3, CHANGELOG.md:19);
 its ML-II inner step is "set params -> read log_lh" (gp/gp.py:216-223, 337-367).
 This harness runs that step for a whole table of restarts on one resident data set:
-one ``gpx_gp`` handle per process, x / y uploaded once, then set_params + fit +
-log_lh per row.  With a process group the rows are dealt round-robin to the ranks
+one ``gpx_gp`` handle per process, x / y uploaded once, then ONE call of
+``gpx_gp_fit_batch``: the kernel matrices of all rows sit in HBM side by side and are
+factored in lock-step (every launch covers all of them), so the chain of small
+dependent launches that bounds a single n = 8192 factorisation is paid once per batch.
+With a process group the rows are dealt round-robin to the ranks
 (replicas only: no intra-GP sharding) and one all-reduce assembles the
 table on every rank.
 """
@@ -19,7 +22,8 @@ __all__ = ["log_lh_batch", "best_restart"]
 _KERNEL_IDS = {"gaussian": (_lib.KERNEL_GAUSSIAN, 2), "periodic": (_lib.KERNEL_PERIODIC, 3)}
 
 
-def log_lh_batch(x, y, thetas, kernel="gaussian", dtype="float64", dist=None, device=None, concurrency=None):
+def log_lh_batch(x, y, thetas, kernel="gaussian", dtype="float64", dist=None, device=None, concurrency=None,
+                 batched=True):
     """log_lh for every row ``(kernel params..., s)`` of `thetas`.
 
     x: (n,) or (n, d); y: (n,); thetas: (r, n_params + 1).  Rows with invalid parameters
@@ -27,6 +31,8 @@ def log_lh_batch(x, y, thetas, kernel="gaussian", dtype="float64", dist=None, de
     kernel matrix is not positive definite give ``-inf`` / ``nan`` as the reference would
     (-inf for non-PD, gp/gp.py:362-365; nan marks a row that would have raised ValueError).
     `dist`: an initialised ``torch.distributed`` module (any backend) or None.
+    `batched` (default): this process's rows go through one ``gpx_gp_fit_batch`` call (lock-step
+    factorisation of all their matrices).  ``batched=False`` is the row-at-a-time route:
     `concurrency`: handles (= host threads, each with its own HIP streams) working on this
     process's rows at the same time (default 1).  ctypes drops the GIL for the duration of a
     call, the library keeps its per-thread scratch and look-ahead streams thread-local, and every
@@ -77,7 +83,21 @@ def log_lh_batch(x, y, thetas, kernel="gaussian", dtype="float64", dist=None, de
         finally:
             lib.gpx_gp_destroy(h)
 
-    if concurrency == 1:
+    if batched and concurrency == 1:
+        if device is not None:
+            _lib.check(lib.gpx_set_device(int(device)))
+        if mine:
+            h = ctypes.c_void_p()
+            _lib.check(lib.gpx_gp_create(ctypes.byref(h), dt, kid, n, d))
+            try:
+                _lib.check(lib.gpx_gp_set_data(h, _lib.dptr(x), _lib.dptr(y)))
+                th = np.ascontiguousarray(thetas[mine])
+                res = np.empty(len(mine), dtype=np.float64)
+                _lib.check(lib.gpx_gp_fit_batch(h, _lib.dptr(th), len(mine), _lib.dptr(res), None))
+                out[mine] = res
+            finally:
+                lib.gpx_gp_destroy(h)
+    elif concurrency == 1:
         work(mine)
     else:
         from concurrent.futures import ThreadPoolExecutor

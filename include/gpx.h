@@ -281,6 +281,16 @@ int gpx_gp_get_inv_Kxx(gpx_gp_t *gp, double *out, int64_t ld);
  * kernel, then one fused pass against kernel derivatives evaluated on the fly.  All NaN when the
  * factorisation failed (gp/gp.py:424-428).  Periodic kernel: d == 1 only. */
 int gpx_gp_dloglh_dtheta(gpx_gp_t *gp, double *out);
+/* Batched ML-II step (BASELINE config 5; the reference's inner step "set params -> read log_lh",
+ * gp/gp.py:216-223,337-367, for a table of restarts on the handle's data set).
+ * thetas: HOST (B, n_params + 1) row-major, rows (kernel params..., s); log_lh: HOST B doubles;
+ * info: HOST B ints or NULL (potrf info per row; -1 for a row with invalid parameters).
+ * A row whose parameters the reference rejects with ValueError (kernel parameter < EPS, s < 0,
+ * non-finite) yields NaN; a non-positive-definite row or logdet < MIN yields -inf.
+ * The kernel matrices of the rows are held in HBM together and factored in lock-step (every
+ * launch covers all of them); chunked by free memory (cap: environment GPX_BATCH_MAX).
+ * Leaves the handle's own fitted state untouched. */
+int gpx_gp_fit_batch(gpx_gp_t *gp, const double *thetas, int64_t B, double *log_lh, int *info);
 /* timing of the last fit, milliseconds per stage (HIP events on the handle's
  * stream): [0] kernel build [1] potrf [2] solve [3] logdet+dot [4] total */
 int gpx_gp_last_timing(gpx_gp_t *gp, float *ms5);

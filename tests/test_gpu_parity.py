@@ -551,9 +551,33 @@ def test_mlii_batch_matches_oracle_and_reference_conventions():
     assert np.isnan(llh[6]) and np.isnan(llh[7])
     i, th, best = mlii.best_restart(X, y, thetas)
     assert i == int(np.argmax(llh[:6])) and best == llh[i]
-    # several handles at once (one host thread each): bit-identical to the sequential table
-    llh3 = mlii.log_lh_batch(X, y, thetas, concurrency=3)
+    # the row-at-a-time route (one fit per row) and several handles at once (one host thread each) give the
+    # same table as the default lock-step batched route (same kernels, same summation order per matrix)
+    llh1 = mlii.log_lh_batch(X, y, thetas, batched=False)
+    np.testing.assert_array_equal(llh1, llh)
+    llh3 = mlii.log_lh_batch(X, y, thetas, batched=False, concurrency=3)
     np.testing.assert_array_equal(llh3, llh)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_fit_batch_lock_step_vs_oracle(dtype, monkeypatch):
+    """gpx_gp_fit_batch (BASELINE config 5's engine): B matrices factored in lock-step -- batched diag /
+    panel / trailing / TRSV launches -- at a size with several outer blocks, a ragged last block and the
+    look-ahead on; chunked (GPX_BATCH_MAX = 3 with 7 rows: chunks of 3, 3, 1); one non-PD row, one invalid."""
+    from gaussian_processes_amd import mlii
+    N, d = 1350, 2
+    X, y, _ = orc.synth_inputs(N, d, 4)
+    rs = np.random.RandomState(5)
+    thetas = np.column_stack([rs.uniform(0.5, 2, 5), rs.uniform(0.3, 1.5, 5) * np.sqrt(d), rs.uniform(0.6, 2, 5)])
+    thetas = np.vstack([thetas, [1.0, 50.0, 0.0], [1.0, -1.0, 1.0]])     # rank-deficient (w huge, s = 0); invalid w
+    monkeypatch.setenv("GPX_BATCH_MAX", "3")
+    llh = mlii.log_lh_batch(X, y, thetas, dtype=dtype)
+    for i in range(5):
+        o = orc.OracleGP("gaussian", thetas[i, :2], X, y, thetas[i, 2])
+        np.testing.assert_allclose(llh[i], o.log_lh, rtol=1e-10 if dtype == "float64" else 1e-4)
+    assert llh[5] == -np.inf and np.isnan(llh[6])
+    monkeypatch.setenv("GPX_BATCH_MAX", "64")
+    np.testing.assert_array_equal(mlii.log_lh_batch(X, y, thetas, dtype=dtype), llh)
 
 
 @pytest.mark.parametrize("N,d", [(16389, 5), (17408 + 63, 2)])
@@ -763,13 +787,17 @@ def test_plugin_kernel_path_vs_numpy(dtype, N):
         np.testing.assert_allclose(g.log_lh, llh, rtol=1e-4)
         np.testing.assert_allclose(g.mean(Xo), mean, rtol=1e-3, atol=1e-3)
         np.testing.assert_allclose(g.cov(Xo), cov, rtol=1e-2, atol=5e-3)
-    # a parameter change through the plugin's own setter refits
-    g.params = np.array([1.1, 0.7, 0.5])
+    # a parameter change through the plugin's own setter refits (s large enough that logdet stays above
+    # MIN = -705.6: below it the reference's clamp, gp_c.pyx:22-23, returns -inf -- and so does this path)
+    g.params = np.array([1.1, 0.7, 0.9])
     k2 = _PlainRBF(1.1, 0.7)
-    K2 = k2(X, X) + 0.25 * np.eye(N)
+    K2 = k2(X, X) + 0.81 * np.eye(N)
     L2 = scipy.linalg.cholesky(K2, lower=True)
     llh2 = -0.5 * y @ scipy.linalg.cho_solve((L2, True), y) - np.log(np.diag(L2)).sum() - 0.5 * N * np.log(2 * np.pi)
     np.testing.assert_allclose(g.log_lh, llh2, rtol=1e-10 if dtype == "float64" else 1e-4)
+    if N == 700 and dtype == "float64":
+        g.params = np.array([1.1, 0.7, 0.5])             # logdet = -741 < MIN: the clamp fires
+        assert g.log_lh == -np.inf and g.lh == 0
 
 
 def test_plugin_kernel_nonpd_raises_like_the_reference():
