@@ -431,6 +431,15 @@ struct GemmMap {
     // batched launches (blockIdx.y = matrix index): element strides between consecutive matrices
     int64_t sA, sB, sC;
     int sflag;    // stride of abort_flag (one info word per matrix)
+    // EXACT enumeration (BM = 128, lower-triangular single-rank maps whose triangle is tile aligned): the
+    // grid holds only tiles that exist -- tile (i, j) with j <= min(eTC - 1, i + eD), i < eTR.  Order: bands
+    // of 8 tile rows, column-major inside a band, so that 64 consecutive tiles are an 8 x 8 patch (8 A- and
+    // 8 B-slices); chunks of 2^ecl consecutive tiles go to one XCD (chunk c -> blocks with blockIdx % 8 ==
+    // c % 8).  epre[b] = tiles before band b.  With the 1024 x 1024 patch grid a trailing update of a
+    // small matrix launched up to 6 x more workgroups than it has tiles (n = 8192, nb = 256: 800 for the
+    // 124 tiles of a block-column update), each still passing through the dispatcher.
+    int exact, ecl, eT, eD, eTR, eTC, ebands;
+    int epre[66];
 };
 static unsigned long long *g_gemm_stamps = nullptr;
 
@@ -466,7 +475,29 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_nt_fast_kernel(int64_t M, int6
     const int tsh = RSH + fm.csh;
     int patch = (loc >> tsh) * 8 + xcd, within = loc & ((1 << tsh) - 1);
     int pb_r, pb_c;
-    if (BM == 128 && bid >= fm.dbegin) {
+    if (BM == 128 && fm.exact) {
+        const int chunk = ((loc >> fm.ecl) << 3) + xcd;
+        const int t = (chunk << fm.ecl) + (loc & ((1 << fm.ecl) - 1));
+        if (t >= fm.eT) return;
+        int lo = 0, hi = fm.ebands;                                   // band: epre[lo] <= t < epre[lo + 1]
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (fm.epre[mid] <= t) lo = mid; else hi = mid; }
+        int tt = t - fm.epre[lo];
+        const int h = min(8, fm.eTR - 8 * lo);                        // tile rows in this band
+        const int dj = 8 * lo + fm.eD;                                // column j holds rows r >= j - dj
+        const int jfull = max(0, min(fm.eTC, dj + 1));                // columns that hold all h rows
+        int j, r;
+        if (tt < jfull * h) { j = tt / h; r = tt - j * h; }
+        else {
+            tt -= jfull * h;
+            j = jfull;
+            for (;;) {                                                // at most 8 partial columns
+                const int rmin = max(0, j - dj), cnt = max(0, h - rmin);
+                if (tt < cnt) { r = rmin + tt; break; }
+                tt -= cnt; ++j;
+            }
+        }
+        pb_r = lo; pb_c = j >> 3; within = (r << 3) | (j & 7);
+    } else if (BM == 128 && bid >= fm.dbegin) {
         const int b2 = bid - fm.dbegin;
         const int loc2 = b2 >> 3, dp = (loc2 / 36) * 8 + (b2 & 7), t = loc2 % 36;
         if (dp >= fm.ndiag) return;
@@ -695,12 +726,12 @@ static int launch_gemm_nt_fast(int64_t M, int64_t N, int64_t K, const void *A, i
 {
     constexpr int F_SMEM = FGeo<BN, BM>::SMEM;
     GPX_TRY(set_max_lds((const void *)gemm_nt_fast_kernel<T, BN, TAG, BM>, F_SMEM));
-    GemmMap fm;
+    GemmMap fm{};
     if (map) {
         fm = *map;
     } else {
         fm.boff = 0; fm.cbase = 0; fm.nb = (int64_t)1 << 40; fm.pm1nb = 0; fm.brows = N;
-        fm.abort_flag = nullptr;
+        fm.abort_flag = nullptr; fm.sflag = 0; fm.exact = 0;
         fm.a = 0; fm.b = 0; fm.csh = 3;
         // lower-triangular result: skip the patch rows above the diagonal; with more than one patch
         // column the staircase (a = 1) drops one more patch row per column
@@ -724,7 +755,7 @@ static int launch_gemm_nt_fast(int64_t M, int64_t N, int64_t K, const void *A, i
     int64_t dblocks = 0;
     {
         static const bool no_split = getenv("GPX_GEMM_NO_DSPLIT") != nullptr;
-        if (!no_split && BM == 128 && BN == 128 && tri == GPX_LOWER && fm.a == 1 && fm.csh == 3 && fm.pm1nb == 0 &&
+        if (!no_split && !fm.exact && BM == 128 && BN == 128 && tri == GPX_LOWER && fm.a == 1 && fm.csh == 3 && fm.pm1nb == 0 &&
             col0 - row0 == (int64_t)fm.b * 1024 && fm.np > 0) {
             const int64_t pbc = cdiv(N, 1024);
             fm.bdiag = fm.b;
@@ -741,7 +772,8 @@ static int launch_gemm_nt_fast(int64_t M, int64_t N, int64_t K, const void *A, i
         }
     }
     const int64_t np = fm.np;
-    if (np <= 0 && dblocks == 0) return GPX_OK;
+    if (BM == 128 && fm.exact) { if (fm.eT <= 0) return GPX_OK; }
+    else if (np <= 0 && dblocks == 0) return GPX_OK;
     {
         static const bool no_vec = getenv("GPX_GEMM_NO_VEC_C") != nullptr;
         fm.vec_c = (!no_vec && ldc % 2 == 0 && N % 2 == 0 && N >= 2 && ((uintptr_t)C) % (2 * sizeof(T)) == 0) ? 1 : 0;
@@ -756,7 +788,8 @@ static int launch_gemm_nt_fast(int64_t M, int64_t N, int64_t K, const void *A, i
     }
     const int64_t ablocks = (cdiv(np, 8) * 8 * (1024 / BM)) << fm.csh;
     if (dblocks) fm.dbegin = (int)ablocks;
-    const int64_t blocks = ablocks + dblocks;
+    int64_t blocks = ablocks + dblocks;
+    if (BM == 128 && fm.exact) blocks = cdiv(fm.eT, (int64_t)8 << fm.ecl) * ((int64_t)8 << fm.ecl);
     ProfScope prof(TAG == 1 ? PC_GEMM : (BN == 128 ? PC_GEMM_PANEL : PC_GEMM_SKINNY),
                    (work >= 0 ? work : 2.0 * (double)K * updated_elements(M, N, tri, row0, col0)) * nbatch, st);
     hipLaunchKernelGGL((gemm_nt_fast_kernel<T, BN, TAG, BM>), dim3((unsigned)blocks, (unsigned)nbatch), dim3(BM * 2), F_SMEM, st, M, N, K,
@@ -852,7 +885,7 @@ int syrk_bc(int dtype, int64_t n, int64_t row_begin, void *Cloc, int64_t ldc, in
     char *C = (char *)Cloc + (row_begin * ldc + cl0) * es;
     const char *A = (const char *)Pb + (row_begin - k0) * ldp * es;
     if (fast) {
-        GemmMap fm;
+        GemmMap fm{};
         fm.cbase = cl0; fm.nb = nb; fm.pm1nb = (int64_t)(P - 1) * nb;
         fm.boff = cl0 + (int64_t)rank * nb - k0;
         fm.brows = n - k0;
@@ -871,6 +904,34 @@ int syrk_bc(int dtype, int64_t n, int64_t row_begin, void *Cloc, int64_t ldc, in
         fm.np = (int)np;
         fm.stamps = nullptr; fm.ablate = 0;
         fm.abort_flag = abort_flag; fm.sflag = bt ? 1 : 0;
+        fm.exact = 0;
+        {
+            // single rank, triangle aligned to the 128 x 128 tiles: enumerate exactly the tiles that exist
+            static const int exact_env = getenv("GPX_GEMM_EXACT") ? atoi(getenv("GPX_GEMM_EXACT")) : 1;
+            const int64_t off = row_begin - G0;                       // row origin minus column origin (global)
+            if (exact_env && P == 1 && fast_bm() == 128 && off % 128 == 0 && cdiv(M, 1024) <= 64) {
+                const int TR = (int)cdiv(M, 128), TC = (int)cdiv(Ncols, 128), D = (int)(off / 128);
+                const int bands = (int)cdiv(TR, 8);
+                int total = 0;
+                for (int b = 0; b < bands; ++b) {
+                    fm.epre[b] = total;
+                    const int h = std::min(8, TR - 8 * b), dj = 8 * b + D;
+                    const int jfull = std::max(0, std::min(TC, dj + 1));
+                    total += jfull * h;
+                    for (int j = jfull; j < TC; ++j) {
+                        const int cnt = std::max(0, h - std::max(0, j - dj));
+                        if (cnt == 0) break;
+                        total += cnt;
+                    }
+                }
+                fm.epre[bands] = total;
+                fm.exact = 1; fm.eT = total; fm.eD = D; fm.eTR = TR; fm.eTC = TC; fm.ebands = bands;
+                int cl = 6;                                           // chunk of 64 tiles = one 8 x 8 patch per XCD turn
+                while (cl > 2 && ((int64_t)8 << cl) > total) --cl;   // few tiles: smaller chunks, every XCD still gets some
+                fm.ecl = cl;
+                if (total <= 0) return GPX_OK;
+            }
+        }
         if (fast_bm() == 128) {
             if (dtype == GPX_F64)
                 return launch_gemm_nt_fast<double, 128, 1, 128>(M, Ncols, kb, A, ldp, Pb, ldp, C, ldc, -1.0, GPX_LOWER,

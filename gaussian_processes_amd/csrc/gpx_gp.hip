@@ -26,6 +26,8 @@ struct gpx_gp {
     double s;
     bool have_data, have_params, fitted, have_K;
     float ms[5];
+    // fit_batch workspace (grow-only, freed with the handle): the matrices of one chunk + their vectors
+    void *bw; size_t bw_bytes; int64_t bw_cap;
 };
 
 namespace gpx {
@@ -182,7 +184,7 @@ int gpx_gp_destroy(gpx_gp_t *g)
     if (!g) return GPX_OK;
     gpx::DeviceGuard guard__(g->device);
     if (g->st) (void)hipStreamSynchronize(g->st);
-    void *bufs[] = {g->x, g->y, g->A, g->alpha, g->t0, g->t1, g->scal};
+    void *bufs[] = {g->x, g->y, g->A, g->alpha, g->t0, g->t1, g->scal, g->bw};
     for (void *b : bufs) if (b) (void)hipFree(b);
     for (int i = 0; i < 6; ++i) if (g->ev[i]) (void)hipEventDestroy(g->ev[i]);
     if (g->st) (void)hipStreamDestroy(g->st);
@@ -521,14 +523,28 @@ int gpx_gp_fit_batch(gpx_gp_t *g, const double *thetas, int64_t B, double *log_l
     int64_t Bc = (int64_t)((double)freeb * 0.85 / (double)(per + 4 * (size_t)n * es + 64));
     if (const char *env = getenv("GPX_BATCH_MAX")) Bc = std::min<int64_t>(Bc, std::max<int64_t>(1, atoll(env)));
     Bc = std::max<int64_t>(1, std::min<int64_t>(Bc, B));
-    if ((double)per > (double)freeb * 0.85) { set_error("fit_batch: not even one more n x n matrix fits in HBM"); return GPX_ERR_NOMEM; }
-    DevBuf Ab, t0, t1, al, sc, inf;
-    GPX_TRY(Ab.alloc((size_t)Bc * per));
-    GPX_TRY(t0.alloc((size_t)Bc * n * es));
-    GPX_TRY(t1.alloc((size_t)Bc * n * es));
-    GPX_TRY(al.alloc((size_t)Bc * n * es));
-    GPX_TRY(sc.alloc((size_t)Bc * 2 * sizeof(double)));
-    GPX_TRY(inf.alloc((size_t)Bc * sizeof(int)));
+    if (!g->bw && (double)per > (double)freeb * 0.85) { set_error("fit_batch: not even one more n x n matrix fits in HBM"); return GPX_ERR_NOMEM; }
+    // one block, kept in the handle between calls (an ML-II loop calls this once per sweep; a fresh
+    // hipMalloc of tens of GB costs more than the factorisations)
+    const size_t vec = ((size_t)n * es + 255) / 256 * 256;
+    if (g->bw && g->bw_cap >= Bc) Bc = std::min<int64_t>(g->bw_cap, B);
+    const size_t need = (size_t)Bc * (per + 3 * vec) + (size_t)Bc * 2 * sizeof(double) + (size_t)Bc * sizeof(int) + 1024;
+    if (g->bw_bytes < need) {
+        if (g->bw) { GPX_HIP(hipStreamSynchronize(g->st)); (void)hipFree(g->bw); g->bw = nullptr; g->bw_bytes = 0; g->bw_cap = 0; }
+        GPX_HIP(hipMalloc(&g->bw, need));
+        g->bw_bytes = need; g->bw_cap = Bc;
+    }
+    struct Ptr { void *p; } Ab, t0, t1, al, sc, inf;
+    {
+        char *w = (char *)g->bw;
+        Ab.p = w; w += (size_t)Bc * per;
+        t0.p = w; w += (size_t)Bc * vec;
+        t1.p = w; w += (size_t)Bc * vec;
+        al.p = w; w += (size_t)Bc * vec;
+        sc.p = w; w += ((size_t)Bc * 2 * sizeof(double) + 255) / 256 * 256;
+        inf.p = w;
+    }
+    const int64_t sV = (int64_t)(vec / es);               // element stride between the vectors of a chunk
     hipStream_t st = g->st;
     const int64_t sM = n * lda;
     std::vector<double> hs((size_t)Bc * 2);
@@ -546,15 +562,15 @@ int gpx_gp_fit_batch(gpx_gp_t *g, const double *thetas, int64_t B, double *log_l
             const double s = ok ? th[np] : 1.0;
             GPX_TRY(kmat(g->dtype, g->kernel, GPX_K, g->x, n, g->x, n, g->d, prm, s * s, GPX_LOWER,
                          (char *)Ab.p + (size_t)i * per, lda, st));
-            GPX_HIP(hipMemcpyAsync((char *)t0.p + (size_t)i * n * es, g->y, (size_t)n * es, hipMemcpyDeviceToDevice, st));
+            GPX_HIP(hipMemcpyAsync((char *)t0.p + (size_t)i * vec, g->y, (size_t)n * es, hipMemcpyDeviceToDevice, st));
         }
         Batch bm; bm.count = cnt; bm.sA = bm.sB = bm.sC = sM;
         GPX_TRY(potrf(g->dtype, Ab.p, n, lda, (int *)inf.p, st, cnt > 1 ? &bm : nullptr));
-        Batch bs; bs.count = cnt; bs.sA = sM; bs.sB = n; bs.sC = 0;
+        Batch bs; bs.count = cnt; bs.sA = sM; bs.sB = sV; bs.sC = 0;
         GPX_TRY(trsv_lower(g->dtype, Ab.p, n, lda, t0.p, t1.p, 0, st, &bs));
         GPX_TRY(trsv_lower(g->dtype, Ab.p, n, lda, t1.p, al.p, 1, st, &bs));
         GPX_TRY(logdet_chol(g->dtype, Ab.p, n, lda, (double *)sc.p, st, cnt, sM, 2));
-        GPX_TRY(dot(g->dtype, g->y, al.p, n, (double *)sc.p + 1, st, cnt, 0, n, 2));
+        GPX_TRY(dot(g->dtype, g->y, al.p, n, (double *)sc.p + 1, st, cnt, 0, sV, 2));
         GPX_HIP(hipMemcpyAsync(hs.data(), sc.p, (size_t)cnt * 2 * sizeof(double), hipMemcpyDeviceToHost, st));
         GPX_HIP(hipMemcpyAsync(hi.data(), inf.p, (size_t)cnt * sizeof(int), hipMemcpyDeviceToHost, st));
         GPX_HIP(hipStreamSynchronize(st));

@@ -17,9 +17,61 @@ import numpy as np
 
 from . import _lib
 
-__all__ = ["log_lh_batch", "best_restart"]
+__all__ = ["log_lh_batch", "best_restart", "BatchEvaluator"]
 
 _KERNEL_IDS = {"gaussian": (_lib.KERNEL_GAUSSIAN, 2), "periodic": (_lib.KERNEL_PERIODIC, 3)}
+
+
+class BatchEvaluator(object):
+    """One resident data set, many sweeps: keeps the ``gpx_gp`` handle (x, y and the lock-step
+    workspace in HBM) alive between calls, so that an outer optimiser pays the upload and the
+    tens-of-GB workspace allocation once.  ``ev(thetas)`` -> log_lh of every row."""
+
+    def __init__(self, x, y, kernel="gaussian", dtype="float64", device=None):
+        self.kid, self.nkp = _KERNEL_IDS[kernel]
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        n = x.shape[0]
+        d = 1 if x.ndim == 1 else x.shape[1]
+        if y.shape != (n,):
+            raise ValueError("invalid shape for y: %s" % str(y.shape))
+        self.lib = _lib.load()
+        if device is not None:
+            _lib.check(self.lib.gpx_set_device(int(device)))
+        dt = _lib.F64 if dtype in ("float64", "f64") else _lib.F32
+        self.h = ctypes.c_void_p()
+        _lib.check(self.lib.gpx_gp_create(ctypes.byref(self.h), dt, self.kid, n, d))
+        try:
+            _lib.check(self.lib.gpx_gp_set_data(self.h, _lib.dptr(x), _lib.dptr(y)))
+        except Exception:
+            self.close()
+            raise
+
+    def __call__(self, thetas):
+        th = np.ascontiguousarray(np.atleast_2d(np.asarray(thetas, dtype=np.float64)))
+        if th.shape[1] != self.nkp + 1:
+            raise ValueError("thetas must have %d columns (kernel params + s)" % (self.nkp + 1))
+        res = np.empty(th.shape[0], dtype=np.float64)
+        if th.shape[0]:
+            _lib.check(self.lib.gpx_gp_fit_batch(self.h, _lib.dptr(th), th.shape[0], _lib.dptr(res), None))
+        return res
+
+    def close(self):
+        if self.h:
+            self.lib.gpx_gp_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def log_lh_batch(x, y, thetas, kernel="gaussian", dtype="float64", dist=None, device=None, concurrency=None,
@@ -87,16 +139,8 @@ def log_lh_batch(x, y, thetas, kernel="gaussian", dtype="float64", dist=None, de
         if device is not None:
             _lib.check(lib.gpx_set_device(int(device)))
         if mine:
-            h = ctypes.c_void_p()
-            _lib.check(lib.gpx_gp_create(ctypes.byref(h), dt, kid, n, d))
-            try:
-                _lib.check(lib.gpx_gp_set_data(h, _lib.dptr(x), _lib.dptr(y)))
-                th = np.ascontiguousarray(thetas[mine])
-                res = np.empty(len(mine), dtype=np.float64)
-                _lib.check(lib.gpx_gp_fit_batch(h, _lib.dptr(th), len(mine), _lib.dptr(res), None))
-                out[mine] = res
-            finally:
-                lib.gpx_gp_destroy(h)
+            with BatchEvaluator(x, y, kernel=kernel, dtype=dtype, device=device) as ev:
+                out[mine] = ev(thetas[mine])
     elif concurrency == 1:
         work(mine)
     else:

@@ -19,10 +19,12 @@ summary["row_at_a_time_s"] = dt
 t0 = time.perf_counter(); o4 = mlii.log_lh_batch(X, y, thetas, batched=False, concurrency=4); dt = time.perf_counter() - t0
 print("row at a time, 4 handles: %.3f s = %.2f ms per restart" % (dt, dt / R * 1e3))
 summary["row_at_a_time_4_handles_s"] = dt
-for cap in (8, 16, 32, 64):
+for cap in (4, 8, 16, 32, 64):
     os.environ["GPX_BATCH_MAX"] = str(cap)
-    mlii.log_lh_batch(X, y, thetas[:cap])                      # warm-up at this batch size
-    t0 = time.perf_counter(); out = mlii.log_lh_batch(X, y, thetas); dt = time.perf_counter() - t0
+    t0 = time.perf_counter(); ev = mlii.BatchEvaluator(X, y); out = ev(thetas); cold = time.perf_counter() - t0
+    t0 = time.perf_counter(); out = ev(thetas); dt = time.perf_counter() - t0     # steady state: workspace resident
+    ev.close()
+    summary["batched_%d_cold_s" % cap] = cold
     fin = np.isfinite(out) & np.isfinite(ref)
     err = np.max(np.abs(out[fin] - ref[fin]) / np.abs(ref[fin])) if fin.any() else 0.0
     same = bool((np.isfinite(out) == np.isfinite(ref)).all())
