@@ -64,6 +64,8 @@ _SIGNATURES = {
                            c_double_p, c_double, c_int, c_void_p, c_int64, c_void_p]),
     "gpx_d_mean": (c_int, [c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int, c_double_p,
                            c_void_p, c_void_p, c_void_p]),
+    "gpx_d_mean_member": (c_int, [c_int, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int, c_double_p,
+                                  c_void_p, c_void_p, c_void_p]),
     "gpx_d_gemm_nt": (c_int, [c_int, c_int64, c_int64, c_int64, c_double, c_void_p, c_int64,
                               c_void_p, c_int64, c_void_p, c_int64, c_int, c_int64, c_int64,
                               c_void_p]),
@@ -102,6 +104,8 @@ _SIGNATURES = {
     "gpx_gp_get_alpha": (c_int, [c_void_p, c_double_p]),
     "gpx_gp_get_inv_Kxx": (c_int, [c_void_p, c_double_p, c_int64]),
     "gpx_gp_dloglh_dtheta": (c_int, [c_void_p, c_double_p]),
+    "gpx_gp_dlh_d2lh": (c_int, [c_void_p, c_double_p, c_double_p, c_double_p]),
+    "gpx_gp_dm_dtheta": (c_int, [c_void_p, c_double_p, c_int64, c_double_p]),
     "gpx_gp_fit_batch": (c_int, [c_void_p, c_double_p, c_int64, c_double_p, c_int_p]),
     "gpx_gp_last_timing": (c_int, [c_void_p, POINTER(c_float)]),
     "gpx_gp_device_ptrs": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int64), POINTER(c_void_p),

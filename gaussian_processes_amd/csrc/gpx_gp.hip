@@ -14,21 +14,7 @@
 #include <cmath>
 #include <vector>
 
-struct gpx_gp {
-    int device;        // the HIP device the handle lives on; every entry point makes it current
-    int dtype, kernel, d, nparams;
-    int64_t n, lda;
-    void *x, *y, *A, *alpha, *t0, *t1;
-    double *scal;      // device: [0] logdet [1] y^T alpha [2] spare ; int info at scal + 3
-    hipStream_t st;
-    hipEvent_t ev[6];
-    double params[3];
-    double s;
-    bool have_data, have_params, fitted, have_K;
-    float ms[5];
-    // fit_batch workspace (grow-only, freed with the handle): the matrices of one chunk + their vectors
-    void *bw; size_t bw_bytes; int64_t bw_cap;
-};
+#include "gpx_gp_internal.h"
 
 namespace gpx {
 
@@ -104,17 +90,6 @@ static int download_f64(int dtype, double *dst, int64_t ldh, const void *src, in
     return GPX_OK;
 }
 
-struct DevBuf {
-    void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int alloc(size_t bytes)
-    {
-        hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
-        if (e != hipSuccess) { p = nullptr; return hip_fail(e, "hipMalloc", __FILE__, __LINE__); }
-        return GPX_OK;
-    }
-};
-
 int kmat(int dtype, int kernel, int member, const void *x1, int64_t n, const void *x2, int64_t m,
          int d, const double *params, double diag_add, int tri, void *out, int64_t ld, hipStream_t st)
 {
@@ -122,12 +97,6 @@ int kmat(int dtype, int kernel, int member, const void *x1, int64_t n, const voi
 }
 
 static int nparams_of(int kernel) { return kernel == GPX_KERNEL_PERIODIC ? 3 : 2; }
-
-// every gpx_gp_* entry: the handle's device becomes current for the duration of the call
-#define GP_ENTER(g)                                                          \
-    GPX_ARG((g) != nullptr, "gp is NULL");                                   \
-    gpx::DeviceGuard guard__((g)->device);                                   \
-    if (guard__.rc != GPX_OK) return guard__.rc
 
 }  // namespace gpx
 

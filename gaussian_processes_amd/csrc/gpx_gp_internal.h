@@ -1,0 +1,41 @@
+// gpx_gp_internal.h -- the fitted-GP handle, shared by gpx_gp.hip and gpx_deriv.hip (not part of the ABI).
+#pragma once
+#include "gpx_common.h"
+
+struct gpx_gp {
+    int device;        // the HIP device the handle lives on; every entry point makes it current
+    int dtype, kernel, d, nparams;
+    int64_t n, lda;
+    void *x, *y, *A, *alpha, *t0, *t1;
+    double *scal;      // device: [0] logdet [1] y^T alpha [2] spare ; int info at scal + 3
+    hipStream_t st;
+    hipEvent_t ev[6];
+    double params[3];
+    double s;
+    bool have_data, have_params, fitted, have_K;
+    float ms[5];
+    // fit_batch workspace (grow-only, freed with the handle): the matrices of one chunk + their vectors
+    void *bw; size_t bw_bytes; int64_t bw_cap;
+};
+
+namespace gpx {
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes)
+    {
+        hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+        if (e != hipSuccess) { p = nullptr; return hip_fail(e, "hipMalloc", __FILE__, __LINE__); }
+        return GPX_OK;
+    }
+};
+
+}  // namespace gpx
+
+// every gpx_gp_* entry: the handle's device becomes current for the duration of the call
+#define GP_ENTER(g)                                                          \
+    GPX_ARG((g) != nullptr, "gp is NULL");                                   \
+    gpx::DeviceGuard guard__((g)->device);                                   \
+    if (guard__.rc != GPX_OK) return guard__.rc
+

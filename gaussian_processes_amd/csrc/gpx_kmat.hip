@@ -12,6 +12,7 @@
 // sum_k (a_k - b_k)^2 (never |a|^2+|b|^2-2ab: that loses the digits near r = 0
 // that the reference keeps).
 #include "gpx_common.h"
+#include "gpx_kernels_dev.h"
 #include <vector>
 
 namespace gpx {
@@ -59,56 +60,6 @@ int make_kparams(int kernel, int member, const double *params, double diag_add, 
         return GPX_ERR_ARG;
     }
     return GPX_OK;
-}
-
-template <typename T> struct Vec;
-template <> struct Vec<double> { static constexpr int N = 2; typedef double2 type; };
-template <> struct Vec<float>  { static constexpr int N = 4; typedef float4 type; };
-
-template <typename T> __device__ __forceinline__ T dev_exp(T x);
-template <> __device__ __forceinline__ double dev_exp<double>(double x) { return exp(x); }
-template <> __device__ __forceinline__ float  dev_exp<float>(float x)  { return expf(x); }
-
-// one kernel-matrix entry from the accumulated squared distance (gaussian) --
-// FORM 0: c2*exp(e)   1: exp(e)*(c3*d2 - c2)   2: exp(e)*(c4*d2^2 - c3*d2 + c2)
-// with the reference's underflow clamp  e < MIN -> 0  (gaussian_c.pyx:31-34)
-template <typename T, int FORM>
-__device__ __forceinline__ T gaussian_entry(T d2, T c1, T c2, T c3, T c4)
-{
-    const T e = c1 * d2;
-    T v;
-    if (FORM == 0)      v = c2 * dev_exp<T>(e);
-    else if (FORM == 1) v = dev_exp<T>(e) * (c3 * d2 - c2);
-    else                v = dev_exp<T>(e) * (c4 * (d2 * d2) - c3 * d2 + c2);
-    return (e < (T)GPX_MIN_LOG) ? (T)0 : v;
-}
-
-// periodic members for d == 1 (periodic_c.pyx), dd = x1[i] - x2[j]
-template <typename T>
-__device__ __forceinline__ T periodic_entry(int member, T dd, T h, T w, T p)
-{
-    const T h2 = h * h, w2 = w * w, p2 = p * p;
-    const T arg = (T)0.5 * dd / p;
-    const T sn = sin(arg), cs = cos(arg);
-    const T ex = dev_exp<T>((T)-2.0 * (sn * sn) / w2);
-    const T w3 = w2 * w, w4 = w2 * w2, p4 = p2 * p2;
-    switch (member) {
-    case GPX_K:        return h2 * ex;                                                    // :30
-    case GPX_DK_DH:    return (T)2.0 * h * ex;                                            // :65
-    case GPX_DK_DW:    return (T)4.0 * h2 * ex * (sn * sn) / w3;                          // :80
-    case GPX_DK_DP:    return (T)2.0 * dd * h2 * ex * sn * cs / (p2 * w2);                // :96
-    case GPX_D2K_DHDH: return (T)2.0 * ex;                                                // :111
-    case GPX_D2K_DHDW: return (T)8.0 * h * ex * (sn * sn) / w3;                           // :126
-    case GPX_D2K_DHDP: return (T)4.0 * dd * h * ex * sn * cs / (p2 * w2);                 // :142
-    case GPX_D2K_DWDW: return (T)-12.0 * h2 * ex * (sn * sn) / w4                         // :172
-                              + (T)16.0 * h2 * ex * (sn * sn) * (sn * sn) / (w4 * w2);
-    case GPX_D2K_DWDP: return (T)-4.0 * dd * h2 * ex * sn * cs / (p2 * w3)                // :188
-                              + (T)8.0 * dd * h2 * ex * (sn * sn * sn) * cs / (p2 * w3 * w2);
-    default:           return (dd * dd) * h2 * ex * (sn * sn) / (p4 * w2)                 // :235
-                              - (dd * dd) * h2 * ex * (cs * cs) / (p4 * w2)
-                              + (T)4.0 * (dd * dd) * h2 * ex * (sn * sn) * (cs * cs) / (p4 * w4)
-                              - (T)4.0 * dd * h2 * ex * sn * cs / (p2 * p * w2);
-    }
 }
 
 struct KP32 { float c[6]; };
@@ -295,7 +246,9 @@ static int launch_kmat(const void *x1, int64_t n, const void *x2, int64_t m, int
 constexpr int MP = 8;
 constexpr int MCP = 257;           // padded chunk row
 
-template <typename T, int KIND>
+// KIND: kernel family; FORM: gaussian member form 0..2 (see gaussian_entry), or for the periodic family
+// 0 = K for any d, 1 = any member at d == 1 (kp.member) -- out = member(xo, x) @ alpha.
+template <typename T, int KIND, int FORM>
 __global__ __launch_bounds__(256) void mean_kernel(const T *__restrict__ xo, int64_t m,
                                                    const T *__restrict__ x, int64_t n, int d,
                                                    KParams kp, const T *__restrict__ alpha,
@@ -318,7 +271,7 @@ __global__ __launch_bounds__(256) void mean_kernel(const T *__restrict__ xo, int
 #pragma unroll
     for (int pp = 0; pp < MP; ++pp) acc[pp] = 0.0;
 
-    const T c1 = (T)kp.c[0], c2 = (T)kp.c[1];
+    const T c1 = (T)kp.c[0], c2 = (T)kp.c[1], c3 = (T)kp.c[2], c4 = (T)kp.c[3];
     const int qd = 256 / d, rd = 256 - qd * d;          // idx += 256  <=>  (c, k) += (qd, rd) with carry
     const int cst = tid / d, kst = tid - cst * d;
     const int64_t jbeg = (int64_t)blockIdx.y * slice_len, jend = min(n, jbeg + slice_len);
@@ -348,6 +301,8 @@ __global__ __launch_bounds__(256) void mean_kernel(const T *__restrict__ xo, int
                     if (KIND == GPX_KERNEL_GAUSSIAN) {
                         const T t = so[pp * d + k] - b;
                         r[pp] = fma(t, t, r[pp]);
+                    } else if (FORM == 1) {
+                        r[pp] = so[pp * d + k] - b;                   // d == 1: the signed difference
                     } else {
                         const T sn = sin((T)0.5 * (so[pp * d + k] - b) / (T)kp.c[2]);
                         r[pp] = fma(sn, sn, r[pp]);
@@ -358,7 +313,9 @@ __global__ __launch_bounds__(256) void mean_kernel(const T *__restrict__ xo, int
             for (int pp = 0; pp < MP; ++pp) {
                 T kv;
                 if (KIND == GPX_KERNEL_GAUSSIAN) {
-                    kv = gaussian_entry<T, 0>(r[pp], c1, c2, (T)0, (T)0);
+                    kv = gaussian_entry<T, FORM>(r[pp], c1, c2, c3, c4);
+                } else if (FORM == 1) {
+                    kv = periodic_entry<T>(kp.member, r[pp], (T)kp.c[0], (T)kp.c[1], (T)kp.c[2]);
                 } else {
                     const T h = (T)kp.c[0], w = (T)kp.c[1];
                     kv = (h * h) * dev_exp<T>((T)-2.0 * r[pp] / (w * w));
@@ -431,21 +388,27 @@ static int launch_mean(int kernel, const void *xo, int64_t m, const void *x, int
     }
     dim3 grid((unsigned)gx, (unsigned)nslice), block(256);
     ProfScope prof(PC_MEAN, (double)m * n, st);
+#define GPX_MEAN_LAUNCH(KIND, FORM)                                                                 \
+    do {                                                                                            \
+        if (smem > 48 * 1024)                                                                       \
+            GPX_HIP(hipFuncSetAttribute((const void *)mean_kernel<T, KIND, FORM>,                   \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));    \
+        hipLaunchKernelGGL((mean_kernel<T, KIND, FORM>), grid, block, smem, st, (const T *)xo, m,   \
+                           (const T *)x, n, d, kp, (const T *)alpha, slice_len, partial, (T *)out); \
+    } while (0)
     if (kernel == GPX_KERNEL_GAUSSIAN) {
-        if (smem > 48 * 1024)
-            GPX_HIP(hipFuncSetAttribute((const void *)mean_kernel<T, GPX_KERNEL_GAUSSIAN>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL((mean_kernel<T, GPX_KERNEL_GAUSSIAN>), grid, block, smem, st,
-                           (const T *)xo, m, (const T *)x, n, d, kp, (const T *)alpha, slice_len, partial,
-                           (T *)out);
+        switch ((int)kp.c[4]) {
+        case 0: GPX_MEAN_LAUNCH(GPX_KERNEL_GAUSSIAN, 0); break;
+        case 1: GPX_MEAN_LAUNCH(GPX_KERNEL_GAUSSIAN, 1); break;
+        default: GPX_MEAN_LAUNCH(GPX_KERNEL_GAUSSIAN, 2); break;
+        }
+    } else if (kp.member == GPX_K) {
+        GPX_MEAN_LAUNCH(GPX_KERNEL_PERIODIC, 0);
     } else {
-        if (smem > 48 * 1024)
-            GPX_HIP(hipFuncSetAttribute((const void *)mean_kernel<T, GPX_KERNEL_PERIODIC>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL((mean_kernel<T, GPX_KERNEL_PERIODIC>), grid, block, smem, st,
-                           (const T *)xo, m, (const T *)x, n, d, kp, (const T *)alpha, slice_len, partial,
-                           (T *)out);
+        if (d != 1) { set_error("periodic derivative members need d == 1 (got %d)", d); return GPX_ERR_UNSUPPORTED; }
+        GPX_MEAN_LAUNCH(GPX_KERNEL_PERIODIC, 1);
     }
+#undef GPX_MEAN_LAUNCH
     if (partial)
         hipLaunchKernelGGL((mean_reduce_kernel<T>), dim3((unsigned)cdiv(m, 256)), dim3(256), 0, st, partial,
                            (int)nslice, m, (T *)out);
@@ -618,8 +581,8 @@ int gpx_d_kmat(int dtype, int kernel, int member, const void *x1, int64_t n, con
     return launch_kmat<float>(x1, n, x2, m, d, kp, tri, out, ld, S(stream));
 }
 
-int gpx_d_mean(int dtype, int kernel, const void *xo, int64_t m, const void *x, int64_t n, int d,
-               const double *params, const void *alpha, void *out, void *stream)
+int gpx_d_mean_member(int dtype, int kernel, int member, const void *xo, int64_t m, const void *x,
+                      int64_t n, int d, const double *params, const void *alpha, void *out, void *stream)
 {
     GPX_TRY(ensure_device());
     GPX_ARG(dtype == GPX_F64 || dtype == GPX_F32, "dtype must be GPX_F64 or GPX_F32");
@@ -627,9 +590,15 @@ int gpx_d_mean(int dtype, int kernel, const void *xo, int64_t m, const void *x, 
     if (m == 0) return GPX_OK;
     GPX_ARG(xo && out && (n == 0 || (x && alpha)), "NULL pointer");
     KParams kp;
-    GPX_TRY(make_kparams(kernel, GPX_K, params, 0.0, &kp));
+    GPX_TRY(make_kparams(kernel, member, params, 0.0, &kp));
     if (dtype == GPX_F64) return launch_mean<double>(kernel, xo, m, x, n, d, kp, alpha, out, S(stream));
     return launch_mean<float>(kernel, xo, m, x, n, d, kp, alpha, out, S(stream));
+}
+
+int gpx_d_mean(int dtype, int kernel, const void *xo, int64_t m, const void *x, int64_t n, int d,
+               const double *params, const void *alpha, void *out, void *stream)
+{
+    return gpx_d_mean_member(dtype, kernel, GPX_K, xo, m, x, n, d, params, alpha, out, stream);
 }
 
 }  // extern "C"

@@ -380,8 +380,17 @@ class GP(object):
             gp_c.dloglh_dtheta(self._y, Ki, self.Kxx_J, self.inv_Kxx_y, self._s, out)
         return out
 
+    def _native_derivs(self):
+        """True when the derivative stack can stay on the device (built-in kernel; periodic: 1-D)."""
+        kid = getattr(self.K, "_native_kernel", None)
+        return kid is not None and (self._d == 1 or kid == _lib.KERNEL_GAUSSIAN)
+
     @memoprop
     def dlh_dtheta(self):
+        r"""Gradient of the marginal likelihood (gp/gp.py:435-465).  Native kernels: device resident."""
+        if self._native_derivs():
+            # gp_c.pyx:52-67 is lh times gp_c.pyx:34-49 term by term: 0.5 lh (y^T K^-1 dK K^-1 y - tr(K^-1 dK))
+            return np.asarray(self.lh * self.dloglh_dtheta, dtype=DTYPE)
         out, Ki = self._nan_or(len(self.params))
         if Ki is not None:
             gp_c.dlh_dtheta(self._y, Ki, self.Kxx_J, self.inv_Kxx_y, self._s, self.lh, out)
@@ -389,11 +398,35 @@ class GP(object):
 
     @memoprop
     def d2lh_dtheta2(self):
+        r"""Hessian of the marginal likelihood (gp/gp.py:467-502).  Native kernels: device resident
+        (K^-1, the K^-1 dK_i products and all traces / quadratic forms stay in HBM)."""
+        if self._native_derivs():
+            st = self._fit()
+            npar = len(self.params)
+            out = np.empty((npar, npar), dtype=DTYPE)
+            hess = np.empty((npar, npar), dtype=DTYPE)
+            _lib.check(_lib.load().gpx_gp_dlh_d2lh(st.handle, None, _lib.dptr(out), _lib.dptr(hess)))
+            self._memoized.setdefault("d2loglh_dtheta2", hess)       # same device pass
+            return out
         npar = len(self.params)
         out, Ki = self._nan_or((npar, npar))
         if Ki is not None:
             gp_c.d2lh_dtheta2(self._y, Ki, self.Kxx_J, self.Kxx_H, self.inv_Kxx_y, self._s,
                               self.lh, self.dlh_dtheta, out)
+        return out
+
+    @memoprop
+    def d2loglh_dtheta2(self):
+        r"""Hessian of the LOG marginal likelihood w.r.t. ``(kernel params..., s)`` -- an extension:
+        the reference only offers the lh-scaled `d2lh_dtheta2`, which is identically zero once
+        ``log_lh < MIN`` (any n beyond a few hundred).  ``d2lh / lh - (dlh / lh)(dlh / lh)^T`` from the
+        same device pass (csrc/gpx_deriv.hip); native kernels only.  NaN when `Kxx` is not PD."""
+        if not self._native_derivs():
+            raise NotImplementedError("d2loglh_dtheta2 needs a built-in kernel (periodic: 1-D inputs)")
+        st = self._fit()
+        npar = len(self.params)
+        out = np.empty((npar, npar), dtype=DTYPE)
+        _lib.check(_lib.load().gpx_gp_dlh_d2lh(st.handle, None, None, _lib.dptr(out)))
         return out
 
     # ---- prediction (gp/gp.py:504-662) ----
@@ -450,6 +483,12 @@ class GP(object):
     def dm_dtheta(self, xo):
         r"""Derivative of the predictive mean w.r.t. the parameters, ``(n_p, m)``
         (gp/gp.py:627-662, gp_c.pyx:114-131)."""
+        if self._native_derivs():
+            st = self._fit_pd()                      # LinAlgError when not PD, as inv_Kxx raises in the reference
+            xo, m = self._xo(xo)
+            dm = np.empty((len(self.params), m), dtype=DTYPE)
+            _lib.check(_lib.load().gpx_gp_dm_dtheta(st.handle, _lib.dptr(xo), m, _lib.dptr(dm)))
+            return dm
         Ki = self.inv_Kxx
         Kj = self.Kxx_J
         Kjxo = self.K.jacobian(xo, self._x)

@@ -160,6 +160,12 @@ int gpx_d_mean(int dtype, int kernel, const void *xo, int64_t m, const void *x,
                int64_t n, int d, const double *params, const void *alpha,
                void *out, void *stream);
 
+/* The same with any member of the kernel family in place of K (the Jacobian / Hessian members of
+ * gaussian_c.pyx:51-164, periodic_c.pyx:53-235): out = member(xo, x) @ alpha, never materialised.
+ * Periodic members other than GPX_K need d == 1. */
+int gpx_d_mean_member(int dtype, int kernel, int member, const void *xo, int64_t m, const void *x,
+                      int64_t n, int d, const double *params, const void *alpha, void *out, void *stream);
+
 /* C (M x N, ldc) += alpha * A (M x K, lda) * B (N x K, ldb)^T -- the MFMA work-horse.
  * tri = GPX_LOWER: only tiles with some row >= col are touched and elements
  * with col > row are left unchanged (SYRK form; requires M == N geometry with
@@ -281,6 +287,20 @@ int gpx_gp_get_inv_Kxx(gpx_gp_t *gp, double *out, int64_t ld);
  * kernel, then one fused pass against kernel derivatives evaluated on the fly.  All NaN when the
  * factorisation failed (gp/gp.py:424-428).  Periodic kernel: d == 1 only. */
 int gpx_gp_dloglh_dtheta(gpx_gp_t *gp, double *out);
+/* dlh / d(theta) (gp/gp.py:435-465, gp_c.pyx:52-67) and d2lh / d(theta)^2 (gp/gp.py:467-502,
+ * gp_c.pyx:70-111), both HOST float64: dlh[n_params + 1], d2lh[(n_params + 1)^2] row-major, parameter
+ * order (kernel params..., s); either pointer may be NULL.  Device resident: K^-1, the products
+ * K^-1 dK_i (one MFMA GEMM per kernel parameter) and every trace / quadratic form stay in HBM, the
+ * kernel derivatives inside traces and quadratic forms are evaluated on the fly; only the scalars
+ * return.  All NaN when the factorisation failed (gp/gp.py:458-462,493-497).  Native kernels only
+ * (periodic: d == 1).  d2loglh (extension, may be NULL): the Hessian of the LOG marginal likelihood,
+ * d2lh / lh - (dlh / lh)(dlh / lh)^T, from the same pass; it stays finite where lh underflows to 0
+ * (log_lh < MIN, i.e. any n beyond a few hundred) and the reference's lh-scaled Hessian is all zeros. */
+int gpx_gp_dlh_d2lh(gpx_gp_t *gp, double *dlh, double *d2lh, double *d2loglh);
+/* d mean(xo) / d(theta) -> out (n_params + 1, m) HOST float64 (gp/gp.py:627-662, gp_c.pyx:114-131):
+ * dK_i(xo, x) alpha - K(xo, x) K^-1 dK_i alpha with fused on-the-fly mat-vecs and two triangular
+ * solves per parameter; no n x n matrix is formed. */
+int gpx_gp_dm_dtheta(gpx_gp_t *gp, const double *xo, int64_t m, double *out);
 /* Batched ML-II step (BASELINE config 5; the reference's inner step "set params -> read log_lh",
  * gp/gp.py:216-223,337-367, for a table of restarts on the handle's data set).
  * thetas: HOST (B, n_params + 1) row-major, rows (kernel params..., s); log_lh: HOST B doubles;

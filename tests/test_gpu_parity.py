@@ -871,3 +871,61 @@ def test_bench_two_ranks_on_one_gpu_from_a_plain_invocation():
     X, y, _ = orc.synth_inputs(2048, 4, 64)
     o = orc.OracleGP("gaussian", (1.0, 0.5 * np.sqrt(4)), X, y, 1.0)
     np.testing.assert_allclose(out["log_lh"], o.log_lh, rtol=1e-10)
+
+
+@pytest.mark.parametrize("kind,N,d", [("gaussian", 150, 3), ("gaussian", 700, 3), ("gaussian", 1536, 2),
+                                      ("periodic", 130, 1), ("periodic", 600, 1)])
+def test_device_second_derivative_stack_vs_oracle(kind, N, d):
+    """dlh_dtheta, d2lh_dtheta2, dm_dtheta on the device (csrc/gpx_deriv.hip: K^-1 and
+    the K^-1 dK_i products resident, traces / quadratic forms fused, only scalars return) against the
+    oracle's restatement of gp_c.pyx:52-131 (dense numpy products).  lh underflows to 0 beyond a few
+    hundred points (log_lh < MIN) and the reference's lh-scaled derivatives are then identically zero;
+    at those sizes the same device pass is checked through the Hessian of log_lh (extension) against
+    central differences of the device gradient (itself checked against the oracle), and dm_dtheta --
+    which carries no lh factor -- against the oracle and the mean's finite differences
+    (gp/tests/test_gp.py:146-174)."""
+    if kind == "gaussian":
+        X, y, Xo = orc.synth_inputs(N, d, 24)
+        prm, s = (0.9, 0.6 * np.sqrt(d)), 1.1
+        g = gp.GP(gp.GaussianKernel(*prm), X, y, s=s)
+    else:
+        X = np.sort(np.random.RandomState(3).uniform(-5, 5, N)); y = np.sin(X)
+        Xo = np.linspace(-4, 4, 24)
+        prm, s = (1.1, 0.8, 2.3), 0.9
+        g = gp.GP(gp.PeriodicKernel(*prm), X, y, s=s)
+    o = orc.OracleGP(kind, prm, X, y, s)
+    npar = len(g.params)
+    if N <= 150:
+        assert g.lh > 0                               # the reference's quantities are non-trivial here
+    if g.lh > 0:
+        scale = np.abs(o.d2lh_dtheta2).max()
+        np.testing.assert_allclose(g.dlh_dtheta, o.dlh_dtheta, rtol=1e-7, atol=1e-9 * np.abs(o.dlh_dtheta).max())
+        np.testing.assert_allclose(g.d2lh_dtheta2, o.d2lh_dtheta2, rtol=1e-6, atol=1e-8 * scale)
+        # d2lh = lh (H + g g^T) with H the Hessian of log_lh
+        gr = g.dloglh_dtheta
+        np.testing.assert_allclose(g.lh * (g.d2loglh_dtheta2 + np.outer(gr, gr)), o.d2lh_dtheta2,
+                                   rtol=1e-6, atol=1e-8 * scale)
+    else:
+        assert not g.d2lh_dtheta2.any() and not o.d2lh_dtheta2.any()
+    H = g.d2loglh_dtheta2
+    np.testing.assert_allclose(H, H.T, rtol=1e-9, atol=1e-10 * np.abs(H).max())
+    eps = 1e-5
+    fdH = np.empty((npar, npar))
+    for i in range(npar):
+        p0, p1 = g.params.copy(), g.params.copy()
+        p0[i] -= eps; p1[i] += eps
+        g0, g1 = g.copy(), g.copy()
+        g0.params = p0; g1.params = p1
+        fdH[i] = (g1.dloglh_dtheta - g0.dloglh_dtheta) / (2 * eps)
+    np.testing.assert_allclose(H, fdH, rtol=2e-5, atol=2e-6 * np.abs(H).max())
+    dm = g.dm_dtheta(Xo)
+    odm = o.dm_dtheta(Xo)
+    np.testing.assert_allclose(dm, odm, rtol=1e-6, atol=1e-8 * np.abs(odm).max())
+    eps = 1e-6
+    for i in range(npar):
+        p0, p1 = g.params.copy(), g.params.copy()
+        p0[i] -= eps; p1[i] += eps
+        g0, g1 = g.copy(), g.copy()
+        g0.params = p0; g1.params = p1
+        fd = (g1.mean(Xo) - g0.mean(Xo)) / (2 * eps)
+        np.testing.assert_allclose(dm[i], fd, rtol=1e-4, atol=1e-6 * max(1.0, np.abs(fd).max()))
