@@ -580,31 +580,6 @@ int gpx_gp_device_ptrs(gpx_gp_t *g, void **A, int64_t *lda, void **x, void **y, 
 }
 
 // ----------------------------------------------- host-pointer drop-ins --
-int gpx_kmat_host(int kernel, int member, double *out, const double *x1, int64_t n, const double *x2,
-                  int64_t m, int d, const double *params, double diag_add)
-{
-    GPX_TRY(ensure_device());
-    GPX_ARG(n >= 0 && m >= 0 && d >= 1, "bad dimensions");
-    if (n == 0 || m == 0) return GPX_OK;
-    GPX_ARG(out && x1 && x2 && params, "NULL pointer");
-    const int64_t ld = round_up(m, 16);
-    DevBuf a, b, o;
-    GPX_TRY(a.alloc((size_t)n * d * 8));
-    GPX_TRY(o.alloc((size_t)n * ld * 8));
-    GPX_HIP(hipMemcpy(a.p, x1, (size_t)n * d * 8, hipMemcpyHostToDevice));
-    const void *bp = a.p;
-    if (!(x2 == x1 && m == n)) {
-        GPX_TRY(b.alloc((size_t)m * d * 8));
-        GPX_HIP(hipMemcpy(b.p, x2, (size_t)m * d * 8, hipMemcpyHostToDevice));
-        bp = b.p;
-    }
-    GPX_TRY(gpx_d_kmat(GPX_F64, kernel, member, a.p, n, bp, m, d, params, diag_add, GPX_FULL, o.p, ld,
-                       nullptr));
-    GPX_HIP(hipMemcpy2D(out, (size_t)m * 8, o.p, (size_t)ld * 8, (size_t)m * 8, (size_t)n,
-                        hipMemcpyDeviceToHost));
-    return GPX_OK;
-}
-
 int gpx_gaussian_c(int member, double *out, const double *x1, int64_t n, const double *x2, int64_t m,
                    double h, double w)
 {

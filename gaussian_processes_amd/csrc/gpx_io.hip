@@ -1,0 +1,303 @@
+// gpx_io.hip -- persistence of a fitted GP and the out-of-core kernel-matrix build (gfx950).
+//
+// The reference persists a GP by pickling its memoised host arrays (gp/gp.py:78-92: `_memoized` holds
+// Kxx, Lxx, ... as numpy arrays).  Here the factor lives in HBM (32 GiB at n = 65536): pickling it
+// would need a full host copy.  Two streaming paths replace that:
+//   * gpx_gp_save / gpx_gp_load: a checkpoint file of the fitted handle -- header, x, y, alpha and the
+//     LOWER trapezoid of L in row blocks, moved through two pinned staging buffers (device -> host copy
+//     of block k+1 overlaps the file write of block k); host memory use is two blocks, whatever n is.
+//   * gpx_kmat_host (the host-pointer entry behind gaussian_c.K / periodic_c.K and their derivative
+//     members): the matrix is built in row panels on the device and streamed to the caller's buffer
+//     through the same double buffering, so an (n, m) result larger than HBM -- e.g. a numpy.memmap --
+//     is produced with two panels of device memory.
+#include "gpx_gp_internal.h"
+#include <stdio.h>
+#include <vector>
+
+extern "C" int gpx_gp_create(gpx_gp_t **out, int dtype, int kernel, int64_t n, int d);
+extern "C" int gpx_gp_destroy(gpx_gp_t *g);
+
+namespace gpx {
+
+struct FactorHeader {
+    char magic[8];                 // "GPXFACT1"
+    int32_t version, dtype, kernel, d, nparams, info;
+    int64_t n, block_rows;
+    double params[3], s, logdet, yta;
+};
+
+struct Pinned {
+    void *p = nullptr;
+    ~Pinned() { if (p) (void)hipHostFree(p); }
+    int alloc(size_t bytes)
+    {
+        hipError_t e = hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault);
+        if (e != hipSuccess) { p = nullptr; return hip_fail(e, "hipHostMalloc", __FILE__, __LINE__); }
+        return GPX_OK;
+    }
+};
+
+struct File {
+    FILE *f = nullptr;
+    ~File() { if (f) fclose(f); }
+};
+
+static int64_t io_block_rows(int64_t n, size_t es)
+{
+    const char *env = getenv("GPX_IO_BLOCK_BYTES");
+    const size_t target = env ? (size_t)atoll(env) : ((size_t)64 << 20);
+    int64_t r = (int64_t)(target / ((size_t)std::max<int64_t>(n, 1) * es));
+    return std::max<int64_t>(1, std::min<int64_t>(r, n));
+}
+
+template <typename T>
+__global__ void vec_to_f64(const T *__restrict__ src, double *__restrict__ dst, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (double)src[i];
+}
+template <typename T>
+__global__ void vec_from_f64(const double *__restrict__ src, T *__restrict__ dst, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (T)src[i];
+}
+
+static int vec_d2h_f64(gpx_gp *g, const void *dev, int64_t count, std::vector<double> &out)
+{
+    out.resize((size_t)count);
+    DevBuf tmp;
+    GPX_TRY(tmp.alloc((size_t)count * 8));
+    const unsigned nb = (unsigned)cdiv(count, 256);
+    if (g->dtype == GPX_F64) hipLaunchKernelGGL((vec_to_f64<double>), dim3(nb), dim3(256), 0, g->st, (const double *)dev, (double *)tmp.p, count);
+    else hipLaunchKernelGGL((vec_to_f64<float>), dim3(nb), dim3(256), 0, g->st, (const float *)dev, (double *)tmp.p, count);
+    GPX_LAUNCH_CHECK();
+    GPX_HIP(hipMemcpyAsync(out.data(), tmp.p, (size_t)count * 8, hipMemcpyDeviceToHost, g->st));
+    GPX_HIP(hipStreamSynchronize(g->st));
+    return GPX_OK;
+}
+
+static int vec_h2d_f64(gpx_gp *g, void *dev, int64_t count, const std::vector<double> &in)
+{
+    DevBuf tmp;
+    GPX_TRY(tmp.alloc((size_t)count * 8));
+    GPX_HIP(hipMemcpyAsync(tmp.p, in.data(), (size_t)count * 8, hipMemcpyHostToDevice, g->st));
+    const unsigned nb = (unsigned)cdiv(count, 256);
+    if (g->dtype == GPX_F64) hipLaunchKernelGGL((vec_from_f64<double>), dim3(nb), dim3(256), 0, g->st, (const double *)tmp.p, (double *)dev, count);
+    else hipLaunchKernelGGL((vec_from_f64<float>), dim3(nb), dim3(256), 0, g->st, (const double *)tmp.p, (float *)dev, count);
+    GPX_LAUNCH_CHECK();
+    GPX_HIP(hipStreamSynchronize(g->st));
+    return GPX_OK;
+}
+
+}  // namespace gpx
+
+using namespace gpx;
+
+extern "C" {
+
+int gpx_gp_save(gpx_gp_t *g, const char *path)
+{
+    GP_ENTER(g);
+    GPX_ARG(path && g->fitted, "gp is not fitted / path is NULL");
+    const int64_t n = g->n, lda = g->lda;
+    const size_t es = esize(g->dtype);
+    double h4[4];
+    GPX_HIP(hipMemcpyAsync(h4, g->scal, sizeof(h4), hipMemcpyDeviceToHost, g->st));
+    GPX_HIP(hipStreamSynchronize(g->st));
+    FactorHeader hd;
+    memset(&hd, 0, sizeof(hd));
+    memcpy(hd.magic, "GPXFACT1", 8);
+    hd.version = 1; hd.dtype = g->dtype; hd.kernel = g->kernel; hd.d = g->d;
+    hd.nparams = g->have_params ? g->nparams : 0;          // 0: fitted from an uploaded matrix (plugin kernel)
+    memcpy(&hd.info, &h4[3], sizeof(int));
+    hd.n = n; hd.block_rows = io_block_rows(n, es);
+    for (int i = 0; i < 3; ++i) hd.params[i] = g->have_params ? g->params[i] : 0.0;
+    hd.s = g->s; hd.logdet = h4[0]; hd.yta = h4[1];
+    File fp;
+    fp.f = fopen(path, "wb");
+    if (!fp.f) { set_error("gpx_gp_save: cannot open %s for writing", path); return GPX_ERR_ARG; }
+    bool ok = fwrite(&hd, sizeof(hd), 1, fp.f) == 1;
+    std::vector<double> v;
+    GPX_TRY(vec_d2h_f64(g, g->x, n * g->d, v)); ok = ok && fwrite(v.data(), 8, v.size(), fp.f) == v.size();
+    GPX_TRY(vec_d2h_f64(g, g->y, n, v));        ok = ok && fwrite(v.data(), 8, v.size(), fp.f) == v.size();
+    GPX_TRY(vec_d2h_f64(g, g->alpha, n, v));    ok = ok && fwrite(v.data(), 8, v.size(), fp.f) == v.size();
+    // the lower trapezoid of L, row block [r0, r1): columns [0, r1), packed row-major, two staging buffers
+    const int64_t R = hd.block_rows;
+    Pinned stage[2];
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    GPX_TRY(stage[0].alloc((size_t)R * n * es));
+    GPX_TRY(stage[1].alloc((size_t)R * n * es));
+    GPX_HIP(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
+    GPX_HIP(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+    const int64_t nblk = cdiv(n, R);
+    auto issue = [&](int64_t b) -> int {
+        const int64_t r0 = b * R, r1 = std::min(n, r0 + R);
+        GPX_HIP(hipMemcpy2DAsync(stage[b & 1].p, (size_t)r1 * es, (const char *)g->A + (size_t)r0 * lda * es,
+                                 (size_t)lda * es, (size_t)r1 * es, (size_t)(r1 - r0), hipMemcpyDeviceToHost, g->st));
+        GPX_HIP(hipEventRecord(ev[b & 1], g->st));
+        return GPX_OK;
+    };
+    int rc = issue(0);
+    for (int64_t b = 0; b < nblk && rc == GPX_OK && ok; ++b) {
+        if (b + 1 < nblk) rc = issue(b + 1);                        // in flight while block b is written
+        if (hipEventSynchronize(ev[b & 1]) != hipSuccess) { rc = GPX_ERR_HIP; break; }
+        const int64_t r0 = b * R, r1 = std::min(n, r0 + R);
+        char *buf = (char *)stage[b & 1].p;
+        for (int64_t r = r0; r < r1; ++r)                           // strict upper part of the diagonal block: zeros
+            memset(buf + ((size_t)(r - r0) * r1 + (size_t)r + 1) * es, 0, (size_t)(r1 - r - 1) * es);
+        ok = fwrite(buf, es, (size_t)(r1 - r0) * r1, fp.f) == (size_t)(r1 - r0) * r1;
+    }
+    (void)hipStreamSynchronize(g->st);
+    (void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]);
+    if (rc != GPX_OK) return rc;
+    if (!ok || fflush(fp.f) != 0) { set_error("gpx_gp_save: short write to %s", path); return GPX_ERR_ARG; }
+    return GPX_OK;
+}
+
+int gpx_gp_load(gpx_gp_t **out, const char *path)
+{
+    GPX_TRY(ensure_device());
+    GPX_ARG(out && path, "NULL argument");
+    *out = nullptr;
+    File fp;
+    fp.f = fopen(path, "rb");
+    if (!fp.f) { set_error("gpx_gp_load: cannot open %s", path); return GPX_ERR_ARG; }
+    FactorHeader hd;
+    if (fread(&hd, sizeof(hd), 1, fp.f) != 1 || memcmp(hd.magic, "GPXFACT1", 8) != 0 || hd.version != 1) {
+        set_error("gpx_gp_load: %s is not a gpx factor checkpoint", path);
+        return GPX_ERR_ARG;
+    }
+    gpx_gp_t *g = nullptr;
+    GPX_TRY(gpx_gp_create(&g, hd.dtype, hd.kernel, hd.n, hd.d));
+    struct Guard { gpx_gp_t *g; ~Guard() { if (g) gpx_gp_destroy(g); } } guard{g};
+    const int64_t n = g->n, lda = g->lda;
+    const size_t es = esize(g->dtype);
+    std::vector<double> v;
+    auto rd = [&](void *dev, int64_t count) -> int {
+        v.resize((size_t)count);
+        if (fread(v.data(), 8, v.size(), fp.f) != v.size()) { set_error("gpx_gp_load: %s is truncated", path); return GPX_ERR_ARG; }
+        return vec_h2d_f64(g, dev, count, v);
+    };
+    GPX_TRY(rd(g->x, n * g->d));
+    GPX_TRY(rd(g->y, n));
+    GPX_TRY(rd(g->alpha, n));
+    const int64_t R = hd.block_rows;
+    GPX_ARG(R >= 1 && R <= n, "corrupt header (block_rows)");
+    Pinned stage[2];
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    GPX_TRY(stage[0].alloc((size_t)R * n * es));
+    GPX_TRY(stage[1].alloc((size_t)R * n * es));
+    GPX_HIP(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
+    GPX_HIP(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+    const int64_t nblk = cdiv(n, R);
+    int rc = GPX_OK;
+    bool used[2] = {false, false};
+    for (int64_t b = 0; b < nblk && rc == GPX_OK; ++b) {
+        const int64_t r0 = b * R, r1 = std::min(n, r0 + R);
+        if (used[b & 1] && hipEventSynchronize(ev[b & 1]) != hipSuccess) { rc = GPX_ERR_HIP; break; }   // its upload is done
+        if (fread(stage[b & 1].p, es, (size_t)(r1 - r0) * r1, fp.f) != (size_t)(r1 - r0) * r1) {
+            set_error("gpx_gp_load: %s is truncated", path);
+            rc = GPX_ERR_ARG;
+            break;
+        }
+        if (hipMemcpy2DAsync((char *)g->A + (size_t)r0 * lda * es, (size_t)lda * es, stage[b & 1].p, (size_t)r1 * es,
+                             (size_t)r1 * es, (size_t)(r1 - r0), hipMemcpyHostToDevice, g->st) != hipSuccess ||
+            hipEventRecord(ev[b & 1], g->st) != hipSuccess) { rc = GPX_ERR_HIP; break; }
+        used[b & 1] = true;
+    }
+    (void)hipStreamSynchronize(g->st);
+    (void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]);
+    if (rc != GPX_OK) return rc;
+    double h4[4] = {hd.logdet, hd.yta, 0.0, 0.0};
+    memcpy(&h4[3], &hd.info, sizeof(int));
+    GPX_HIP(hipMemcpy(g->scal, h4, sizeof(h4), hipMemcpyHostToDevice));
+    for (int i = 0; i < 3; ++i) g->params[i] = hd.params[i];
+    g->s = hd.s;
+    g->have_data = true; g->have_params = hd.nparams > 0; g->fitted = true; g->have_K = false;
+    guard.g = nullptr;
+    *out = g;
+    return GPX_OK;
+}
+
+int gpx_gp_describe(gpx_gp_t *g, int *dtype, int *kernel, int64_t *n, int *d, double *params3, double *s)
+{
+    GP_ENTER(g);
+    if (dtype) *dtype = g->dtype;
+    if (kernel) *kernel = g->kernel;
+    if (n) *n = g->n;
+    if (d) *d = g->d;
+    if (params3) for (int i = 0; i < 3; ++i) params3[i] = g->params[i];
+    if (s) *s = g->s;
+    return GPX_OK;
+}
+
+int gpx_gp_get_xy(gpx_gp_t *g, double *x, double *y)
+{
+    GP_ENTER(g);
+    GPX_ARG(g->have_data, "no data in the handle");
+    std::vector<double> v;
+    if (x) { GPX_TRY(vec_d2h_f64(g, g->x, g->n * g->d, v)); memcpy(x, v.data(), v.size() * 8); }
+    if (y) { GPX_TRY(vec_d2h_f64(g, g->y, g->n, v)); memcpy(y, v.data(), v.size() * 8); }
+    return GPX_OK;
+}
+
+// ---- out-of-core kernel-matrix build: row panels, double buffered -------------------------------
+int gpx_kmat_host(int kernel, int member, double *out, const double *x1, int64_t n, const double *x2,
+                  int64_t m, int d, const double *params, double diag_add)
+{
+    GPX_TRY(ensure_device());
+    GPX_ARG(n >= 0 && m >= 0 && d >= 1, "bad dimensions");
+    if (n == 0 || m == 0) return GPX_OK;
+    GPX_ARG(out && x1 && x2 && params, "NULL pointer");
+    const int64_t ld = round_up(m, 16);
+    // panel height: GPX_KMAT_PANEL_BYTES of device memory per panel (default 256 MiB), a multiple of 64 rows
+    const char *env = getenv("GPX_KMAT_PANEL_BYTES");
+    const size_t target = env ? (size_t)atoll(env) : ((size_t)256 << 20);
+    int64_t R = (int64_t)(target / ((size_t)ld * 8));
+    R = std::max<int64_t>(64, R / 64 * 64);
+    R = std::min<int64_t>(R, round_up(n, 64));
+    DevBuf a, b, o[2];
+    GPX_TRY(a.alloc((size_t)n * d * 8));
+    GPX_HIP(hipMemcpy(a.p, x1, (size_t)n * d * 8, hipMemcpyHostToDevice));
+    const void *bp = a.p;
+    if (!(x2 == x1 && m == n)) {
+        GPX_TRY(b.alloc((size_t)m * d * 8));
+        GPX_HIP(hipMemcpy(b.p, x2, (size_t)m * d * 8, hipMemcpyHostToDevice));
+        bp = b.p;
+    }
+    const int64_t npan = cdiv(n, R);
+    GPX_TRY(o[0].alloc((size_t)R * ld * 8));
+    if (npan > 1) GPX_TRY(o[1].alloc((size_t)R * ld * 8));
+    hipStream_t st[2] = {nullptr, nullptr};
+    GPX_HIP(hipStreamCreateWithFlags(&st[0], hipStreamNonBlocking));
+    if (npan > 1) GPX_HIP(hipStreamCreateWithFlags(&st[1], hipStreamNonBlocking));
+    int rc = GPX_OK;
+    // panel p is built and copied out on stream p & 1: the build of panel p + 1 (other stream, other buffer)
+    // overlaps the copy of panel p; a buffer is reused only after its own stream has drained
+    // (the copy into pageable host memory blocks the calling thread, so the NEXT panel's build is
+    //  enqueued first; diag_add belongs to global (i, i) and is applied on the host at the end)
+    auto build = [&](int64_t p) -> int {
+        const int64_t r0 = p * R, rows = std::min(R, n - r0);
+        return gpx_d_kmat(GPX_F64, kernel, member, (const double *)a.p + r0 * d, rows, bp, m, d, params, 0.0, GPX_FULL,
+                          o[p & 1].p, ld, (void *)st[p & 1]);
+    };
+    rc = build(0);
+    for (int64_t p = 0; p < npan && rc == GPX_OK; ++p) {
+        const int64_t r0 = p * R, rows = std::min(R, n - r0);
+        if (p + 1 < npan) { rc = build(p + 1); if (rc != GPX_OK) break; }   // buffer (p+1)&1: its copy (panel p-1) is done
+        if (hipMemcpy2DAsync(out + (size_t)r0 * m, (size_t)m * 8, o[p & 1].p, (size_t)ld * 8, (size_t)m * 8, (size_t)rows,
+                             hipMemcpyDeviceToHost, st[p & 1]) != hipSuccess ||
+            hipStreamSynchronize(st[p & 1]) != hipSuccess) { rc = GPX_ERR_HIP; break; }
+    }
+    for (int i = 0; i < 2; ++i) if (st[i]) { (void)hipStreamSynchronize(st[i]); (void)hipStreamDestroy(st[i]); }
+    if (rc == GPX_ERR_HIP) { set_error("gpx_kmat_host: HIP failure while streaming panels"); return rc; }
+    if (rc != GPX_OK) return rc;
+    if (diag_add != 0.0) {
+        const int64_t k = std::min(n, m);
+        for (int64_t i = 0; i < k; ++i) out[(size_t)i * m + i] += diag_add;
+    }
+    return GPX_OK;
+}
+
+}  // extern "C"

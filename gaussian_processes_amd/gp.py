@@ -68,6 +68,16 @@ class _DeviceState(object):
             _lib.check(lib.gpx_set_device(int(device)))
         _lib.check(lib.gpx_gp_create(ctypes.byref(self.handle), dtype_id, kernel_id, n, d))
 
+    @classmethod
+    def adopt(cls, handle, key):
+        """Wrap an existing fitted gpx_gp handle (gpx_gp_load)."""
+        st = cls.__new__(cls)
+        st.key = key
+        st.handle = handle
+        st.data_version = st.params_version = st.fit_version = -1
+        st.info = None
+        return st
+
     def close(self):
         if self.handle:
             _lib.load().gpx_gp_destroy(self.handle)
@@ -496,6 +506,51 @@ class GP(object):
         dm = np.empty((len(self.params), xo.shape[0]))
         gp_c.dm_dtheta(self._y, Ki, Kj, Kjxo, Kxox, self._s, dm)
         return dm
+
+    # ---- persistence of the DEVICE state (extension; the reference pickles host arrays, gp/gp.py:78-92) ----
+    def save_fitted(self, path):
+        """Checkpoint the fitted device state -- x, y, alpha and the Cholesky factor -- to `path`,
+        streamed from HBM in row blocks (host memory use does not grow with n; a 32 GiB factor never
+        needs a host copy).  Restore with `GP.load_fitted`."""
+        st = self._fit()
+        _lib.check(_lib.load().gpx_gp_save(st.handle, str(path).encode()))
+
+    @classmethod
+    def load_fitted(cls, path, K=None, device=None):
+        """A GP restored from `save_fitted`: the factor goes straight back into HBM and nothing is
+        recomputed (`log_lh`, `mean`, `cov`, ... are served from the loaded state).  `K`: the kernel
+        object for a plugin kernel; built-in kernels are rebuilt from the file."""
+        lib = _lib.load()
+        if device is not None:
+            _lib.check(lib.gpx_set_device(int(device)))
+        h = ctypes.c_void_p()
+        _lib.check(lib.gpx_gp_load(ctypes.byref(h), str(path).encode()))
+        try:
+            dt, kid, n, d = ctypes.c_int(), ctypes.c_int(), ctypes.c_int64(), ctypes.c_int()
+            prm = np.zeros(3)
+            s = ctypes.c_double()
+            _lib.check(lib.gpx_gp_describe(h, ctypes.byref(dt), ctypes.byref(kid), ctypes.byref(n), ctypes.byref(d),
+                                           _lib.dptr(prm), ctypes.byref(s)))
+            x = np.empty((n.value, d.value), dtype=DTYPE)
+            y = np.empty(n.value, dtype=DTYPE)
+            _lib.check(lib.gpx_gp_get_xy(h, _lib.dptr(x), _lib.dptr(y)))
+            if K is None:
+                from .kernels import GaussianKernel, PeriodicKernel
+                K = GaussianKernel(*prm[:2]) if kid.value == _lib.KERNEL_GAUSSIAN else PeriodicKernel(*prm[:3])
+            obj = cls(K, x.ravel() if d.value == 1 else x, y, s=s.value,
+                      dtype="float64" if dt.value == _lib.F64 else "float32", device=device)
+            key = (obj._dtype, kid.value, obj._n, obj._d, obj._device)
+            st = _DeviceState.adopt(h, key)
+        except Exception:
+            lib.gpx_gp_destroy(h)
+            raise
+        info = ctypes.c_int(0)
+        _lib.check(lib.gpx_gp_info(st.handle, ctypes.byref(info)))
+        st.info = info.value
+        st.data_version = obj._data_version
+        st.params_version = st.fit_version = obj._version
+        obj._dev = st
+        return obj
 
     def fit_timing(self):
         """Milliseconds of the last device fit: kernel build, potrf, solve, reductions, total

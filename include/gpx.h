@@ -311,6 +311,17 @@ int gpx_gp_dm_dtheta(gpx_gp_t *gp, const double *xo, int64_t m, double *out);
  * launch covers all of them); chunked by free memory (cap: environment GPX_BATCH_MAX).
  * Leaves the handle's own fitted state untouched. */
 int gpx_gp_fit_batch(gpx_gp_t *gp, const double *thetas, int64_t B, double *log_lh, int *info);
+/* Checkpoint of a fitted handle (the reference persists by pickling its memoised host arrays,
+ * gp/gp.py:78-92; a 32 GiB factor cannot go that way).  File: header (dtype, kernel, n, d, params, s,
+ * logdet, y^T alpha, info), x, y, alpha as float64, then the LOWER trapezoid of L in row blocks
+ * (rows [r0, r1) x columns [0, r1), packed, handle dtype).  Streamed through two pinned staging
+ * buffers of GPX_IO_BLOCK_BYTES (default 64 MiB) each: host memory use does not grow with n.
+ * gpx_gp_load creates a NEW handle on the current device, fitted, without recomputing anything. */
+int gpx_gp_save(gpx_gp_t *gp, const char *path);
+int gpx_gp_load(gpx_gp_t **gp, const char *path);
+/* what a handle holds (any pointer may be NULL); x: (n, d), y: (n,) HOST float64 */
+int gpx_gp_describe(gpx_gp_t *gp, int *dtype, int *kernel, int64_t *n, int *d, double *params3, double *s);
+int gpx_gp_get_xy(gpx_gp_t *gp, double *x, double *y);
 /* timing of the last fit, milliseconds per stage (HIP events on the handle's
  * stream): [0] kernel build [1] potrf [2] solve [3] logdet+dot [4] total */
 int gpx_gp_last_timing(gpx_gp_t *gp, float *ms5);
@@ -335,7 +346,9 @@ int gpx_periodic_c_jacobian(double *out, const double *x1, int64_t n,
                             const double *x2, int64_t m, double h, double w, double p);
 int gpx_periodic_c_hessian(double *out, const double *x1, int64_t n,
                            const double *x2, int64_t m, double h, double w, double p);
-/* (n, d) generalisation of the two above (BASELINE configs use d = 8/16/32) */
+/* (n, d) generalisation of the two above (BASELINE configs use d = 8/16/32).  OUT-OF-CORE: the matrix
+ * is built on the device in row panels of GPX_KMAT_PANEL_BYTES (default 256 MiB) and streamed into
+ * `out` with double buffering, so (n, m) may exceed HBM -- `out` can be a memory-mapped file. */
 int gpx_kmat_host(int kernel, int member, double *out, const double *x1, int64_t n,
                   const double *x2, int64_t m, int d, const double *params,
                   double diag_add);

@@ -929,3 +929,62 @@ def test_device_second_derivative_stack_vs_oracle(kind, N, d):
         g0.params = p0; g1.params = p1
         fd = (g1.mean(Xo) - g0.mean(Xo)) / (2 * eps)
         np.testing.assert_allclose(dm[i], fd, rtol=1e-4, atol=1e-6 * max(1.0, np.abs(fd).max()))
+
+
+# ------------------------------------------------- persistence + out-of-core build --
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_save_load_fitted_roundtrip(tmp_path, dtype, monkeypatch):
+    """gpx_gp_save / gpx_gp_load: the factor streams HBM -> file -> HBM in row blocks (block size forced
+    small so that several blocks and a ragged last one occur); the restored GP serves log_lh, alpha, mean,
+    cov and Lxx bit-identically WITHOUT refitting."""
+    monkeypatch.setenv("GPX_IO_BLOCK_BYTES", str(300 * 1111 * 8))
+    N, d, m = 1111, 3, 20
+    X, y, Xo = orc.synth_inputs(N, d, m)
+    g = gp.GP(gp.GaussianKernel(1.1, 0.9), X, y, s=0.8, dtype=dtype)
+    ref = dict(llh=g.log_lh, alpha=g.inv_Kxx_y, mean=g.mean(Xo), cov=g.cov(Xo), L=g.Lxx)
+    path = tmp_path / "fit.gpx"
+    g.save_fitted(path)
+    es = 8 if dtype == "float64" else 4
+    assert os.path.getsize(path) < 0.8 * N * N * es + (N * (d + 2)) * 8 + 4096       # lower trapezoid, not n^2
+    h = gp.GP.load_fitted(path)
+    assert isinstance(h.K, gp.GaussianKernel) and np.array_equal(h.params, g.params)
+    npdt = np.float64 if dtype == "float64" else np.float32        # x, y come back as the device holds them
+    assert np.array_equal(h.x, g.x.astype(npdt).astype(np.float64)) and np.array_equal(h.y, g.y.astype(npdt).astype(np.float64))
+    fit_version = h._dev.fit_version
+    assert h.log_lh == ref["llh"]
+    np.testing.assert_array_equal(h.inv_Kxx_y, ref["alpha"])
+    np.testing.assert_array_equal(h.mean(Xo), ref["mean"])
+    np.testing.assert_array_equal(h.cov(Xo), ref["cov"])
+    np.testing.assert_array_equal(h.Lxx, ref["L"])
+    assert h._dev.fit_version == fit_version                 # served from the loaded state
+    h.s = 0.5                                                # and it is an ordinary GP afterwards
+    o = orc.OracleGP("gaussian", (1.1, 0.9), X, y, 0.5)
+    np.testing.assert_allclose(h.log_lh, o.log_lh, rtol=1e-10 if dtype == "float64" else 1e-4)
+    with pytest.raises(ValueError):
+        bad = tmp_path / "bad.gpx"
+        bad.write_bytes(b"not a checkpoint")
+        gp.GP.load_fitted(bad)
+
+
+def test_out_of_core_kernel_build_into_memmap(tmp_path, monkeypatch):
+    """gpx_kmat_host streams row panels (panel size forced to 64 rows: 11 panels, ragged last) into the
+    caller's buffer -- here a numpy.memmap, i.e. a matrix that never has to fit in HBM or host RAM."""
+    monkeypatch.setenv("GPX_KMAT_PANEL_BYTES", "1")
+    n, m, d = 700, 333, 5
+    rng = np.random.RandomState(4)
+    a = rng.uniform(-3, 3, (n, d)); b = rng.uniform(-3, 3, (m, d))
+    k = gp.GaussianKernel(0.9, 1.7)
+    out = np.memmap(tmp_path / "K.bin", dtype=np.float64, mode="w+", shape=(n, m))
+    k(a, b, out=out)
+    np.testing.assert_allclose(np.asarray(out), orc.kernel_matrix("gaussian", "K", a, b, k.params), rtol=1e-12, atol=1e-300)
+    monkeypatch.delenv("GPX_KMAT_PANEL_BYTES")
+    np.testing.assert_array_equal(k(a, b), np.asarray(out))            # one panel == many panels, bit for bit
+    np.testing.assert_array_equal(k.dK_dw(a, b), _panelled(monkeypatch, lambda: k.dK_dw(a, b)))
+
+
+def _panelled(monkeypatch, f):
+    monkeypatch.setenv("GPX_KMAT_PANEL_BYTES", "1")
+    try:
+        return f()
+    finally:
+        monkeypatch.delenv("GPX_KMAT_PANEL_BYTES")
