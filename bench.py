@@ -196,7 +196,9 @@ def main():
 
     if world > 1 or os.environ.get("GPX_BENCH_FORCE_DIST"):
         from gaussian_processes_amd import multi_gpu
-        result = multi_gpu.bench_distributed(args, X, y, Xo, params, s, dtid)
+        result = multi_gpu.bench_distributed(
+            args, X, y, Xo, params, s, dtid,
+            residual_check=lambda alpha: sampled_row_residual(X, y, alpha, h, w, s))
         if rank == 0:
             print(json.dumps(result))
         return

@@ -29,6 +29,10 @@ MEMBER_BY_NAME = {
     "d2K_dwdp": D2K_DWDP, "d2K_dpdw": D2K_DWDP, "d2K_dpdp": D2K_DPDP,
 }
 
+MG_ID_BYTES = 128
+MG_BCAST_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_size_t, c_int, c_void_p)
+MG_ALLREDUCE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p)
+
 c_double_p = POINTER(c_double)
 c_int_p = POINTER(c_int)
 
@@ -114,6 +118,17 @@ _SIGNATURES = {
     "gpx_gp_last_timing": (c_int, [c_void_p, POINTER(c_float)]),
     "gpx_gp_device_ptrs": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int64), POINTER(c_void_p),
                                    POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p)]),
+    "gpx_mg_unique_id": (c_int, [c_void_p]),
+    "gpx_mg_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_int64, c_int, c_int64, c_int, c_int, c_void_p]),
+    "gpx_mg_create_cb": (c_int, [POINTER(c_void_p), c_int, c_int, c_int64, c_int, c_int64, c_int, c_int,
+                                 c_void_p, c_void_p, c_void_p]),
+    "gpx_mg_destroy": (c_int, [c_void_p]),
+    "gpx_mg_set_data": (c_int, [c_void_p, c_double_p, c_double_p]),
+    "gpx_mg_fit": (c_int, [c_void_p, c_double_p, c_double, c_double_p, c_int_p]),
+    "gpx_mg_mean": (c_int, [c_void_p, c_double_p, c_double_p, c_int64, c_double_p]),
+    "gpx_mg_get_alpha": (c_int, [c_void_p, c_double_p]),
+    "gpx_mg_scalars": (c_int, [c_void_p, c_double_p, c_double_p, c_int_p]),
+    "gpx_mg_timing": (c_int, [c_void_p, c_double_p]),
     "gpx_gaussian_c": (c_int, [c_int, c_double_p, c_double_p, c_int64, c_double_p, c_int64,
                                c_double, c_double]),
     "gpx_gaussian_c_jacobian": (c_int, [c_double_p, c_double_p, c_int64, c_double_p, c_int64,

@@ -1,0 +1,658 @@
+// gpx_mg.hip -- multi-GPU GP fit / predict behind the C ABI: one process per GPU, the factorisation's
+// critical path (panel -> pack -> broadcast -> column update) driven from C on HIP streams with RCCL
+// collectives over xGMI (the reference has nothing distributed).
+//
+// Layout: 1-D block-cyclic block columns of width nb -- global block column j lives on rank j % P as local
+// block j / P (row-major local matrix: n rows x ceil(nblk / P) * nb columns).
+// Per panel k (right-looking, one-panel look-ahead, two panel buffers):
+//   owner(k)    factors its block column below the diagonal (potrf_panel) on the side stream Q,
+//               packs it into a contiguous (n - k0) x nb buffer (pack kernel),
+//   all ranks   receive it by a broadcast rooted at the owner, issued in ROW CHUNKS on Q: the owner of
+//               panel k+1 applies chunk c to its block column k+1 (main stream S) as soon as chunk c has
+//               landed, so that its column update hides under the tail of the transfer,
+//   all ranks   update their remaining block columns with the whole panel (one launch, syrk_bc) on S
+//               while Q already factors / broadcasts panel k+1.
+// Solves walk the block columns (one small all-reduce / broadcast per block), logdet and the posterior
+// mean are local sums plus one all-reduce.
+//
+// Communicator back-ends: (1) RCCL, loaded with dlopen at first use -- libgpx.so itself has no link-time
+// dependency on it, single-GPU users never load it; ranks are joined through an ncclUniqueId that the
+// host distributes out of band (gpx_mg_unique_id on rank 0).  (2) host callbacks on DEVICE pointers
+// (gpx_mg_create_cb): the same C schedule over any transport -- the tests run it with several ranks on
+// ONE GPU over gloo, which RCCL cannot do.
+#include "gpx_common.h"
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+#include <cmath>
+#include <vector>
+
+extern "C" int gpx_d_mean(int dtype, int kernel, const void *xo, int64_t m, const void *x, int64_t n, int d,
+                          const double *params, const void *alpha, void *out, void *stream);
+extern "C" int gpx_d_trsv_lower_cols(int dtype, const void *L, int64_t n, int64_t ldl, int64_t ncols, void *b,
+                                     void *x, void *stream);
+extern "C" int gpx_d_panel_gemv_t(int dtype, const void *Lp, int64_t ldl, int64_t rows, int64_t ncols,
+                                  const void *x, void *y, void *work, void *stream);
+
+namespace gpx {
+
+// ---- RCCL through dlopen ---------------------------------------------------------------------------
+struct Rccl {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+static Rccl g_rccl;
+
+static int rccl_load()
+{
+    if (g_rccl.lib) return GPX_OK;
+    const char *names[] = {getenv("GPX_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const char *nm : names) {
+        if (!nm || !*nm) continue;
+        h = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+        if (h) break;
+    }
+    if (!h) { set_error("cannot load RCCL (librccl.so.1): %s", dlerror()); return GPX_ERR_UNSUPPORTED; }
+#define GPX_SYM(field, name)                                                                  \
+    *(void **)(&g_rccl.field) = dlsym(h, name);                                               \
+    if (!g_rccl.field) { set_error("RCCL symbol %s not found", name); dlclose(h); return GPX_ERR_UNSUPPORTED; }
+    GPX_SYM(GetUniqueId, "ncclGetUniqueId");
+    GPX_SYM(CommInitRank, "ncclCommInitRank");
+    GPX_SYM(CommDestroy, "ncclCommDestroy");
+    GPX_SYM(Broadcast, "ncclBroadcast");
+    GPX_SYM(AllReduce, "ncclAllReduce");
+    GPX_SYM(Send, "ncclSend");
+    GPX_SYM(Recv, "ncclRecv");
+    GPX_SYM(GroupStart, "ncclGroupStart");
+    GPX_SYM(GroupEnd, "ncclGroupEnd");
+    GPX_SYM(GetErrorString, "ncclGetErrorString");
+#undef GPX_SYM
+    g_rccl.lib = h;
+    return GPX_OK;
+}
+
+#define GPX_NCCL(call)                                                                              \
+    do {                                                                                            \
+        ncclResult_t r__ = (call);                                                                  \
+        if (r__ != ncclSuccess) {                                                                   \
+            set_error("RCCL error %d (%s) in %s", (int)r__, g_rccl.GetErrorString(r__), #call);     \
+            return GPX_ERR_HIP;                                                                     \
+        }                                                                                           \
+    } while (0)
+
+// contiguous copy of a factored block column: rows x kb of A (ld) -> buf (ld nb), 16 bytes per lane
+template <typename T>
+__global__ __launch_bounds__(256) void pack_panel_kernel(const T *__restrict__ A, int64_t lda, T *__restrict__ buf,
+                                                         int64_t nb, int64_t rows, int kb)
+{
+    constexpr int V = 16 / sizeof(T);
+    const int chunks = (kb + V - 1) / V;                  // 16-byte chunks per row (kb % 16 == 0 except ragged last block)
+    const int64_t total = rows * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / chunks;
+        const int c = (int)(i - r * chunks) * V;
+        if (c + V <= kb) {
+            struct alignas(16) Q { T e[V]; };
+            *reinterpret_cast<Q *>(buf + r * nb + c) = *reinterpret_cast<const Q *>(A + r * lda + c);
+        } else {
+            for (int e = c; e < kb; ++e) buf[r * nb + e] = A[r * lda + e];
+        }
+    }
+}
+
+template <typename T>
+__global__ void axpy_slot_kernel(double *__restrict__ acc, const double *__restrict__ v)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) acc[0] += v[0];
+}
+
+__global__ void info_key_kernel(const int *__restrict__ info, int *__restrict__ key)
+{
+    // LAPACK info over all ranks = the SMALLEST positive one: max-reduce of (BIG - info) for info > 0
+    if (threadIdx.x == 0 && blockIdx.x == 0) key[0] = info[0] > 0 ? (1 << 30) - info[0] : 0;
+}
+
+}  // namespace gpx
+
+using namespace gpx;
+
+typedef int (*gpx_mg_bcast_fn)(void *user, void *dev_ptr, size_t bytes, int root, void *stream);
+typedef int (*gpx_mg_allreduce_fn)(void *user, void *dev_ptr, size_t count, int dtype, int op, void *stream);
+
+struct gpx_mg {
+    int device, dtype, kernel, d, world, rank;
+    int64_t n, nb, nblk, ncols_local, ld;
+    size_t es;
+    std::vector<int64_t> my_blocks;
+    // communicator
+    ncclComm_t comm = nullptr;
+    gpx_mg_bcast_fn cb_bcast = nullptr;
+    gpx_mg_allreduce_fn cb_allreduce = nullptr;
+    void *cb_user = nullptr;
+    int bcast_chunks = 4;
+    // device state
+    void *A = nullptr, *pbuf[2] = {nullptr, nullptr}, *x = nullptr, *y = nullptr, *w = nullptr, *z = nullptr,
+         *alpha = nullptr, *tmp = nullptr;
+    double *work = nullptr, *scal = nullptr;      // scal: [0] logdet block [1] y^T alpha [2] logdet acc [3] spare
+    int *info = nullptr;                          // [0] info [1] reduction key
+    hipStream_t S = nullptr, Q = nullptr;
+    std::vector<hipEvent_t> ev;                   // sync events (no timing), reused round-robin per fit
+    size_t ev_next = 0;
+    std::vector<hipEvent_t> tev;                  // timing events (pairs)
+    std::vector<int> tcls;                        // class of each timing pair
+    size_t tev_next = 0;
+    bool have_data = false, fitted = false;
+    double logdet = 0, yta = 0;
+    int info_host = 0;
+    double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool timing = true;
+
+    int64_t owner(int64_t j) const { return j % world; }
+    int64_t local_col(int64_t j) const { return (j / world) * nb; }
+    int64_t k0(int64_t j) const { return j * nb; }
+    int64_t kb(int64_t j) const { return std::min(nb, n - j * nb); }
+    int64_t first_local_block_after(int64_t k) const
+    {
+        for (size_t jl = 0; jl < my_blocks.size(); ++jl) if (my_blocks[jl] > k) return (int64_t)jl;
+        return -1;
+    }
+    char *Aat(int64_t r, int64_t c) const { return (char *)A + ((size_t)r * ld + c) * es; }
+};
+
+namespace gpx {
+
+enum { T_BUILD = 0, T_FACTOR = 1, T_SOLVE = 2, T_REDUCE = 3, T_PANEL = 4, T_PACK = 5, T_BCAST = 6, T_UPDATE = 7 };
+
+static int mg_event(gpx_mg *g, hipEvent_t *e)
+{
+    if (g->ev_next == g->ev.size()) {
+        hipEvent_t x;
+        GPX_HIP(hipEventCreateWithFlags(&x, hipEventDisableTiming));
+        g->ev.push_back(x);
+    }
+    *e = g->ev[g->ev_next++];
+    return GPX_OK;
+}
+
+// record a "now" on `to` after everything enqueued so far on `from`
+static int mg_order(gpx_mg *g, hipStream_t from, hipStream_t to)
+{
+    hipEvent_t e;
+    GPX_TRY(mg_event(g, &e));
+    GPX_HIP(hipEventRecord(e, from));
+    GPX_HIP(hipStreamWaitEvent(to, e, 0));
+    return GPX_OK;
+}
+
+struct MgTimer {
+    gpx_mg *g; hipStream_t st; size_t idx; bool on;
+    MgTimer(gpx_mg *g_, int cls, hipStream_t s) : g(g_), st(s), idx(0), on(g_->timing)
+    {
+        if (!on) return;
+        if (g->tev_next + 2 > g->tev.size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { (void)hipGetLastError(); on = false; return; }
+            g->tev.push_back(a); g->tev.push_back(b); g->tcls.push_back(cls);
+        }
+        idx = g->tev_next; g->tev_next += 2;
+        g->tcls[idx / 2] = cls;
+        (void)hipEventRecord(g->tev[idx], st);
+    }
+    ~MgTimer() { if (on) (void)hipEventRecord(g->tev[idx + 1], st); }
+};
+
+static ncclDataType_t nccl_type(int dtype) { return dtype == GPX_F64 ? ncclFloat64 : ncclFloat32; }
+
+// broadcast `count` elements of the handle's dtype at dev_ptr from `root`, on stream st
+static int mg_bcast(gpx_mg *g, void *dev_ptr, size_t count, int root, hipStream_t st)
+{
+    if (count == 0) return GPX_OK;
+    if (g->cb_bcast) {
+        if (g->world == 1) return GPX_OK;
+        const int rc = g->cb_bcast(g->cb_user, dev_ptr, count * g->es, root, (void *)st);
+        if (rc != 0) { set_error("broadcast callback failed (%d)", rc); return GPX_ERR_HIP; }
+        return GPX_OK;
+    }
+    if (g->world == 1 && !getenv("GPX_FORCE_COLLECTIVES")) return GPX_OK;
+    GPX_NCCL(g_rccl.Broadcast(dev_ptr, dev_ptr, count, nccl_type(g->dtype), root, g->comm, st));
+    return GPX_OK;
+}
+
+// op 0: sum of `count` elements of dtype (GPX_F64 / GPX_F32 / 2 = int32); op 1: max
+static int mg_allreduce(gpx_mg *g, void *dev_ptr, size_t count, int dtype, int op, hipStream_t st)
+{
+    if (count == 0) return GPX_OK;
+    if (g->cb_allreduce) {
+        if (g->world == 1) return GPX_OK;
+        const int rc = g->cb_allreduce(g->cb_user, dev_ptr, count, dtype, op, (void *)st);
+        if (rc != 0) { set_error("all-reduce callback failed (%d)", rc); return GPX_ERR_HIP; }
+        return GPX_OK;
+    }
+    if (g->world == 1 && !getenv("GPX_FORCE_COLLECTIVES")) return GPX_OK;
+    const ncclDataType_t t = dtype == GPX_F64 ? ncclFloat64 : (dtype == GPX_F32 ? ncclFloat32 : ncclInt32);
+    GPX_NCCL(g_rccl.AllReduce(dev_ptr, dev_ptr, count, t, op == 0 ? ncclSum : ncclMax, g->comm, st));
+    return GPX_OK;
+}
+
+static int mg_pack(gpx_mg *g, int64_t r0, int64_t cl, int64_t rows, int64_t kb, void *buf, hipStream_t st)
+{
+    const unsigned blocks = (unsigned)std::min<int64_t>(cdiv(rows * cdiv(kb, 2), 256), 4096);
+    if (g->dtype == GPX_F64)
+        hipLaunchKernelGGL((pack_panel_kernel<double>), dim3(blocks), dim3(256), 0, st, (const double *)g->Aat(r0, cl), g->ld,
+                           (double *)buf, g->nb, rows, (int)kb);
+    else
+        hipLaunchKernelGGL((pack_panel_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float *)g->Aat(r0, cl), g->ld,
+                           (float *)buf, g->nb, rows, (int)kb);
+    GPX_LAUNCH_CHECK();
+    return GPX_OK;
+}
+
+// Factor (owner), pack (owner) and broadcast block column j into buf, on Q.  chunk_ev: when non-null the
+// broadcast goes out in row chunks and an event is recorded after each (chunk_rows[c] = first row AFTER chunk c,
+// relative to the panel's first row).
+static int mg_factor_and_bcast(gpx_mg *g, int64_t j, void *buf, std::vector<hipEvent_t> *chunk_ev,
+                               std::vector<int64_t> *chunk_end)
+{
+    const int64_t r0 = g->k0(j), kb = g->kb(j), rows = g->n - r0;
+    hipStream_t Q = g->Q;
+    if (g->owner(j) == g->rank) {
+        const int64_t cl = g->local_col(j);
+        { MgTimer t(g, T_PANEL, Q); GPX_TRY(potrf_panel(g->dtype, g->A, g->ld, g->n, r0, cl, kb, g->info, Q)); }
+        { MgTimer t(g, T_PACK, Q); GPX_TRY(mg_pack(g, r0, cl, rows, kb, buf, Q)); }
+    }
+    // row chunks: the first one covers at least the next block column's diagonal rows (its B-operand rows)
+    int nch = (chunk_ev && g->world > 1) ? g->bcast_chunks : 1;
+    const int64_t min_rows = std::min(rows, std::max<int64_t>(2 * g->nb, 1024));
+    if (rows < 4 * min_rows) nch = 1;
+    MgTimer t(g, T_BCAST, Q);
+    int64_t done = 0;
+    for (int c = 0; c < nch; ++c) {
+        int64_t end = (c + 1 == nch) ? rows : std::max(min_rows, (rows * (c + 1) / nch) / 128 * 128);
+        end = std::min(end, rows);
+        if (end <= done) continue;
+        GPX_TRY(mg_bcast(g, (char *)buf + (size_t)done * g->nb * g->es, (size_t)(end - done) * g->nb, (int)g->owner(j), Q));
+        done = end;
+        if (chunk_ev) {
+            hipEvent_t e;
+            GPX_TRY(mg_event(g, &e));
+            GPX_HIP(hipEventRecord(e, Q));
+            chunk_ev->push_back(e);
+            chunk_end->push_back(end);
+        }
+    }
+    return GPX_OK;
+}
+
+static int mg_build(gpx_mg *g, const double *params, double s)
+{
+    MgTimer t(g, T_BUILD, g->S);
+    for (int64_t j : g->my_blocks) {
+        const int64_t r0 = g->k0(j), kb = g->kb(j), cl = g->local_col(j);
+        // A[r0:n, cl:cl+kb] <- K(x[r0:n], x[r0:r0+kb]) + s^2 on the block's diagonal; lower tiles only
+        GPX_TRY(kmat(g->dtype, g->kernel, GPX_K, (const char *)g->x + (size_t)r0 * g->d * g->es, g->n - r0,
+                     (const char *)g->x + (size_t)r0 * g->d * g->es, kb, g->d, params, s * s, GPX_LOWER, g->Aat(r0, cl),
+                     g->ld, g->S));
+    }
+    return GPX_OK;
+}
+
+static int mg_factor(gpx_mg *g)
+{
+    hipStream_t S = g->S, Q = g->Q;
+    MgTimer tf(g, T_FACTOR, S);
+    GPX_TRY(mg_order(g, S, Q));                                   // the kernel build is done
+    std::vector<hipEvent_t> cev; std::vector<int64_t> cend;
+    GPX_TRY(mg_factor_and_bcast(g, 0, g->pbuf[0], &cev, &cend));
+    hipEvent_t readers_done[2] = {nullptr, nullptr};              // last update that read pbuf[i]
+    for (int64_t k = 0; k < g->nblk; ++k) {
+        const int64_t k0 = g->k0(k), kb = g->kb(k), r = k0 + kb;
+        if (r >= g->n) {                                          // last panel: S must see it before the solves
+            GPX_HIP(hipStreamWaitEvent(S, cev.back(), 0));
+            break;
+        }
+        void *Pk = g->pbuf[k % 2];
+        const int64_t nxt = k + 1;
+        const bool own_next = g->owner(nxt) == g->rank;
+        int64_t jl_first = g->first_local_block_after(k);
+        if (own_next) {
+            // block column k+1 first, chunk by chunk as the panel lands (rows of chunk c: [lo, hi) global)
+            const int64_t cl = g->local_col(nxt);
+            MgTimer t(g, T_UPDATE, S);
+            int64_t lo = r;
+            for (size_t c = 0; c < cev.size(); ++c) {
+                const int64_t hi = k0 + cend[c];
+                GPX_HIP(hipStreamWaitEvent(S, cev[c], 0));
+                if (hi > lo)
+                    GPX_TRY(syrk_bc(g->dtype, hi, lo, g->A, g->ld, cl, cl + g->nb, Pk, g->nb, k0, kb, g->nb, g->world,
+                                    g->rank, S));
+                lo = std::max(lo, hi);
+            }
+            GPX_TRY(mg_order(g, S, Q));
+            jl_first = g->first_local_block_after(nxt);
+        } else {
+            GPX_HIP(hipStreamWaitEvent(S, cev.back(), 0));        // the whole panel k is here
+        }
+        if (readers_done[nxt % 2]) GPX_HIP(hipStreamWaitEvent(Q, readers_done[nxt % 2], 0));   // update k-1 has let go of that buffer
+        std::vector<hipEvent_t> nev; std::vector<int64_t> nend;
+        GPX_TRY(mg_factor_and_bcast(g, nxt, g->pbuf[nxt % 2], &nev, &nend));
+        if (jl_first >= 0) {
+            MgTimer t(g, T_UPDATE, S);
+            GPX_TRY(syrk_bc(g->dtype, g->n, r, g->A, g->ld, jl_first * g->nb, g->ncols_local, Pk, g->nb, k0, kb, g->nb,
+                            g->world, g->rank, S));
+        }
+        hipEvent_t e;
+        GPX_TRY(mg_event(g, &e));
+        GPX_HIP(hipEventRecord(e, S));
+        readers_done[k % 2] = e;
+        cev.swap(nev); cend.swap(nend);
+    }
+    GPX_TRY(mg_order(g, Q, S));
+    return GPX_OK;
+}
+
+static int mg_solve(gpx_mg *g)
+{
+    hipStream_t S = g->S;
+    MgTimer t(g, T_SOLVE, S);
+    const int64_t n = g->n;
+    if (g->rank == 0) GPX_HIP(hipMemcpyAsync(g->w, g->y, (size_t)n * g->es, hipMemcpyDeviceToDevice, S));
+    else GPX_HIP(hipMemsetAsync(g->w, 0, (size_t)n * g->es, S));
+    for (int64_t j = 0; j < g->nblk; ++j) {                        // forward: L z = y
+        const int64_t r0 = g->k0(j), kb = g->kb(j);
+        GPX_TRY(mg_allreduce(g, (char *)g->w + (size_t)r0 * g->es, (size_t)kb, g->dtype, 0, S));
+        if (g->owner(j) == g->rank)
+            GPX_TRY(gpx_d_trsv_lower_cols(g->dtype, g->Aat(r0, g->local_col(j)), n - r0, g->ld, kb,
+                                          (char *)g->w + (size_t)r0 * g->es, (char *)g->z + (size_t)r0 * g->es, (void *)S));
+    }
+    for (int64_t j = g->nblk - 1; j >= 0; --j) {                   // backward: L^T alpha = z
+        const int64_t r0 = g->k0(j), kb = g->kb(j);
+        if (g->owner(j) == g->rank) {
+            const int64_t cl = g->local_col(j), below = n - r0 - kb;
+            GPX_HIP(hipMemcpyAsync(g->tmp, (char *)g->z + (size_t)r0 * g->es, (size_t)kb * g->es, hipMemcpyDeviceToDevice, S));
+            if (below > 0)
+                GPX_TRY(gpx_d_panel_gemv_t(g->dtype, g->Aat(r0 + kb, cl), g->ld, below, kb,
+                                           (char *)g->alpha + (size_t)(r0 + kb) * g->es, g->tmp, g->work, (void *)S));
+            GPX_TRY(trsv_lower(g->dtype, g->Aat(r0, cl), kb, g->ld, g->tmp, (char *)g->alpha + (size_t)r0 * g->es, 1, S));
+        }
+        GPX_TRY(mg_bcast(g, (char *)g->alpha + (size_t)r0 * g->es, (size_t)kb, (int)g->owner(j), S));
+    }
+    return GPX_OK;
+}
+
+static int mg_reduce(gpx_mg *g)
+{
+    hipStream_t S = g->S;
+    {
+        MgTimer t(g, T_REDUCE, S);
+        GPX_HIP(hipMemsetAsync(g->scal + 2, 0, sizeof(double), S));
+        for (int64_t j : g->my_blocks) {
+            GPX_TRY(logdet_chol(g->dtype, g->Aat(g->k0(j), g->local_col(j)), g->kb(j), g->ld, g->scal + 0, S));
+            hipLaunchKernelGGL((axpy_slot_kernel<double>), dim3(1), dim3(64), 0, S, g->scal + 2, g->scal + 0);
+        }
+        GPX_LAUNCH_CHECK();
+        GPX_TRY(dot(g->dtype, g->y, g->alpha, g->n, g->scal + 1, S));
+        GPX_TRY(mg_allreduce(g, g->scal + 2, 1, GPX_F64, 0, S));
+        hipLaunchKernelGGL(info_key_kernel, dim3(1), dim3(64), 0, S, g->info, g->info + 1);
+        GPX_LAUNCH_CHECK();
+        GPX_TRY(mg_allreduce(g, g->info + 1, 1, 2, 1, S));
+    }
+    double h[4]; int hi[2];
+    GPX_HIP(hipMemcpyAsync(h, g->scal, sizeof(h), hipMemcpyDeviceToHost, S));
+    GPX_HIP(hipMemcpyAsync(hi, g->info, sizeof(hi), hipMemcpyDeviceToHost, S));
+    GPX_HIP(hipStreamSynchronize(S));
+    GPX_HIP(hipStreamSynchronize(g->Q));
+    g->logdet = h[2]; g->yta = h[1];
+    g->info_host = hi[1] == 0 ? 0 : (1 << 30) - hi[1];
+    return GPX_OK;
+}
+
+static int mg_alloc(gpx_mg *g)
+{
+    const size_t es = g->es;
+    const int64_t n = g->n;
+#define MG_ALLOC(field, bytes) GPX_HIP(hipMalloc((void **)&g->field, (bytes) ? (bytes) : 16))
+    MG_ALLOC(A, (size_t)n * g->ld * es);
+    MG_ALLOC(pbuf[0], (size_t)n * g->nb * es);
+    MG_ALLOC(pbuf[1], (size_t)n * g->nb * es);
+    MG_ALLOC(x, (size_t)n * g->d * es);
+    MG_ALLOC(y, (size_t)n * es);
+    MG_ALLOC(w, (size_t)n * es);
+    MG_ALLOC(z, (size_t)n * es);
+    MG_ALLOC(alpha, (size_t)n * es);
+    MG_ALLOC(tmp, (size_t)g->nb * es);
+    MG_ALLOC(work, (size_t)std::max<int64_t>(1, cdiv(n, 256)) * g->nb * sizeof(double));
+    MG_ALLOC(scal, 4 * sizeof(double));
+    MG_ALLOC(info, 4 * sizeof(int));
+#undef MG_ALLOC
+    GPX_HIP(hipMemset(g->info, 0, 4 * sizeof(int)));
+    GPX_HIP(hipStreamCreateWithFlags(&g->S, hipStreamNonBlocking));
+    int least = 0, greatest = 0;
+    GPX_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    GPX_HIP(hipStreamCreateWithPriority(&g->Q, hipStreamNonBlocking, greatest));   // panel + broadcast: critical path
+    return GPX_OK;
+}
+
+static int mg_new(gpx_mg **out, int dtype, int kernel, int64_t n, int d, int64_t nb, int world, int rank)
+{
+    GPX_TRY(ensure_device());
+    GPX_ARG(out, "mg is NULL");
+    *out = nullptr;
+    GPX_ARG(dtype == GPX_F64 || dtype == GPX_F32, "dtype must be GPX_F64 or GPX_F32");
+    GPX_ARG(kernel == GPX_KERNEL_GAUSSIAN || kernel == GPX_KERNEL_PERIODIC, "unknown kernel family");
+    GPX_ARG(n >= 1 && d >= 1, "need n >= 1 and d >= 1");
+    GPX_ARG(world >= 1 && rank >= 0 && rank < world, "bad world / rank");
+    GPX_ARG(nb >= 64 && nb % 64 == 0 && 1024 % nb == 0, "nb must be 64 / 128 / 256 / 512 / 1024");
+    gpx_mg *g = new gpx_mg();
+    g->dtype = dtype; g->kernel = kernel; g->n = n; g->d = d; g->nb = nb; g->world = world; g->rank = rank;
+    g->es = esize(dtype);
+    if (hipGetDevice(&g->device) != hipSuccess) { (void)hipGetLastError(); g->device = 0; }
+    g->nblk = cdiv(n, nb);
+    for (int64_t j = rank; j < g->nblk; j += world) g->my_blocks.push_back(j);
+    g->ncols_local = std::max<int64_t>(1, (int64_t)g->my_blocks.size()) * nb;
+    g->ld = g->ncols_local;
+    if (const char *env = getenv("GPX_MG_BCAST_CHUNKS")) g->bcast_chunks = std::max(1, std::min(16, atoi(env)));
+    g->timing = getenv("GPX_MG_NO_TIMING") == nullptr;
+    *out = g;
+    return GPX_OK;
+}
+
+}  // namespace gpx
+
+#define MG_ENTER(g)                                                          \
+    GPX_ARG((g) != nullptr, "mg is NULL");                                   \
+    gpx::DeviceGuard guard__((g)->device);                                   \
+    if (guard__.rc != GPX_OK) return guard__.rc
+
+extern "C" {
+
+int gpx_mg_unique_id(void *id128)
+{
+    GPX_ARG(id128, "id is NULL");
+    GPX_TRY(ensure_device());
+    GPX_TRY(rccl_load());
+    ncclUniqueId id;
+    GPX_NCCL(g_rccl.GetUniqueId(&id));
+    memcpy(id128, &id, sizeof(id));
+    return GPX_OK;
+}
+
+int gpx_mg_destroy(gpx_mg_t *g)
+{
+    if (!g) return GPX_OK;
+    gpx::DeviceGuard guard__(g->device);
+    if (g->S) (void)hipStreamSynchronize(g->S);
+    if (g->Q) (void)hipStreamSynchronize(g->Q);
+    if (g->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(g->comm);
+    void *bufs[] = {g->A, g->pbuf[0], g->pbuf[1], g->x, g->y, g->w, g->z, g->alpha, g->tmp, g->work, g->scal, g->info};
+    for (void *b : bufs) if (b) (void)hipFree(b);
+    for (hipEvent_t e : g->ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : g->tev) (void)hipEventDestroy(e);
+    if (g->S) (void)hipStreamDestroy(g->S);
+    if (g->Q) (void)hipStreamDestroy(g->Q);
+    delete g;
+    return GPX_OK;
+}
+
+int gpx_mg_create(gpx_mg_t **out, int dtype, int kernel, int64_t n, int d, int64_t nb, int world, int rank,
+                  const void *id128)
+{
+    GPX_ARG(id128, "the RCCL unique id is NULL");
+    GPX_TRY(mg_new(out, dtype, kernel, n, d, nb, world, rank));
+    gpx_mg *g = *out;
+    int rc = rccl_load();
+    if (rc == GPX_OK) rc = mg_alloc(g);
+    if (rc == GPX_OK) {
+        ncclUniqueId id;
+        memcpy(&id, id128, sizeof(id));
+        ncclResult_t r = g_rccl.CommInitRank(&g->comm, world, id, rank);
+        if (r != ncclSuccess) { set_error("ncclCommInitRank failed: %s", g_rccl.GetErrorString(r)); rc = GPX_ERR_HIP; }
+    }
+    if (rc != GPX_OK) { gpx_mg_destroy(g); *out = nullptr; }
+    return rc;
+}
+
+int gpx_mg_create_cb(gpx_mg_t **out, int dtype, int kernel, int64_t n, int d, int64_t nb, int world, int rank,
+                     gpx_mg_bcast_fn bcast, gpx_mg_allreduce_fn allreduce, void *user)
+{
+    GPX_ARG(world == 1 || (bcast && allreduce), "callbacks are NULL");
+    GPX_TRY(mg_new(out, dtype, kernel, n, d, nb, world, rank));
+    gpx_mg *g = *out;
+    g->cb_bcast = bcast ? bcast : [](void *, void *, size_t, int, void *) { return 0; };
+    g->cb_allreduce = allreduce ? allreduce : [](void *, void *, size_t, int, int, void *) { return 0; };
+    g->cb_user = user;
+    const int rc = mg_alloc(g);
+    if (rc != GPX_OK) { gpx_mg_destroy(g); *out = nullptr; }
+    return rc;
+}
+
+int gpx_mg_set_data(gpx_mg_t *g, const double *x, const double *y)
+{
+    MG_ENTER(g);
+    GPX_ARG(x && y, "NULL argument");
+    const int64_t n = g->n;
+    if (g->dtype == GPX_F64) {
+        GPX_HIP(hipMemcpy(g->x, x, (size_t)n * g->d * 8, hipMemcpyHostToDevice));
+        GPX_HIP(hipMemcpy(g->y, y, (size_t)n * 8, hipMemcpyHostToDevice));
+    } else {
+        std::vector<float> hx((size_t)n * g->d), hy((size_t)n);
+        for (size_t i = 0; i < hx.size(); ++i) hx[i] = (float)x[i];
+        for (size_t i = 0; i < hy.size(); ++i) hy[i] = (float)y[i];
+        GPX_HIP(hipMemcpy(g->x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
+        GPX_HIP(hipMemcpy(g->y, hy.data(), hy.size() * 4, hipMemcpyHostToDevice));
+    }
+    g->have_data = true; g->fitted = false;
+    return GPX_OK;
+}
+
+int gpx_mg_fit(gpx_mg_t *g, const double *params, double s, double *log_lh, int *info)
+{
+    MG_ENTER(g);
+    GPX_ARG(g->have_data && params, "set_data must be called before fit");
+    GPX_ARG(s >= 0, "invalid value for s");
+    g->ev_next = 0; g->tev_next = 0;
+    GPX_HIP(hipMemsetAsync(g->info, 0, 4 * sizeof(int), g->S));
+    GPX_TRY(mg_build(g, params, s));
+    GPX_TRY(mg_factor(g));
+    GPX_TRY(mg_solve(g));
+    GPX_TRY(mg_reduce(g));
+    g->fitted = true;
+    // stage and chain times of this rank (HIP events, all streams drained by mg_reduce)
+    for (double &v : g->ms) v = 0;
+    for (size_t i = 0; i + 1 < g->tev_next; i += 2) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, g->tev[i], g->tev[i + 1]) == hipSuccess) g->ms[g->tcls[i / 2]] += t;
+        else (void)hipGetLastError();
+    }
+    if (info) *info = g->info_host;
+    if (log_lh) {
+        // gp/gp.py:362-365 and gp_c.pyx:22-29
+        if (g->info_host != 0 || !(g->logdet >= GPX_MIN_LOG)) *log_lh = -INFINITY;
+        else *log_lh = -0.5 * g->yta - 0.5 * g->logdet - 0.5 * (double)g->n * log(2 * M_PI);
+    }
+    return GPX_OK;
+}
+
+int gpx_mg_mean(gpx_mg_t *g, const double *params, const double *xo, int64_t m, double *out)
+{
+    MG_ENTER(g);
+    GPX_ARG(g->fitted && params, "mg is not fitted");
+    GPX_ARG(m >= 0 && (m == 0 || (xo && out)), "bad arguments");
+    if (m == 0) return GPX_OK;
+    const size_t es = g->es;
+    void *dxo = nullptr, *dout = nullptr;
+    GPX_HIP(hipMalloc(&dxo, (size_t)m * g->d * es));
+    hipError_t e = hipMalloc(&dout, (size_t)m * es);
+    if (e != hipSuccess) { (void)hipFree(dxo); return hip_fail(e, "hipMalloc", __FILE__, __LINE__); }
+    int rc = GPX_OK;
+    {
+        if (g->dtype == GPX_F64) e = hipMemcpy(dxo, xo, (size_t)m * g->d * 8, hipMemcpyHostToDevice);
+        else {
+            std::vector<float> h((size_t)m * g->d);
+            for (size_t i = 0; i < h.size(); ++i) h[i] = (float)xo[i];
+            e = hipMemcpy(dxo, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+        }
+        if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy", __FILE__, __LINE__);
+    }
+    // every rank evaluates a slice of the test points, one all-reduce assembles the vector
+    const int64_t per = cdiv(m, g->world);
+    const int64_t m0 = std::min(m, g->rank * per), m1 = std::min(m, (g->rank + 1) * per);
+    if (rc == GPX_OK && hipMemsetAsync(dout, 0, (size_t)m * es, g->S) != hipSuccess) rc = GPX_ERR_HIP;
+    if (rc == GPX_OK && m1 > m0)
+        rc = gpx_d_mean(g->dtype, g->kernel, (char *)dxo + (size_t)m0 * g->d * es, m1 - m0, g->x, g->n, g->d, params, g->alpha,
+                        (char *)dout + (size_t)m0 * es, (void *)g->S);
+    if (rc == GPX_OK) rc = mg_allreduce(g, dout, (size_t)m, g->dtype, 0, g->S);
+    if (rc == GPX_OK) {
+        if (g->dtype == GPX_F64) e = hipMemcpyAsync(out, dout, (size_t)m * 8, hipMemcpyDeviceToHost, g->S);
+        std::vector<float> h;
+        if (g->dtype != GPX_F64) { h.resize((size_t)m); e = hipMemcpyAsync(h.data(), dout, (size_t)m * 4, hipMemcpyDeviceToHost, g->S); }
+        if (e == hipSuccess) e = hipStreamSynchronize(g->S);
+        if (e != hipSuccess) rc = hip_fail(e, "mean copy-out", __FILE__, __LINE__);
+        else if (g->dtype != GPX_F64) for (int64_t i = 0; i < m; ++i) out[i] = (double)h[(size_t)i];
+    }
+    (void)hipStreamSynchronize(g->S);
+    (void)hipFree(dxo); (void)hipFree(dout);
+    return rc;
+}
+
+int gpx_mg_get_alpha(gpx_mg_t *g, double *out)
+{
+    MG_ENTER(g);
+    GPX_ARG(g->fitted && out, "bad arguments");
+    if (g->dtype == GPX_F64) {
+        GPX_HIP(hipMemcpy(out, g->alpha, (size_t)g->n * 8, hipMemcpyDeviceToHost));
+    } else {
+        std::vector<float> h((size_t)g->n);
+        GPX_HIP(hipMemcpy(h.data(), g->alpha, h.size() * 4, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < g->n; ++i) out[i] = (double)h[(size_t)i];
+    }
+    return GPX_OK;
+}
+
+int gpx_mg_scalars(gpx_mg_t *g, double *logdet, double *yta, int *info)
+{
+    MG_ENTER(g);
+    GPX_ARG(g->fitted, "mg is not fitted");
+    if (logdet) *logdet = g->logdet;
+    if (yta) *yta = g->yta;
+    if (info) *info = g->info_host;
+    return GPX_OK;
+}
+
+int gpx_mg_timing(gpx_mg_t *g, double *ms8)
+{
+    MG_ENTER(g);
+    GPX_ARG(g->fitted && ms8, "bad arguments");
+    for (int i = 0; i < 8; ++i) ms8[i] = g->ms[i];
+    return GPX_OK;
+}
+
+}  // extern "C"

@@ -423,89 +423,247 @@ class DistributedGP(object):
         return out
 
 
+# ------------------------------------------------- the C schedule (gpx_mg_*, RCCL) --
+class GlooCallbacks(object):
+    """Host-side collectives for gpx_mg_create_cb: device pointer -> host staging -> torch.distributed
+    (any CPU backend) -> device.  Slow by construction; it exists so that the C schedule can be run with
+    several ranks on ONE GPU (RCCL cannot put two ranks on a device) and verified in tests/"""
+
+    _NP = {_lib.F64: np.float64, _lib.F32: np.float32, 2: np.int32}
+
+    def __init__(self, dist):
+        import torch
+        self.torch, self.dist = torch, dist
+        self.rank = dist.get_rank()
+        self.lib = _lib.load()
+        self.error = None
+        self.bcast = _lib.MG_BCAST_FN(self._bcast)
+        self.allreduce = _lib.MG_ALLREDUCE_FN(self._allreduce)
+
+    def _bcast(self, user, dev_ptr, nbytes, root, stream):
+        try:
+            buf = np.empty(nbytes, dtype=np.uint8)
+            _lib.check(self.lib.gpx_stream_sync(stream))
+            if self.rank == root:
+                _lib.check(self.lib.gpx_memcpy_d2h(buf.ctypes.data_as(ctypes.c_void_p), dev_ptr, nbytes, stream))
+            self.dist.broadcast(self.torch.from_numpy(buf), src=root)
+            if self.rank != root:
+                _lib.check(self.lib.gpx_memcpy_h2d(dev_ptr, buf.ctypes.data_as(ctypes.c_void_p), nbytes, stream))
+            return 0
+        except Exception as exc:       # an exception must not unwind through the C frames
+            self.error = exc
+            return 1
+
+    def _allreduce(self, user, dev_ptr, count, dtype, op, stream):
+        try:
+            buf = np.empty(count, dtype=self._NP[dtype])
+            _lib.check(self.lib.gpx_stream_sync(stream))
+            _lib.check(self.lib.gpx_memcpy_d2h(buf.ctypes.data_as(ctypes.c_void_p), dev_ptr, buf.nbytes, stream))
+            self.dist.all_reduce(self.torch.from_numpy(buf),
+                                 op=self.dist.ReduceOp.SUM if op == 0 else self.dist.ReduceOp.MAX)
+            _lib.check(self.lib.gpx_memcpy_h2d(dev_ptr, buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes, stream))
+            return 0
+        except Exception as exc:
+            self.error = exc
+            return 1
+
+
+class NativeDistributedGP(object):
+    """One rank's share of a GP whose factorisation schedule runs in C (csrc/gpx_mg.hip): HIP streams,
+    events and the panel broadcasts are issued by libgpx, the collectives are RCCL (`backend="rccl"`,
+    one process per GPU; the ncclUniqueId travels over `dist`, a torch.distributed CPU group) or host
+    callbacks over `dist` (`backend="callbacks"`: several ranks may share a GPU).  `dist=None`: one rank."""
+
+    TIMING_KEYS = ("kernel_build", "factor", "solve", "reduce", "chain_panel", "chain_pack", "chain_bcast",
+                   "chain_update")
+
+    def __init__(self, n, d, dtype_id=_lib.F64, kernel_id=_lib.KERNEL_GAUSSIAN, nb=None, dist=None,
+                 backend="rccl", device=0):
+        self.lib = _lib.load()
+        self.n, self.d = int(n), int(d)
+        self.rank, self.world = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
+        self.nb = int(nb or default_nb(n, self.world))
+        _lib.check(self.lib.gpx_set_device(int(device)))
+        self.h = ctypes.c_void_p()
+        self._cb = None
+        if backend == "rccl":
+            import torch
+            ident = np.zeros(_lib.MG_ID_BYTES, dtype=np.uint8)
+            if self.rank == 0:
+                _lib.check(self.lib.gpx_mg_unique_id(ident.ctypes.data_as(ctypes.c_void_p)))
+            if dist is not None and self.world > 1:
+                t = torch.from_numpy(ident)
+                dist.broadcast(t, src=0)                      # out-of-band exchange over the CPU group
+            _lib.check(self.lib.gpx_mg_create(ctypes.byref(self.h), dtype_id, kernel_id, self.n, self.d, self.nb,
+                                              self.world, self.rank, ident.ctypes.data_as(ctypes.c_void_p)))
+        elif backend == "callbacks":
+            if dist is not None and self.world > 1:
+                self._cb = GlooCallbacks(dist)
+                b = ctypes.cast(self._cb.bcast, ctypes.c_void_p)
+                a = ctypes.cast(self._cb.allreduce, ctypes.c_void_p)
+            else:
+                b = a = None
+            _lib.check(self.lib.gpx_mg_create_cb(ctypes.byref(self.h), dtype_id, kernel_id, self.n, self.d, self.nb,
+                                                 self.world, self.rank, b, a, None))
+        else:
+            raise ValueError("backend must be 'rccl' or 'callbacks'")
+        self.log_lh = None
+        self.info = None
+
+    def _check(self, rc):
+        if rc != 0 and self._cb is not None and self._cb.error is not None:
+            err, self._cb.error = self._cb.error, None
+            raise err
+        _lib.check(rc)
+
+    def set_data(self, x, y):
+        x = np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(self.n, self.d))
+        y = np.ascontiguousarray(np.asarray(y, dtype=np.float64).reshape(self.n))
+        self._check(self.lib.gpx_mg_set_data(self.h, _lib.dptr(x), _lib.dptr(y)))
+
+    def fit(self, params, s):
+        p = np.ascontiguousarray(params, dtype=np.float64)
+        llh, info = ctypes.c_double(0.0), ctypes.c_int(0)
+        self._check(self.lib.gpx_mg_fit(self.h, _lib.dptr(p), float(s), ctypes.byref(llh), ctypes.byref(info)))
+        self.log_lh, self.info = llh.value, info.value
+        return self.log_lh
+
+    def mean(self, params, xo):
+        p = np.ascontiguousarray(params, dtype=np.float64)
+        xo = np.ascontiguousarray(np.asarray(xo, dtype=np.float64).reshape(-1, self.d))
+        out = np.empty(xo.shape[0], dtype=np.float64)
+        self._check(self.lib.gpx_mg_mean(self.h, _lib.dptr(p), _lib.dptr(xo), xo.shape[0], _lib.dptr(out)))
+        return out
+
+    @property
+    def alpha(self):
+        out = np.empty(self.n, dtype=np.float64)
+        self._check(self.lib.gpx_mg_get_alpha(self.h, _lib.dptr(out)))
+        return out
+
+    @property
+    def logdet(self):
+        v = ctypes.c_double(0.0)
+        self._check(self.lib.gpx_mg_scalars(self.h, ctypes.byref(v), None, None))
+        return v.value
+
+    def timing(self):
+        ms = np.zeros(8)
+        self._check(self.lib.gpx_mg_timing(self.h, _lib.dptr(ms)))
+        return dict(zip(self.TIMING_KEYS, [float(v) for v in ms]))
+
+    def close(self):
+        if self.h:
+            self.lib.gpx_mg_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # ------------------------------------------------------------------ benchmark --
-def bench_distributed(args, X, y, Xo, params, s, dtype_id):
-    """bench.py's N > 1 leg: same workload as N = 1 (strong scaling), one rank per GPU."""
-    import sys
+def bench_distributed(args, X, y, Xo, params, s, dtype_id, residual_check=None):
+    """bench.py's N > 1 leg: the same workload as N = 1 (strong scaling), one rank per GPU.  Control plane:
+    a torch.distributed gloo group (rendezvous, barriers, the ncclUniqueId, the max-over-ranks clock); data
+    plane: libgpx's C schedule with RCCL collectives.  GPX_DIST_BACKEND=gloo swaps the data-plane
+    collectives for host callbacks over the same gloo group (rehearsal with several ranks on one GPU)."""
     import torch
     import torch.distributed as dist
-    # RCCL prints a version banner on stdout when its communicator is created; keep
-    # stdout clean for the single JSON line (stderr still shows everything)
-    sys.stdout.flush()
-    saved_stdout = os.dup(1)
-    os.dup2(2, 1)
     rank = int(os.environ["RANK"])
     world = int(os.environ["WORLD_SIZE"])
     local_rank = int(os.environ.get("LOCAL_RANK", rank))
-    if os.environ.get("GPX_BENCH_SINGLE_DEVICE"):      # rehearsal on a 1-GPU box (use with gloo)
+    if os.environ.get("GPX_BENCH_SINGLE_DEVICE"):      # rehearsal on a 1-GPU box
         local_rank = 0
-    torch.cuda.set_device(local_rank)
-    backend = os.environ.get("GPX_DIST_BACKEND", "nccl")
-    dist.init_process_group(backend=backend, rank=rank, world_size=world,
-                            device_id=torch.device("cuda", local_rank) if backend == "nccl" else None)
-    ops = HipOps(dtype_id, local_rank)
-    comm = TorchComm(dist)
-    N, d, m = args.n, args.d, args.m
-    gp = DistributedGP(ops, comm, N, d)
-    gp.set_data(X, y)
-    xo_dev = ops.from_host(Xo)
-    mean_dev = ops.empty((m,))
-
-    def step():
-        llh = gp.fit(params, s)
-        gp.mean(xo_dev, m, params, mean_dev)
-        ops.sync()
-        return llh
-
-    for _ in range(args.warmup):
-        step()
-    dist.barrier()
-    torch.cuda.synchronize()
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     lib = _lib.load()
-    if rank == 0 and not args.no_prof:
-        _lib.check(lib.gpx_prof_enable(1))       # per-launch HIP events on this rank's streams
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        llh = step()
-    dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=ops.device)
-    dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    sec = float(elapsed.item()) / args.steps
-    mean_host = ops.to_host(mean_dev)
-    assert np.isfinite(llh) and np.isfinite(mean_host).all()
-    peak = 78.6 if dtype_id == _lib.F64 else 157.3
-    tfl = (N ** 3 / 3.0) / sec / 1e12
-    rank0_gemm = None
-    if rank == 0 and not args.no_prof:
-        a, b, c = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
-        _lib.check(lib.gpx_prof_read(1, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
-        _lib.check(lib.gpx_prof_enable(0))
-        if b.value > 0:
-            rank0_gemm = {"launches_per_step": a.value / args.steps, "ms_per_step": b.value / args.steps,
-                          "tflops": c.value / (b.value * 1e-3) / 1e12}
-    result = {
-        "metric": "GP fit+predict wall-clock (kernel build + Cholesky + solve + log_lh + posterior mean)",
-        "value": round(sec, 4), "unit": "s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(sec * 1e3, 2), "higher_is_better": False, "scaling": "strong",
-        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "N=%d d=%d RBF(GaussianKernel) %s, m=%d test points, h=1 w=0.5*sqrt(d) s=1"
-                               % (N, d, args.dtype, m), "N": N, "d": d, "m": m,
-                   "parallelism": "1-D block-cyclic block columns (nb=%d) over %d GPUs, RCCL panel broadcast"
-                                  % (gp.lay.nb, world)},
-        "log_lh": llh,
-        "whole_step_tflops_n3_over_3": round(tfl, 3),
-        "whole_step_frac_of_peak_all_gpus": round(tfl / (peak * world), 4),
-        "roofline": ({"bound": "mfma",
-                      "kernel": "gpx::gemm_nt_fast_kernel<T, 128, 1, 128> (trailing SYRK updates) on rank 0",
-                      "achieved": round(rank0_gemm["tflops"], 3), "peak": peak, "unit": "TFLOP/s",
-                      "frac": round(rank0_gemm["tflops"] / peak, 4), "traffic": None,
-                      "launches_per_step": rank0_gemm["launches_per_step"],
-                      "kernel_ms_per_step_rank0": round(rank0_gemm["ms_per_step"], 3)}
-                     if rank0_gemm else None),
-    }
-    dist.destroy_process_group()
+    backend = "callbacks" if os.environ.get("GPX_DIST_BACKEND", "nccl") == "gloo" else "rccl"
+    N, d, m = args.n, args.d, args.m
+    # RCCL prints a version banner on stdout when its communicator is created; keep stdout clean for the
+    # single JSON line (stderr still shows everything)
+    import sys
     sys.stdout.flush()
-    os.dup2(saved_stdout, 1)
-    os.close(saved_stdout)
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        gp = NativeDistributedGP(N, d, dtype_id=dtype_id, dist=dist, backend=backend, device=local_rank)
+        gp.set_data(X, y)
+
+        def step():
+            llh = gp.fit(params, s)                    # synchronous: returns when this rank's streams have drained
+            mean = gp.mean(params, Xo)
+            return llh, mean
+
+        for _ in range(args.warmup):
+            step()
+        dist.barrier()
+        _lib.check(lib.gpx_device_sync())
+        if rank == 0 and not args.no_prof:
+            _lib.check(lib.gpx_prof_enable(1))         # per-launch HIP events on this rank's streams
+        chain = np.zeros(8)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            llh, mean_host = step()
+            tm = gp.timing()
+            chain += np.array([tm[k] for k in gp.TIMING_KEYS])
+        _lib.check(lib.gpx_device_sync())
+        dist.barrier()
+        elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+        sec = float(elapsed.item()) / args.steps
+        chain /= args.steps
+        assert np.isfinite(llh) and np.isfinite(mean_host).all()
+        all_chain = [None] * world
+        dist.all_gather_object(all_chain, {k: round(float(v), 3) for k, v in zip(gp.TIMING_KEYS, chain)})
+        peak = 78.6 if dtype_id == _lib.F64 else 157.3
+        tfl = (N ** 3 / 3.0) / sec / 1e12
+        rank0_gemm = None
+        if rank == 0 and not args.no_prof:
+            a, b, c = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+            _lib.check(lib.gpx_prof_read(1, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+            _lib.check(lib.gpx_prof_enable(0))
+            if b.value > 0:
+                rank0_gemm = {"launches_per_step": a.value / args.steps, "ms_per_step": b.value / args.steps,
+                              "tflops": c.value / (b.value * 1e-3) / 1e12}
+        check = None
+        if rank == 0 and residual_check is not None:
+            res, nres = residual_check(gp.alpha)
+            tol = 1e-9 if dtype_id == _lib.F64 else 2e-3
+            assert res < tol, "sampled-row residual %.3e exceeds %.1e" % (res, tol)
+            check = {"sampled_rows": nres, "max_abs_residual_K_alpha_minus_y_over_max_y": res, "tolerance": tol}
+        result = {
+            "metric": "GP fit+predict wall-clock (kernel build + Cholesky + solve + log_lh + posterior mean)",
+            "value": round(sec, 4), "unit": "s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(sec * 1e3, 2), "higher_is_better": False, "scaling": "strong",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "N=%d d=%d RBF(GaussianKernel) %s, m=%d test points, h=1 w=0.5*sqrt(d) s=1"
+                                   % (N, d, args.dtype, m), "N": N, "d": d, "m": m,
+                       "parallelism": "1-D block-cyclic block columns (nb=%d) over %d GPUs, %s panel broadcast, "
+                                      "schedule in C (gpx_mg_*)"
+                                      % (gp.nb, world, "RCCL" if backend == "rccl" else "host-callback (gloo)")},
+            "log_lh": llh,
+            "check": check,
+            "whole_step_tflops_n3_over_3": round(tfl, 3),
+            "whole_step_frac_of_peak_all_gpus": round(tfl / (peak * world), 4),
+            # where each rank's step went (ms per step, HIP events on its own streams): the stages, and inside
+            # the factorisation the owner's chain -- panels it factored, packs, broadcasts (including the wait
+            # for the root), updates
+            "stage_and_chain_ms_per_rank": all_chain,
+            "roofline": ({"bound": "mfma",
+                          "kernel": "gpx::gemm_nt_fast_kernel<T, 128, 1, 128> (trailing SYRK updates) on rank 0",
+                          "achieved": round(rank0_gemm["tflops"], 3), "peak": peak, "unit": "TFLOP/s",
+                          "frac": round(rank0_gemm["tflops"] / peak, 4), "traffic": None,
+                          "launches_per_step": rank0_gemm["launches_per_step"],
+                          "kernel_ms_per_step_rank0": round(rank0_gemm["ms_per_step"], 3)}
+                         if rank0_gemm else None),
+        }
+        gp.close()
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
+    dist.barrier()
+    dist.destroy_process_group()
     return result

@@ -329,6 +329,44 @@ int gpx_gp_last_timing(gpx_gp_t *gp, float *ms5);
 int gpx_gp_device_ptrs(gpx_gp_t *gp, void **A, int64_t *lda, void **x, void **y,
                        void **alpha, void **stream);
 
+/* ------------------------------------------------------------- multi-GPU -- */
+/* One GP spread over the GPUs of a node, one PROCESS per GPU (north-star; SURVEY 8e -- the reference has
+ * nothing distributed).  1-D block-cyclic block columns of width nb (global block column j on rank
+ * j % world); per panel the owner factors, packs and broadcasts it (root = owner, row-chunked so that
+ * the next owner's column update hides under the transfer), every rank updates its own block columns;
+ * one-panel look-ahead on a high-priority side stream.  The whole schedule -- HIP streams, events and
+ * the collectives -- runs in C.
+ * Communicator: RCCL over xGMI (librccl is dlopen'ed at first use; libgpx has no link-time dependency on
+ * it).  Rank 0 calls gpx_mg_unique_id and distributes the GPX_MG_ID_BYTES out of band (MPI, a file,
+ * torch.distributed over gloo ...); every rank then calls gpx_mg_create on its own device
+ * (gpx_set_device first).  gpx_mg_create_cb runs the same schedule over host-supplied collectives on
+ * DEVICE pointers (tests: several ranks on one GPU over gloo, which RCCL cannot do). */
+#define GPX_MG_ID_BYTES 128
+typedef struct gpx_mg gpx_mg_t;
+typedef int (*gpx_mg_bcast_fn)(void *user, void *dev_ptr, size_t bytes, int root, void *stream);
+/* dtype: GPX_F64 / GPX_F32 / 2 (int32); op: 0 sum, 1 max; in place on dev_ptr; 0 = success */
+typedef int (*gpx_mg_allreduce_fn)(void *user, void *dev_ptr, size_t count, int dtype, int op, void *stream);
+int gpx_mg_unique_id(void *id128);
+int gpx_mg_create(gpx_mg_t **mg, int dtype, int kernel, int64_t n, int d, int64_t nb, int world, int rank,
+                  const void *id128);
+int gpx_mg_create_cb(gpx_mg_t **mg, int dtype, int kernel, int64_t n, int d, int64_t nb, int world, int rank,
+                     gpx_mg_bcast_fn bcast, gpx_mg_allreduce_fn allreduce, void *user);
+int gpx_mg_destroy(gpx_mg_t *mg);
+/* x: (n, d), y: (n,) HOST float64, the same on every rank */
+int gpx_mg_set_data(gpx_mg_t *mg, const double *x, const double *y);
+/* kernel build (owned block columns) -> distributed Cholesky -> alpha (replicated) -> log_lh with the
+ * reference's conventions (gp/gp.py:360-367, gp_c.pyx:17-31); *info = first failing leading minor over
+ * all ranks.  Collective: every rank calls it with the same arguments.  Synchronous. */
+int gpx_mg_fit(gpx_mg_t *mg, const double *params, double s, double *log_lh, int *info);
+/* posterior mean at xo (m, d) HOST float64 -> out (m,) on every rank (each evaluates a slice) */
+int gpx_mg_mean(gpx_mg_t *mg, const double *params, const double *xo, int64_t m, double *out);
+int gpx_mg_get_alpha(gpx_mg_t *mg, double *out);
+int gpx_mg_scalars(gpx_mg_t *mg, double *logdet, double *yta, int *info);
+/* this rank's times of the last fit, ms (HIP events): [0] kernel build [1] factorisation [2] solves
+ * [3] reductions, and the chain inside [1]: [4] panels it factored [5] packs [6] broadcasts (incl.
+ * waiting for the root) [7] trailing / column updates */
+int gpx_mg_timing(gpx_mg_t *mg, double *ms8);
+
 /* ------------------------------------------ host-level drop-in entry points -- */
 /* gaussian_c.K(out, x1, x2, h, w) -- gaussian_c.pyx:18 ; and the derivative
  * members through `member`.  out: (n, m) C-contiguous float64. */

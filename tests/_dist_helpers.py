@@ -157,3 +157,37 @@ def run_world(world, backend, use_hip, N, d, nb, m, outdir, s=1.0):
     sock.close()
     mp.spawn(worker, args=(world, port, backend, use_hip, N, d, nb, m, outdir, s), nprocs=world, join=True)
     return np.load(os.path.join(outdir, "result.npz"))
+
+
+def native_worker(rank, world, port, N, d, nb, m, outdir, dtype_id, s=1.0):
+    """One rank of the C schedule (gpx_mg_*) with host-callback collectives over gloo; all ranks on GPU 0."""
+    import torch.distributed as dist
+    from gaussian_processes_amd import multi_gpu
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        X, y, Xo = orc.synth_inputs(N, d, m)
+        params = np.array([1.0, 0.5 * np.sqrt(d)])
+        g = multi_gpu.NativeDistributedGP(N, d, dtype_id=dtype_id, nb=nb, dist=dist, backend="callbacks", device=0)
+        g.set_data(X, y)
+        llh = g.fit(params, s)
+        llh2 = g.fit(params, s)                       # a second fit reuses buffers, events and streams
+        mean = g.mean(params, Xo)
+        if rank == 0:
+            np.savez(os.path.join(outdir, "result.npz"), log_lh=llh, log_lh2=llh2, alpha=g.alpha, mean=mean,
+                     logdet=g.logdet, info=g.info, timing=np.array(list(g.timing().values())))
+        g.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def run_native_world(world, N, d, nb, m, outdir, dtype_id=0, s=1.0):
+    import socket
+    import torch.multiprocessing as mp
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    mp.spawn(native_worker, args=(world, port, N, d, nb, m, outdir, dtype_id, s), nprocs=world, join=True)
+    return np.load(os.path.join(outdir, "result.npz"))

@@ -988,3 +988,52 @@ def _panelled(monkeypatch, f):
         return f()
     finally:
         monkeypatch.delenv("GPX_KMAT_PANEL_BYTES")
+
+
+# ------------------------------------------------------- the C multi-GPU schedule (gpx_mg_*) --
+@pytest.mark.parametrize("N,nb,force", [(2300, 256, False), (1500, 128, True), (4200, 1024, True)])
+def test_native_mg_single_rank_rccl_vs_oracle(N, nb, force, monkeypatch):
+    """gpx_mg_* with a ONE-rank RCCL communicator (librccl dlopen'ed, ncclCommInitRank with nranks = 1):
+    the C schedule -- block-cyclic maps, look-ahead, pack kernel, chunked panel broadcast, distributed
+    solves -- against the oracle; GPX_FORCE_COLLECTIVES makes every broadcast / all-reduce a real RCCL
+    call on the handle's streams."""
+    from gaussian_processes_amd import multi_gpu
+    if force:
+        monkeypatch.setenv("GPX_FORCE_COLLECTIVES", "1")
+    d, m = 3, 40
+    X, y, Xo = orc.synth_inputs(N, d, m)
+    params = np.array([1.0, 0.5 * np.sqrt(d)])
+    g = multi_gpu.NativeDistributedGP(N, d, nb=nb, backend="rccl", device=0)
+    g.set_data(X, y)
+    llh = g.fit(params, 1.0)
+    o = orc.OracleGP("gaussian", params, X, y, 1.0)
+    assert g.info == 0
+    np.testing.assert_allclose(llh, o.log_lh, rtol=1e-10)
+    np.testing.assert_allclose(g.alpha, o.inv_Kxx_y, rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(g.mean(params, Xo), o.mean(Xo), rtol=1e-8, atol=1e-11)
+    tm = g.timing()
+    assert tm["factor"] > 0 and tm["chain_panel"] > 0 and tm["chain_update"] > 0
+    # non-PD: info is the first failing minor, log_lh = -inf
+    assert g.fit(np.array([1.0, 50.0]), 0.0) == -np.inf and g.info > 0
+    g.close()
+
+
+@pytest.mark.parametrize("world,N,nb,dtype_id", [(2, 3000, 256, 0), (3, 2500, 128, 0), (4, 5200, 512, 0), (2, 2100, 256, 1)])
+def test_native_mg_world_on_one_gpu_vs_oracle(tmp_path, world, N, nb, dtype_id):
+    """The same C schedule with `world` ranks sharing GPU 0, collectives through host callbacks over gloo
+    (gpx_mg_create_cb): ownership maps, buffer reuse, chunked broadcasts and the distributed solves with
+    real peers, against the oracle.  (4, 5200, 512): tall enough for the row-chunked broadcast path.)"""
+    from _dist_helpers import run_native_world
+    d, m = 3, 40
+    res = run_native_world(world, N, d, nb, m, str(tmp_path), dtype_id=dtype_id)
+    X, y, Xo = orc.synth_inputs(N, d, m)
+    o = orc.OracleGP("gaussian", (1.0, 0.5 * np.sqrt(d)), X, y, 1.0)
+    assert int(res["info"]) == 0
+    if dtype_id == 0:
+        np.testing.assert_allclose(float(res["log_lh"]), o.log_lh, rtol=1e-10)
+        np.testing.assert_allclose(res["alpha"], o.inv_Kxx_y, rtol=1e-8, atol=1e-11)
+        np.testing.assert_allclose(res["mean"], o.mean(Xo), rtol=1e-8, atol=1e-11)
+    else:
+        np.testing.assert_allclose(float(res["log_lh"]), o.log_lh, rtol=1e-4)
+        np.testing.assert_allclose(res["mean"], o.mean(Xo), rtol=1e-3, atol=1e-3)
+    assert float(res["log_lh2"]) == float(res["log_lh"])
