@@ -34,6 +34,7 @@ template <> struct MF<double> {
     typedef d4_t acc_t;
     static constexpr int EPK = 16;   // elements per k-step (128 B per row)
     static constexpr int CH = 2;     // elements per 16-byte chunk
+    static constexpr int NR = 4;     // accumulator registers per 16 x 16 tile
     __device__ static __forceinline__ acc_t mfma(double a, double b, acc_t c)
     { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
     // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
@@ -43,10 +44,32 @@ template <> struct MF<float> {
     typedef f4_t acc_t;
     static constexpr int EPK = 32;
     static constexpr int CH = 4;
+    static constexpr int NR = 4;
     __device__ static __forceinline__ acc_t mfma(float a, float b, acc_t c)
     { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
     // C/D layout of v_mfma_f32_16x16x4_f32: col = lane & 15, row = 4 * (lane >> 4) + reg
     __device__ static __forceinline__ int row(int lane, int reg) { return 4 * (lane >> 4) + reg; }
+};
+
+typedef float f16_t __attribute__((ext_vector_type(16)));
+
+// MFMA shape of the FAST kernel.  fp64: v_mfma_f64_16x16x4 (64 cycles).  fp32: v_mfma_f32_32x32x2 (64
+// cycles, 4096 flop) instead of 16x16x4 (32 cycles, 2048 flop): the same matrix-pipe rate and the same
+// LDS bytes per flop for a 64 x 64 wave tile, but HALF as many MFMA instructions per k-step -- every
+// ds_read / LDS-DMA / waitcnt issued between two MFMAs then has 64 cycles to hide in instead of 32.
+// TM: tile edge; NR: accumulator registers per tile; lane -> (row within tile, k group): lane & (TM-1), lane / TM;
+// KG = 64 / TM k groups; a lane holds EPK / KG consecutive elements of its row per k-step.
+template <typename T> struct MFF;
+template <> struct MFF<double> : MF<double> {
+    static constexpr int TM = 16, NR = 4;
+};
+template <> struct MFF<float> {
+    typedef f16_t acc_t;
+    static constexpr int EPK = 32, CH = 4, TM = 32, NR = 16;
+    __device__ static __forceinline__ acc_t mfma(float a, float b, acc_t c)
+    { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+    // C/D layout of v_mfma_f32_32x32x2_f32: col = lane & 31, row = 8 * (reg / 4) + 4 * (lane >> 5) + reg % 4
+    __device__ static __forceinline__ int row(int lane, int reg) { return 8 * (reg >> 2) + 4 * (lane >> 5) + (reg & 3); }
 };
 
 constexpr int GB_M = 128, GB_N = 128;
@@ -83,36 +106,37 @@ __device__ __forceinline__ Chunk16 load_chunk(const T *__restrict__ base, int64_
 // `beta0`) for one wave's 64 x (16 * NTW) tile.  The 32 loads of two MFMA tile rows
 // are issued before the first use (clamped addresses keep them unconditional), so a
 // lane pays 2 memory round trips per tile instead of 64.
-template <typename T, int NTW>
-__device__ __forceinline__ void store_wave_tile(typename MF<T>::acc_t (&acc)[4][NTW], T *__restrict__ C,
-                                                int64_t ldc, int64_t M, int64_t N, int64_t r_base,
+template <typename T, int NTW, typename M = MF<T>, int NTJ = NTW>
+__device__ __forceinline__ void store_wave_tile(typename M::acc_t (&acc)[64 / (M::NR == 4 ? 16 : 32)][NTJ], T *__restrict__ C,
+                                                int64_t ldc, int64_t Mr, int64_t N, int64_t r_base,
                                                 int64_t c_base, int lane, T alpha, int tri,
                                                 int64_t row0, int64_t col0, int beta0)
 {
-    const int ccol = lane & 15;
+    constexpr int TM = M::NR == 4 ? 16 : 32, NR = M::NR, TI = 64 / TM, IB = TM == 16 ? 2 : 1;
+    const int ccol = lane & (TM - 1);
 #pragma unroll
-    for (int ib = 0; ib < 4; ib += 2) {
-        T cv[2][NTW][4];
+    for (int ib = 0; ib < TI; ib += IB) {
+        T cv[IB][NTJ][NR];
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
+        for (int ii = 0; ii < IB; ++ii)
 #pragma unroll
-            for (int j = 0; j < NTW; ++j) {
-                const int64_t gc = min(c_base + j * 16 + ccol, N - 1);
+            for (int j = 0; j < NTJ; ++j) {
+                const int64_t gc = min(c_base + j * TM + ccol, N - 1);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int64_t gr = min(r_base + (ib + ii) * 16 + MF<T>::row(lane, r), M - 1);
+                for (int r = 0; r < NR; ++r) {
+                    const int64_t gr = min(r_base + (ib + ii) * TM + M::row(lane, r), Mr - 1);
                     cv[ii][j][r] = beta0 ? (T)0 : C[gr * ldc + gc];
                 }
             }
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
+        for (int ii = 0; ii < IB; ++ii)
 #pragma unroll
-            for (int j = 0; j < NTW; ++j) {
-                const int64_t gc = c_base + j * 16 + ccol;
+            for (int j = 0; j < NTJ; ++j) {
+                const int64_t gc = c_base + j * TM + ccol;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int64_t gr = r_base + (ib + ii) * 16 + MF<T>::row(lane, r);
-                    if (gr < M && gc < N && !(tri == GPX_LOWER && row0 + gr < col0 + gc))
+                for (int r = 0; r < NR; ++r) {
+                    const int64_t gr = r_base + (ib + ii) * TM + M::row(lane, r);
+                    if (gr < Mr && gc < N && !(tri == GPX_LOWER && row0 + gr < col0 + gc))
                         C[gr * ldc + gc] = fma(alpha, acc[ib + ii][j][r], cv[ii][j][r]);
                 }
             }
@@ -131,22 +155,23 @@ __device__ __forceinline__ void atomic_add_nr(float *p, float v)
 {
     (void)__builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float *)p, v);
 }
-template <typename T, int NTW>
-__device__ __forceinline__ void store_wave_tile_atomic(typename MF<T>::acc_t (&acc)[4][NTW], T *__restrict__ C,
-                                                       int64_t ldc, int64_t M, int64_t N, int64_t r_base,
-                                                       int64_t c_base, int lane, T alpha, int tri,
+template <typename T, int NTW, typename M = MF<T>, int NTJ = NTW>
+__device__ __forceinline__ void store_wave_tile_atomic(typename M::acc_t (&acc)[64 / (M::NR == 4 ? 16 : 32)][NTJ],
+                                                       T *__restrict__ C, int64_t ldc, int64_t Mr, int64_t N,
+                                                       int64_t r_base, int64_t c_base, int lane, T alpha, int tri,
                                                        int64_t row0, int64_t col0)
 {
-    const int ccol = lane & 15;
+    constexpr int TM = M::NR == 4 ? 16 : 32, NR = M::NR, TI = 64 / TM;
+    const int ccol = lane & (TM - 1);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < NTW; ++j) {
-            const int64_t gc = c_base + j * 16 + ccol;
+        for (int j = 0; j < NTJ; ++j) {
+            const int64_t gc = c_base + j * TM + ccol;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t gr = r_base + i * 16 + MF<T>::row(lane, r);
-                if (gr < M && gc < N && !(tri == GPX_LOWER && row0 + gr < col0 + gc))
+            for (int r = 0; r < NR; ++r) {
+                const int64_t gr = r_base + i * TM + M::row(lane, r);
+                if (gr < Mr && gc < N && !(tri == GPX_LOWER && row0 + gr < col0 + gc))
                     atomic_add_nr(C + gr * ldc + gc, alpha * acc[i][j][r]);
             }
         }
@@ -170,43 +195,44 @@ __device__ __forceinline__ float swap_pair(float v)
 // pair the even lane owns two columns of rows {q, q+8} and the odd lane two columns
 // of rows {q+4, q+12}: every lane moves 2 elements per access and the tile needs half
 // the memory instructions.  Elements outside the triangle are written back unchanged.
-template <typename T, int NTW>
-__device__ __forceinline__ void store_wave_tile_v2(typename MF<T>::acc_t (&acc)[4][NTW], T *__restrict__ C,
-                                                   int64_t ldc, int64_t M, int64_t N, int64_t r_base,
+template <typename T, int NTW, typename M = MF<T>, int NTJ = NTW>
+__device__ __forceinline__ void store_wave_tile_v2(typename M::acc_t (&acc)[64 / (M::NR == 4 ? 16 : 32)][NTJ], T *__restrict__ C,
+                                                   int64_t ldc, int64_t Mr, int64_t N, int64_t r_base,
                                                    int64_t c_base, int lane, T alpha, int tri,
                                                    int64_t row0, int64_t col0, int beta0)
 {
+    constexpr int TM = M::NR == 4 ? 16 : 32, NH = M::NR / 2, TI = 64 / TM, IB = TM == 16 ? 2 : 1;
     struct alignas(2 * sizeof(T)) P2 { T x, y; };
     const int odd = lane & 1;
-    const int ccol = (lane & 15) & ~1;                 // first column of the lane pair
+    const int ccol = (lane & (TM - 1)) & ~1;           // first column of the lane pair
 #pragma unroll
-    for (int ib = 0; ib < 4; ib += 2) {                // two MFMA tile rows per round trip
-        P2 cv[2][NTW][2];
-        int64_t grr[2][2];
+    for (int ib = 0; ib < TI; ib += IB) {              // IB MFMA tile rows per round trip
+        P2 cv[IB][NTJ][NH];
+        int64_t grr[IB][NH];
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
+        for (int ii = 0; ii < IB; ++ii)
 #pragma unroll
-            for (int h = 0; h < 2; ++h)                // h = 0: registers (0,1), h = 1: registers (2,3)
-                grr[ii][h] = r_base + (ib + ii) * 16 + MF<T>::row(lane, 2 * h + odd);
+            for (int h = 0; h < NH; ++h)               // register pair (2h, 2h + 1): two neighbouring rows
+                grr[ii][h] = r_base + (ib + ii) * TM + M::row(lane, 2 * h + odd);
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
+        for (int ii = 0; ii < IB; ++ii)
 #pragma unroll
-            for (int j = 0; j < NTW; ++j) {
-                const int64_t gc = min(c_base + j * 16 + ccol, N - 2);
+            for (int j = 0; j < NTJ; ++j) {
+                const int64_t gc = min(c_base + j * TM + ccol, N - 2);
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int64_t gr = min(grr[ii][h], M - 1);
+                for (int h = 0; h < NH; ++h) {
+                    const int64_t gr = min(grr[ii][h], Mr - 1);
                     if (beta0) { cv[ii][j][h].x = (T)0; cv[ii][j][h].y = (T)0; }
                     else cv[ii][j][h] = *reinterpret_cast<const P2 *>(C + gr * ldc + gc);
                 }
             }
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
+        for (int ii = 0; ii < IB; ++ii)
 #pragma unroll
-            for (int j = 0; j < NTW; ++j) {
-                const int64_t gc = c_base + j * 16 + ccol;
+            for (int j = 0; j < NTJ; ++j) {
+                const int64_t gc = c_base + j * TM + ccol;
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
+                for (int h = 0; h < NH; ++h) {
                     // even lane keeps register 2h (sends 2h+1), odd lane keeps 2h+1 (sends 2h)
                     const T keep = odd ? acc[ib + ii][j][2 * h + 1] : acc[ib + ii][j][2 * h];
                     const T send = odd ? acc[ib + ii][j][2 * h] : acc[ib + ii][j][2 * h + 1];
@@ -214,7 +240,7 @@ __device__ __forceinline__ void store_wave_tile_v2(typename MF<T>::acc_t (&acc)[
                     const T vx = odd ? recv : keep;    // column gc
                     const T vy = odd ? keep : recv;    // column gc + 1
                     const int64_t gr = grr[ii][h];
-                    if (gr < M && gc + 1 < N) {
+                    if (gr < Mr && gc + 1 < N) {
                         P2 o = cv[ii][j][h];
                         if (!(tri == GPX_LOWER && row0 + gr < col0 + gc)) o.x = fma(alpha, vx, o.x);
                         if (!(tri == GPX_LOWER && row0 + gr < col0 + gc + 1)) o.y = fma(alpha, vy, o.y);
@@ -458,14 +484,19 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_nt_fast_kernel(int64_t M, int6
                                                               int tri, int64_t row0, int64_t col0,
                                                               GemmMap fm, int beta0)
 {
-    typedef typename MF<T>::acc_t acc_t;
-    constexpr int EPK = MF<T>::EPK;
-    constexpr int SUB = EPK / 4;
+    typedef MFF<T> MM;                                   // MFMA shape of this kernel (fp64 16x16x4, fp32 32x32x2)
+    typedef typename MM::acc_t acc_t;
+    constexpr int EPK = MM::EPK;
+    constexpr int TM = MM::TM;                           // MFMA tile edge
+    constexpr int TI = 64 / TM, TJ = (BN / 2) / TM;      // MFMA tiles of the 64 x (BN / 2) wave tile
+    constexpr int KG = 64 / TM;                          // k groups over the lanes
+    constexpr int SUB = EPK / KG;                        // MFMA sub-steps per k-step = elements per lane and row
+    constexpr int CPL = SUB * (int)sizeof(T) / 16;       // 16-byte chunks per lane and row per k-step: 2 / 4
+    constexpr int UH = CPL / 2;                          // chunks per lane, row and HALF k-step: 1 / 2
     typedef FGeo<BN, BM> Geo;
     constexpr int F_STAGE = Geo::STAGE, PW = Geo::PW, NTW = Geo::NTW, F_NST = Geo::NST;
     constexpr int F_BM = BM;
-
-    // ---- block -> tile (XCD-aware patch order) ----
+    (void)NTW;
     // requested now, looked at after the prologue's DMA is under way (its latency hides there)
     const int aborted = fm.abort_flag ? fm.abort_flag[(int64_t)blockIdx.y * fm.sflag] : 0;
     A += (int64_t)blockIdx.y * fm.sA; B += (int64_t)blockIdx.y * fm.sB; C += (int64_t)blockIdx.y * fm.sC;
@@ -559,13 +590,13 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_nt_fast_kernel(int64_t M, int6
             }
         }
     }
-    acc_t acc[4][NTW];
+    acc_t acc[TI][TJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < NTW; ++j)
+        for (int j = 0; j < TJ; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[i][j][r] = (T)0;
+            for (int r = 0; r < MM::NR; ++r) acc[i][j][r] = (T)0;
 
     const int nk = (int)(K / EPK) - kskip;
     // three stages in flight before the first wait; when K has fewer than three slices the
@@ -589,21 +620,24 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_nt_fast_kernel(int64_t M, int6
     // writes (other stages) do not alias them and would otherwise drain vmcnt(0)
     // before every k-step's first ds_read.  Ordering is by hand (counted vmcnt /
     // lgkmcnt + raw barrier + sched_barrier).
-    // per-lane read address: row (lane & 15) of a 16-row MFMA tile, chunks 2q, 2q+1 swizzled
-    const int q = lane >> 4;
-    const int fl = f_swz(lane & 15);
+    // per-lane read address: row (lane % TM) of an MFMA tile, chunks q * CPL .. q * CPL + CPL - 1 swizzled
+    // (the swizzle of a tile row only depends on (row >> 1) & 7, and tiles start at multiples of 16 rows)
+    const int q = lane / TM;
+    const int fl = f_swz(lane & (TM - 1));
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
-    const unsigned rd0 = (unsigned)((lane & 15) * G_ROWB + ((2 * q) ^ fl) * 16);
-    const unsigned rd1 = (unsigned)((lane & 15) * G_ROWB + ((2 * q + 1) ^ fl) * 16);
+    unsigned rdc[CPL];                                   // byte offset of chunk c of this lane's row
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) rdc[c] = (unsigned)((lane & (TM - 1)) * G_ROWB + ((q * CPL + c) ^ fl) * 16);
     const unsigned a_base = lds0 + (unsigned)((wr * 64) * G_ROWB);
     const unsigned b_base = lds0 + (unsigned)((F_BM + wc * (BN / 2)) * G_ROWB);
 
-    // Schedule of one k-step.  R0 = first-half fragments (MFMA sub-steps 0..H-1),
-    // R1 = second half.  Every memory instruction is issued BETWEEN groups of four
-    // MFMAs, so that its issue cost (an LDS-DMA costs the wave ~60 cycles) falls into
-    // the 256 cycles the matrix pipe needs for the group before it:
-    //   wait R0 | 8 x { 4 MFMA(R0) ; ds_read R1[g] } | wait R1 | wait stage kt+1 | barrier |
-    //   8 x { 4 MFMA(R1) ; DMA piece g of stage kt+3 -> buffer kt%3 ; ds_read R0(kt+1)[g] }
+    // Schedule of one k-step.  R0 = first-half fragments (MFMA sub-steps 0..H-1), R1 = second half; each
+    // half is 4 A and up to 4 B fragment registers of 16 bytes (read slot v of operand A / B = tile v / UH,
+    // chunk v % UH of the half).  Every memory instruction is issued BETWEEN groups of MFMAs worth >= 128
+    // matrix-pipe cycles, so that its issue cost (an LDS-DMA costs the wave ~60 cycles) falls into the
+    // cycles the matrix pipe needs for the group before it:
+    //   wait R0 | { MFMA group(R0) ; ds_read R1[g] } | wait R1 | wait stage kt+1 | barrier |
+    //           { MFMA group(R1) ; DMA piece g of stage kt+NST -> buffer kt % NST ; ds_read R0(kt+1)[g] }
     constexpr int H = SUB / 2;
     u4_t r0a[4], r0b[4], r1a[4], r1b[4];
     // one piece of the next un-fetched k-slice.  Issued unconditionally: past the last slice
@@ -615,16 +649,30 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_nt_fast_kernel(int64_t M, int6
                                          (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
         gsrc[j] += inc;
     };
+    // read slot g of a half: g = 2 v + operand (A even, B odd), v = 0..3; AA / AB: per-u address registers
+    // (base + stage + rdc[half * UH + u]); the tile offset is an immediate
 #define GPX_SLOT_READ(g, RA, RB, AA, AB)                                                        \
     do {                                                                                        \
-        switch (g) {                                                                            \
-        case 0: GPX_DSR(RA[0], AA, 0); break;    case 1: GPX_DSR(RB[0], AB, 0); break;          \
-        case 2: GPX_DSR(RA[1], AA, 2048); break; case 3: GPX_DSR(RB[1], AB, 2048); break;       \
-        case 4: GPX_DSR(RA[2], AA, 4096); break;                                                \
-        case 5: if (NTW > 2) GPX_DSR(RB[2], AB, 4096); break;                                   \
-        case 6: GPX_DSR(RA[3], AA, 6144); break;                                                \
-        case 7: if (NTW > 2) GPX_DSR(RB[3], AB, 6144); break;                                   \
-        default: break;                                                                         \
+        if (TM == 16) {                                                                         \
+            switch (g) {                                                                        \
+            case 0: GPX_DSR(RA[0], AA[0], 0); break;    case 1: GPX_DSR(RB[0], AB[0], 0); break;    \
+            case 2: GPX_DSR(RA[1], AA[0], 2048); break; case 3: GPX_DSR(RB[1], AB[0], 2048); break; \
+            case 4: GPX_DSR(RA[2], AA[0], 4096); break;                                         \
+            case 5: if (TJ > 2) GPX_DSR(RB[2], AB[0], 4096); break;                             \
+            case 6: GPX_DSR(RA[3], AA[0], 6144); break;                                         \
+            case 7: if (TJ > 2) GPX_DSR(RB[3], AB[0], 6144); break;                             \
+            default: break;                                                                     \
+            }                                                                                   \
+        } else {                                                                                \
+            switch (g) {                                                                        \
+            case 0: GPX_DSR(RA[0], AA[0], 0); break;    case 1: GPX_DSR(RB[0], AB[0], 0); break;    \
+            case 2: GPX_DSR(RA[1], AA[UH - 1], 0); break; case 3: GPX_DSR(RB[1], AB[UH - 1], 0); break; \
+            case 4: GPX_DSR(RA[2], AA[0], 4096); break;                                         \
+            case 5: if (TJ > 1) GPX_DSR(RB[2], AB[0], 4096); break;                             \
+            case 6: GPX_DSR(RA[3], AA[UH - 1], 4096); break;                                    \
+            case 7: if (TJ > 1) GPX_DSR(RB[3], AB[UH - 1], 4096); break;                        \
+            default: break;                                                                     \
+            }                                                                                   \
         }                                                                                       \
     } while (0)
 
@@ -637,33 +685,43 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_nt_fast_kernel(int64_t M, int6
     }
     if (fm.stamps) st1 = __builtin_amdgcn_s_memtime();
     {
-        const unsigned aa0 = a_base + rd0, ab0 = b_base + rd0;
+        unsigned aa0[UH], ab0[UH];
+#pragma unroll
+        for (int u = 0; u < UH; ++u) { aa0[u] = a_base + rdc[u]; ab0[u] = b_base + rdc[u]; }
 #pragma unroll
         for (int g = 0; g < 8; ++g) GPX_SLOT_READ(g, r0a, r0b, aa0, ab0);
     }
     int stage = 0;
     for (int kt = 0; kt < nk; ++kt) {
         const unsigned so = (unsigned)(stage * F_STAGE);
-        const unsigned aa1 = a_base + so + rd1, ab1 = b_base + so + rd1;
         int nstage = stage + 1; if (nstage >= F_NST) nstage = 0;
         const unsigned sn = (unsigned)(nstage * F_STAGE);
-        const unsigned aa0 = a_base + sn + rd0, ab0 = b_base + sn + rd0;
+        unsigned aa1[UH], ab1[UH], aa0[UH], ab0[UH];
+#pragma unroll
+        for (int u = 0; u < UH; ++u) {
+            aa1[u] = a_base + so + rdc[UH + u]; ab1[u] = b_base + so + rdc[UH + u];     // second half of this stage
+            aa0[u] = a_base + sn + rdc[u];      ab0[u] = b_base + sn + rdc[u];          // first half of the next
+        }
         const int inc = (kt + F_NST + 1 < nk) ? G_ROWB : 0;   // slice kt+NST is fetched now; is there one more?
 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // R0 of this stage is in
         __builtin_amdgcn_sched_barrier(0);
         {
-            T ha[4][H], hb[4][H];
+            T ha[TI][H], hb[TJ][H];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { memcpy(&ha[i][0], &r0a[i], 16); memcpy(&hb[i][0], &r0b[i], 16); }
+            for (int i = 0; i < TI; ++i) memcpy(&ha[i][0], &r0a[i * UH], 16 * UH);
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) memcpy(&hb[j][0], &r0b[j * UH], 16 * UH);
 #pragma unroll
             for (int ss = 0; ss < H; ++ss)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < TI; ++i) {
 #pragma unroll
-                    for (int j = 0; j < NTW; ++j) acc[i][j] = MF<T>::mfma(ha[i][ss], hb[j][ss], acc[i][j]);
+                    for (int j = 0; j < TJ; ++j) acc[i][j] = MM::mfma(ha[i][ss], hb[j][ss], acc[i][j]);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (!(fm.ablate & 4)) GPX_SLOT_READ(ss * 4 + i, r1a, r1b, aa1, ab1);
+                    const int g = ss * TI + i;               // fp64: 8 slots of 4 MFMAs; fp32: 16 slots of 2 MFMAs
+                    if (TM == 16) { if (!(fm.ablate & 4)) GPX_SLOT_READ(g, r1a, r1b, aa1, ab1); }
+                    else if ((g & 1) == 0) { if (!(fm.ablate & 4)) GPX_SLOT_READ(g / 2, r1a, r1b, aa1, ab1); }
                     __builtin_amdgcn_sched_barrier(0);
                 }
         }
@@ -674,19 +732,27 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_nt_fast_kernel(int64_t M, int6
         }
         __builtin_amdgcn_sched_barrier(0);
         {
-            T ha[4][H], hb[4][H];
+            T ha[TI][H], hb[TJ][H];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { memcpy(&ha[i][0], &r1a[i], 16); memcpy(&hb[i][0], &r1b[i], 16); }
+            for (int i = 0; i < TI; ++i) memcpy(&ha[i][0], &r1a[i * UH], 16 * UH);
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) memcpy(&hb[j][0], &r1b[j * UH], 16 * UH);
 #pragma unroll
             for (int ss = 0; ss < H; ++ss)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < TI; ++i) {
 #pragma unroll
-                    for (int j = 0; j < NTW; ++j) acc[i][j] = MF<T>::mfma(ha[i][ss], hb[j][ss], acc[i][j]);
+                    for (int j = 0; j < TJ; ++j) acc[i][j] = MM::mfma(ha[i][ss], hb[j][ss], acc[i][j]);
                     __builtin_amdgcn_sched_barrier(0);
-                    const int g = ss * 4 + i;
-                    if (g < PW && !(fm.ablate & 2)) issue1(stage, g, inc);      // into the buffer just consumed
-                    if (g < 8 && !(fm.ablate & 4)) GPX_SLOT_READ(g, r0a, r0b, aa0, ab0);
+                    const int g = ss * TI + i;
+                    if (TM == 16) {
+                        if (g < PW && !(fm.ablate & 2)) issue1(stage, g, inc);      // into the buffer just consumed
+                        if (g < 8 && !(fm.ablate & 4)) GPX_SLOT_READ(g, r0a, r0b, aa0, ab0);
+                    } else if ((g & 1) == 0) {                                       // 16 slots: reads on the even ones,
+                        if (!(fm.ablate & 4)) GPX_SLOT_READ(g / 2, r0a, r0b, aa0, ab0);
+                    } else {                                                         // DMA pieces on the odd ones
+                        if (g / 2 < PW && !(fm.ablate & 2)) issue1(stage, g / 2, inc);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
         }
@@ -697,13 +763,13 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_nt_fast_kernel(int64_t M, int6
 
     if (fm.stamps) { __builtin_amdgcn_s_barrier(); st2 = __builtin_amdgcn_s_memtime(); }   // all waves done
     if (fm.atomic_c && !beta0)
-        store_wave_tile_atomic<T, NTW>(acc, C, ldc, M, N, bm0 + wr * 64, bn0 + wc * (BN / 2), lane, alpha, tri, row0,
+        store_wave_tile_atomic<T, NTW, MM, TJ>(acc, C, ldc, M, N, bm0 + wr * 64, bn0 + wc * (BN / 2), lane, alpha, tri, row0,
                                        col0);
     else if (fm.vec_c)
-        store_wave_tile_v2<T, NTW>(acc, C, ldc, M, N, bm0 + wr * 64, bn0 + wc * (BN / 2), lane, alpha, tri, row0,
+        store_wave_tile_v2<T, NTW, MM, TJ>(acc, C, ldc, M, N, bm0 + wr * 64, bn0 + wc * (BN / 2), lane, alpha, tri, row0,
                                    col0, beta0);
     else
-        store_wave_tile<T, NTW>(acc, C, ldc, M, N, bm0 + wr * 64, bn0 + wc * (BN / 2), lane, alpha, tri, row0,
+        store_wave_tile<T, NTW, MM, TJ>(acc, C, ldc, M, N, bm0 + wr * 64, bn0 + wc * (BN / 2), lane, alpha, tri, row0,
                                 col0, beta0);
     if (fm.stamps && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
