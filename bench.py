@@ -294,20 +294,29 @@ def measure_single(args, lib, _lib, N, d, m, dtid, npdt, steps, warmup, local_ra
                     "launches_per_step": g["launches"] / steps,
                     "avg_launch_ms": round(g["ms"] / g["launches"], 4),
                     "flops_per_step": g["work"] / steps}
-        # HBM-side bytes per launch of that kernel: PMC counters cannot be read from inside this
-        # process, so the figure is the committed rocprofv3 --pmc measurement of THIS command and
-        # workload (two separate passes, FETCH_SIZE with the gfx950 x2 correction + WRITE_SIZE);
-        # null for any workload that was not profiled
+        # HBM-side bytes per launch of that kernel: PMC counters cannot be read from inside this process, so
+        # the figure is the committed rocprofv3 --pmc measurement of THIS command and workload (two separate
+        # passes, FETCH_SIZE with the gfx950 x2 correction + WRITE_SIZE; tools/profile_round.sh).  It is only
+        # reported when it was taken with the GEMM source that is running now (sha256 of gpx_gemm.hip recorded
+        # beside the counters); otherwise traffic is null and the stale figure is labelled as such.
         if N == 65536 and d == 32 and dtype_name == "f64":
             try:
-                pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc",
-                                        "traffic_n65536_v8.json")
-                with open(pmc_path) as f:
+                import hashlib
+                here = os.path.dirname(os.path.abspath(__file__))
+                with open(os.path.join(here, "profiles", "r02_pmc", "traffic_n65536.json")) as f:
                     pmc = json.load(f)
-                roofline["traffic"] = round(pmc["traffic_bytes_per_launch"])
-                roofline["traffic_unit"] = "bytes per launch (fetch corrected %.3e + write %.3e)" % (
+                with open(os.path.join(here, "gaussian_processes_amd", "csrc", "gpx_gemm.hip"), "rb") as f:
+                    sha = hashlib.sha256(f.read()).hexdigest()
+                label = "bytes per launch (fetch corrected %.3e + write %.3e)" % (
                     pmc["fetch_bytes_per_launch_corrected"], pmc["write_bytes_per_launch"])
-                roofline["traffic_source"] = "profiles/r01_pmc/traffic_n65536_v8.json (rocprofv3 --pmc, offline)"
+                if pmc.get("gemm_source_sha256") == sha:
+                    roofline["traffic"] = round(pmc["traffic_bytes_per_launch"])
+                    roofline["traffic_unit"] = label
+                    roofline["traffic_over_algorithmic"] = round(pmc["traffic_over_algorithmic"], 2)
+                else:
+                    roofline["traffic_stale"] = {"value": round(pmc["traffic_bytes_per_launch"]), "unit": label,
+                                                 "note": "measured with an earlier build of gpx_gemm.hip"}
+                roofline["traffic_source"] = "profiles/r02_pmc/traffic_n65536.json (rocprofv3 --pmc, offline)"
             except (OSError, KeyError, ValueError):
                 pass
     potrf_tflops = (N ** 3 / 3.0) / (stage_ms[1] * 1e-3) / 1e12 if stage_ms[1] > 0 else None
