@@ -572,7 +572,7 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_nt_fast_kernel(int64_t M, int6
     if (fm.stamps) { st0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
 
     // ktri: rows >= bm0 of an upper-triangular operand are zero for k < bm0 (bm0 is a multiple of EPK)
-    const int kskip = fm.ktri ? (int)(min(bm0, K - EPK) / EPK) : 0;
+    const int kskip = fm.ktri == 1 ? (int)(min(bm0, K - EPK) / EPK) : 0;
     // ---- DMA source pointers: wave w owns pieces PW*w .. PW*w + PW-1 (1 KiB = 8 rows each) of every stage ----
     const unsigned char *gsrc[PW];      // next 128-B k-slice to fetch, per DMA piece
     {
@@ -598,7 +598,9 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_nt_fast_kernel(int64_t M, int6
 #pragma unroll
             for (int r = 0; r < MM::NR; ++r) acc[i][j][r] = (T)0;
 
-    const int nk = (int)(K / EPK) - kskip;
+    // ktri == 2: the B operand is LOWER triangular in (row, k) (W = inv(L)): tile columns [bn0, bn0 + BN)
+    // only have k < bn0 + BN, the k-loop ends there
+    const int nk = (int)((fm.ktri == 2 ? min(K, bn0 + (int64_t)BN) : K) / EPK) - kskip;
     // three stages in flight before the first wait; when K has fewer than three slices the
     // extra stages re-fetch the last slice (never read)
     {
@@ -817,7 +819,7 @@ static int launch_gemm_nt_fast(int64_t M, int64_t N, int64_t K, const void *A, i
     const int nbatch = bt ? bt->count : 1;
     fm.sA = bt ? bt->sA : 0; fm.sB = bt ? bt->sB : 0; fm.sC = bt ? bt->sC : 0;
     fm.dbegin = 0x7fffffff; fm.ndiag = 0; fm.bdiag = 0;
-    fm.ktri = (ktri && M == N && N == K) ? 1 : 0;
+    fm.ktri = (ktri == 1 && M == N && N == K) ? 1 : ((ktri == 2 && N == K) ? 2 : 0);
     int64_t dblocks = 0;
     {
         static const bool no_split = getenv("GPX_GEMM_NO_DSPLIT") != nullptr;

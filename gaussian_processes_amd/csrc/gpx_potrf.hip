@@ -341,10 +341,129 @@ static int leaf_scratch(size_t bytes, void **out)
 // row substitution below it.
 template <typename T>
 static int potrf_panel_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int64_t kb, int *info_dev,
-                         hipStream_t st, int dtype, const Batch *bt)
+                         hipStream_t st, int dtype, const Batch *bt, T *inv_slots = nullptr, int64_t pc0 = 0);
+
+template <typename T>
+__global__ void place_inv_kernel(const T *__restrict__ slots, T *__restrict__ W, T *__restrict__ Wt, int64_t ld)
+{
+    // block b: W[b, b] = X_b (the leaf's 64 x 64 inverse, row-major), Wt[b, b] = X_b^T
+    const T *X = slots + (int64_t)blockIdx.x * (IB * IB);
+    const int64_t o = (int64_t)blockIdx.x * IB * (ld + 1);
+    for (int idx = threadIdx.x; idx < IB * IB; idx += blockDim.x) {
+        const int r = idx / IB, c = idx - r * IB;
+        const T v = X[idx];
+        W[o + (int64_t)r * ld + c] = v;
+        Wt[o + (int64_t)c * ld + r] = v;
+    }
+}
+
+template <typename T>
+__global__ void copy2d_kernel(const T *__restrict__ src, int64_t lds, T *__restrict__ dst, int64_t ldd, int64_t rows,
+                              int cols)
+{
+    constexpr int V = 16 / sizeof(T);
+    const int chunks = cols / V;                          // cols % 16 == 0 here
+    const int64_t total = rows * chunks;
+    struct alignas(16) Q { T e[V]; };
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / chunks;
+        const int c = (int)(i - r * chunks) * V;
+        *reinterpret_cast<Q *>(dst + r * ldd + c) = *reinterpret_cast<const Q *>(src + r * lds + c);
+    }
+}
+
+// grow-only scratch of the tall-panel route (one per host thread and device)
+struct PanelScratch { void *p = nullptr; size_t bytes = 0; int device = -1; };
+static thread_local PanelScratch g_pscr;
+static int panel_scratch(size_t bytes, void **out)
+{
+    int dev = 0;
+    GPX_HIP(hipGetDevice(&dev));
+    if (g_pscr.device != dev || g_pscr.bytes < bytes) {
+        if (g_pscr.p && g_pscr.device == dev) { GPX_HIP(hipDeviceSynchronize()); (void)hipFree(g_pscr.p); }
+        g_pscr.p = nullptr; g_pscr.bytes = 0; g_pscr.device = dev;
+        GPX_HIP(hipMalloc(&g_pscr.p, bytes));
+        g_pscr.bytes = bytes;
+    }
+    *out = g_pscr.p;
+    return GPX_OK;
+}
+
+// Tall panel (rows below the diagonal block >> its width): "diagonal block first".
+//   1. factor ONLY the kb x kb diagonal block (the recursion below sees no further rows); every 64 x 64 leaf
+//      leaves its inverse in a slot;
+//   2. W = inv(L11) (kb x kb, lower) by recursive doubling from the leaf inverses: for block size s -> 2 s
+//      W21 = -W22 L21 W11, three s x s x s products per pair, all pairs of a level in one batched launch
+//      (W and its transpose are both kept: the NT product needs either operand row-major);
+//   3. ALL rows below in ONE product  T = A21 W^T  (K = kb deep on the MFMA kernel, the k-loop of a tile
+//      column stops at the triangle's edge), copied back over A21.
+// The rows below are then touched by 1 efficient launch instead of 2 (kb / 64) thin ones (a one-lane-per-row
+// substitution or a K = 64 product per leaf, plus the K = 64 ... kb / 2 updates in between).
+template <typename T>
+static int potrf_panel_tall(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int64_t kb, int *info_dev,
+                            hipStream_t st, int dtype)
+{
+    const int64_t below = n - (r0 + kb);
+    const int nleaf = (int)(kb / IB);
+    const size_t es = sizeof(T);
+    // scratch: leaf inverses | W | Wt | Pt (kb x kb each, ld = kb) | T (below x kb)
+    const size_t o_w = (size_t)nleaf * IB * IB, o_wt = o_w + (size_t)kb * kb, o_pt = o_wt + (size_t)kb * kb,
+                 o_t = o_pt + (size_t)kb * kb, total = o_t + (size_t)below * kb;
+    void *scr = nullptr;
+    GPX_TRY(panel_scratch(total * es, &scr));
+    T *slots = (T *)scr, *W = slots + o_w, *Wt = slots + o_wt, *Pt = slots + o_pt, *Tm = slots + o_t;
+    // 1. the diagonal block
+    GPX_TRY(potrf_panel_t<T>(A, lda, r0 + kb, r0, c0, kb, info_dev, st, dtype, nullptr, slots, c0));
+    // 2. W = inv(L11)
+    GPX_HIP(hipMemsetAsync(W, 0, 2 * (size_t)kb * kb * es, st));           // W and Wt
+    hipLaunchKernelGGL((place_inv_kernel<T>), dim3(nleaf), dim3(256), 0, st, slots, W, Wt, kb);
+    GPX_LAUNCH_CHECK();
+    const T *L11 = A + r0 * lda + c0;
+    for (int64_t s = IB; s < kb; s *= 2) {
+        Batch b;
+        b.count = (int)(kb / (2 * s));
+        const int64_t dW = 2 * s * kb + 2 * s, dL = 2 * s * lda + 2 * s;
+        // Pt = W11^T L21^T  (s x s):  gemm_nt(A = Wt11, B = L21)
+        b.sA = dW; b.sB = dL; b.sC = dW;
+        GPX_TRY(gemm_nt(dtype, s, s, s, Wt, kb, L11 + s * lda, lda, Pt, kb, 1.0, GPX_FULL, 0, 0, st, 1, 0, &b));
+        // W21 = -W22 (L21 W11) = -W22 Pt^T:  gemm_nt(A = W22, B = Pt)
+        b.sA = dW; b.sB = dW; b.sC = dW;
+        GPX_TRY(gemm_nt(dtype, s, s, s, W + s * kb + s, kb, Pt, kb, W + s * kb, kb, -1.0, GPX_FULL, 0, 0, st, 1, 0, &b));
+        // (W^T)12 = W21^T = -Pt W22^T:  gemm_nt(A = Pt, B = W22)   -- not needed after the last level
+        if (2 * s < kb)
+            GPX_TRY(gemm_nt(dtype, s, s, s, Pt, kb, W + s * kb + s, kb, Wt + s, kb, -1.0, GPX_FULL, 0, 0, st, 1, 0, &b));
+    }
+    // 3. T = A21 W^T, then back over A21
+    const T *A21 = A + (r0 + kb) * lda + c0;
+    GPX_TRY(gemm_nt(dtype, below, kb, kb, A21, lda, W, kb, Tm, kb, 1.0, GPX_FULL, 0, 0, st, 1, 2));
+    const unsigned blocks = (unsigned)std::min<int64_t>(cdiv(below * (kb / (16 / (int64_t)es)), 256), 8192);
+    hipLaunchKernelGGL((copy2d_kernel<T>), dim3(blocks), dim3(256), 0, st, Tm, kb, A + (r0 + kb) * lda + c0, lda, below,
+                       (int)kb);
+    GPX_LAUNCH_CHECK();
+    return GPX_OK;
+}
+
+static bool tall_route(int64_t below, int64_t kb, int64_t lda, size_t es, const void *base, const Batch *bt)
+{
+    // OPT-IN (GPX_POTRF_TALL=<min rows below>): measured on one MI355X it does not pay -- the doubling adds
+    // 5 - 8 dependent small launches to the panel chain (n = 8192: fit 10.6 -> 13.8 ms; n = 16384: 37.9 -> 45.3;
+    // n = 32768 fp32: 108 -> 116) and at n = 65536, where the chain is hidden anyway, the fit is unchanged
+    // (1.383 vs 1.389 s).  Kept because it is the shape a fused inverse kernel would slot into.
+    static const int64_t env = getenv("GPX_POTRF_TALL") ? atoll(getenv("GPX_POTRF_TALL")) : 0;
+    if (!env || bt) return false;
+    if (kb < 2 * IB || (kb & (kb - 1)) != 0) return false;                 // 128, 256, 512, 1024
+    if (below < 2 * kb || below < env) return false;
+    return lda % (16 / (int64_t)es) == 0 && ((uintptr_t)base) % 16 == 0;
+}
+
+template <typename T>
+static int potrf_panel_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int64_t kb, int *info_dev,
+                         hipStream_t st, int dtype, const Batch *bt, T *inv_slots, int64_t pc0)
 {
     const int nbatch = bt ? bt->count : 1;
     const int64_t sM = bt ? bt->sA : 0;              // stride between the matrices of a batch
+    if (!inv_slots && tall_route(n - (r0 + kb), kb, lda, sizeof(T), A + r0 * lda + c0, bt))
+        return potrf_panel_tall<T>(A, lda, n, r0, c0, kb, info_dev, st, dtype);
     if (kb <= IB) {
         const int jb = (int)kb;
         T *D = A + r0 * lda + c0;
@@ -357,7 +476,9 @@ static int potrf_panel_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, i
                                  lda % (16 / (int64_t)sizeof(T)) == 0 &&
                                  ((uintptr_t)(A + (r0 + jb) * lda + c0)) % 16 == 0;
         T *inv = nullptr;
-        if (via_inverse) {
+        if (inv_slots) {
+            inv = inv_slots + ((c0 - pc0) / IB) * (IB * IB);        // tall-panel route: every leaf keeps its inverse
+        } else if (via_inverse) {
             void *p = nullptr;
             GPX_TRY(leaf_scratch((size_t)nbatch * IB * IB * sizeof(T), &p));
             inv = (T *)p;
@@ -372,7 +493,7 @@ static int potrf_panel_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, i
                                    info_dev, inv, sM);
         }
         GPX_LAUNCH_CHECK();
-        if (via_inverse) {
+        if (inv_slots ? below > 0 : via_inverse) {
             // rows below: X <- X * inv(L_jj)^T, in place (each tile reads all 64 columns of its own
             // rows before its epilogue stores them; no other tile touches those rows)
             T *Xb = A + (r0 + jb) * lda + c0;
@@ -386,10 +507,10 @@ static int potrf_panel_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, i
         return GPX_OK;
     }
     const int64_t h = ((kb / IB + 1) / 2) * IB;          // left half, a multiple of 64
-    GPX_TRY(potrf_panel_t<T>(A, lda, n, r0, c0, h, info_dev, st, dtype, bt));
+    GPX_TRY(potrf_panel_t<T>(A, lda, n, r0, c0, h, info_dev, st, dtype, bt, inv_slots, pc0));
     T *R = A + (r0 + h) * lda + c0;                       // rows below the left half's diagonal block
     GPX_TRY(gemm_nt(dtype, n - (r0 + h), kb - h, h, R, lda, R, lda, R + h, lda, -1.0, GPX_LOWER, 0, 0, st, 0, 0, bt));
-    return potrf_panel_t<T>(A, lda, n, r0 + h, c0 + h, kb - h, info_dev, st, dtype, bt);
+    return potrf_panel_t<T>(A, lda, n, r0 + h, c0 + h, kb - h, info_dev, st, dtype, bt, inv_slots, pc0);
 }
 
 int potrf_panel(int dtype, void *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int64_t kb,

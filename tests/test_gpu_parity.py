@@ -1037,3 +1037,19 @@ def test_native_mg_world_on_one_gpu_vs_oracle(tmp_path, world, N, nb, dtype_id):
         np.testing.assert_allclose(float(res["log_lh"]), o.log_lh, rtol=1e-4)
         np.testing.assert_allclose(res["mean"], o.mean(Xo), rtol=1e-3, atol=1e-3)
     assert float(res["log_lh2"]) == float(res["log_lh"])
+
+
+def test_tall_panel_route_opt_in_vs_oracle(monkeypatch):
+    """GPX_POTRF_TALL (opt-in): diagonal block first, W = inv(L11) by recursive doubling (batched s x s x s
+    products), all rows below in one product with the lower-triangular k-loop cut (ktri = 2)."""
+    monkeypatch.setenv("GPX_POTRF_TALL", "1")
+    N, d = 2600, 3
+    X, y, Xo = orc.synth_inputs(N, d, 32)
+    h, w, s = 1.0, 0.5 * np.sqrt(d), 1.0
+    for nb in ("128", "512"):
+        monkeypatch.setenv("GPX_POTRF_NB", nb)
+        g = gp.GP(gp.GaussianKernel(h, w), X, y, s=s)
+        o = orc.OracleGP("gaussian", (h, w), X, y, s)
+        np.testing.assert_allclose(g.log_lh, o.log_lh, rtol=1e-10)
+        np.testing.assert_allclose(g.Lxx, o.Lxx, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(g.inv_Kxx_y, o.inv_Kxx_y, rtol=1e-8, atol=1e-11)
