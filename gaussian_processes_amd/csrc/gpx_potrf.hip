@@ -53,46 +53,17 @@ __device__ __forceinline__ float fast_rsqrt(float p)
     return y;
 }
 
+// The sweep itself: a[4][4] (this thread's tile of the block, lower part meaningful, identity padded beyond jb)
+// is factored in place; with INV x[4][4] (the identity on entry) becomes the tile of X = L^-1.
 template <typename T, bool INV>
-__global__ __launch_bounds__(256) void potrf_diag_kernel(T *__restrict__ blk, int64_t lda, int64_t j0,
-                                                         int jb, int *__restrict__ info, T *__restrict__ inv,
-                                                         int64_t sblk)
+__device__ __forceinline__ void factor64(T (&a)[4][4], T (&x)[4][4], int jb, int64_t j0, int *__restrict__ info)
 {
-    // batched launches: workgroup b factors the block of matrix b (stride sblk), own info word and inverse
-    blk += (int64_t)blockIdx.x * sblk;
-    info += blockIdx.x;
-    if (INV) inv += (int64_t)blockIdx.x * (IB * IB);
-    // blk: the jb x jb diagonal block; j0: its global (0-based) index, for `info`
     __shared__ T sD[4][4];            // factored diagonal tile of the step (lower part)
     __shared__ T sR[4];               // its reciprocal pivots
     __shared__ T pan[IB][4];          // the step's 4 finished columns of L, rows below the diagonal tile
     __shared__ T xrow[4][IB];         // INV: the step's 4 finished rows of X
-    // this one workgroup is the critical path of the whole panel and usually shares its CU with
-    // trailing-update workgroups of the other stream: take the instruction arbiter's top priority
-    __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x;
     const int tr = tid >> 4, tc = tid & 15;
-    // an earlier block already failed: the factor is garbage from there on, do not spend the chain on it
-    __shared__ int s_abort;
-    if (tid == 0) s_abort = *info;
-    __syncthreads();
-    if (s_abort != 0) return;
-    T a[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int row = 4 * tr + r, col = 4 * tc + c;
-            T v = (row == col) ? (T)1 : (T)0;
-            if (row < jb && col <= row) v = blk[(int64_t)row * lda + col];
-            a[r][c] = v;
-        }
-    T x[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) x[r][c] = (4 * tr + r == 4 * tc + c) ? (T)1 : (T)0;
-
 #pragma unroll 1
     for (int jt = 0; jt < IB / 4; ++jt) {
         // ---- A: the diagonal tile ----
@@ -193,6 +164,44 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(T *__restrict__ blk, in
         // (no barrier: the next step's A touches only its own registers and sD / sR, which
         //  nobody reads in C; pan / xrow are rewritten only after the next step's first barrier)
     }
+}
+
+template <typename T, bool INV>
+__global__ __launch_bounds__(256) void potrf_diag_kernel(T *__restrict__ blk, int64_t lda, int64_t j0,
+                                                         int jb, int *__restrict__ info, T *__restrict__ inv,
+                                                         int64_t sblk)
+{
+    // batched launches: workgroup b factors the block of matrix b (stride sblk), own info word and inverse
+    blk += (int64_t)blockIdx.x * sblk;
+    info += blockIdx.x;
+    if (INV) inv += (int64_t)blockIdx.x * (IB * IB);
+    // blk: the jb x jb diagonal block; j0: its global (0-based) index, for `info`
+    // this one workgroup is the critical path of the whole panel and usually shares its CU with
+    // trailing-update workgroups of the other stream: take the instruction arbiter's top priority
+    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x;
+    const int tr = tid >> 4, tc = tid & 15;
+    // an earlier block already failed: the factor is garbage from there on, do not spend the chain on it
+    __shared__ int s_abort;
+    if (tid == 0) s_abort = *info;
+    __syncthreads();
+    if (s_abort != 0) return;
+    T a[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int row = 4 * tr + r, col = 4 * tc + c;
+            T v = (row == col) ? (T)1 : (T)0;
+            if (row < jb && col <= row) v = blk[(int64_t)row * lda + col];
+            a[r][c] = v;
+        }
+    T x[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) x[r][c] = (4 * tr + r == 4 * tc + c) ? (T)1 : (T)0;
+    factor64<T, INV>(a, x, jb, j0, info);
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -201,6 +210,223 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(T *__restrict__ blk, in
             if (row < jb && col <= row) blk[(int64_t)row * lda + col] = a[r][c];
             if (INV) inv[row * IB + col] = (col <= row) ? x[r][c] : (T)0;
         }
+}
+
+// ---- fused panel step: one launch per 64 columns of a panel ---------------------------------------
+// Replaces, per 64-column step of a panel, the chain  leaf -> row substitution -> in-panel update(s)  (3 - 4
+// dependent launches of 12 - 30 us each beside a running trailing update) by ONE launch, left-looking inside
+// the panel.  Step s of the panel at (r0p, c0p), columns [c0, c0 + 64), kin = 64 s columns to its left:
+//   workgroup 0      D' = D - Lp Lp^T (Lp = the diagonal block's rows of the panel columns to the left, MFMA),
+//                    factors D' and forms X = inv(L) in registers (factor64), stores L, publishes X and
+//                    raises a flag (agent-scope release);
+//   workgroup w > 0  64 rows below: R' = R - (their rows of the panel columns to the left) Lp^T on the MFMA
+//                    pipe WHILE workgroup 0 factors, then waits for the flag (one lane polls, bounded spin,
+//                    agent-scope acquire) and stores Y = R' X^T.
+// Operands go global/L2 -> registers directly in MFMA fragment layout (each is used by one wave only).
+// Workgroup 0 is dispatched first, so the producer is resident before any consumer can spin; should that
+// ever fail the spin is bounded and the step reports info = -7 instead of hanging.
+template <typename T> struct PM;
+template <> struct PM<double> {
+    typedef double v4 __attribute__((ext_vector_type(4)));
+    static constexpr int EPK = 16, SUB = 4;
+    __device__ static __forceinline__ v4 mfma(double a, double b, v4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    __device__ static __forceinline__ int row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
+};
+template <> struct PM<float> {
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    static constexpr int EPK = 32, SUB = 8;
+    __device__ static __forceinline__ v4 mfma(float a, float b, v4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    __device__ static __forceinline__ int row(int lane, int reg) { return 4 * (lane >> 4) + reg; }
+};
+
+template <typename T>
+__device__ __forceinline__ void load_frag32(const T *__restrict__ p, T (&f)[PM<T>::SUB])
+{
+    struct alignas(16) Q { unsigned w[4]; };
+    const Q a = reinterpret_cast<const Q *>(p)[0], b = reinterpret_cast<const Q *>(p)[1];
+    memcpy(&f[0], &a, 16);
+    memcpy(&f[PM<T>::SUB / 2], &b, 16);
+}
+
+constexpr int PS_SPIN = 1 << 21;          // polls of ~0.3 us: gives up after ~0.6 s
+
+template <typename T>
+__global__ __launch_bounds__(256) void panel_step_kernel(T *__restrict__ A, int64_t lda, int64_t n, int64_t r0,
+                                                         int64_t c0, int kin, int *__restrict__ info,
+                                                         T *__restrict__ xinv, int *__restrict__ flag, int serial,
+                                                         int64_t sM)
+{
+    typedef PM<T> M;
+    typedef typename M::v4 v4;
+    constexpr int EPK = M::EPK, SUB = M::SUB;
+    A += (int64_t)blockIdx.y * sM; info += blockIdx.y; xinv += (int64_t)blockIdx.y * (IB * IB); flag += blockIdx.y;
+    __shared__ T sT[IB][IB + 2];          // D' (workgroup 0) / R' : accumulator layout -> rows
+    __shared__ int s_ok;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const bool diag = blockIdx.x == 0;
+    if (diag) __builtin_amdgcn_s_setprio(3);
+    if (tid == 0) s_ok = *info;
+    __syncthreads();
+    if (s_ok != 0) {                       // an earlier step failed: nothing to wait for, nothing to compute
+        if (diag && tid == 0) __hip_atomic_store(flag, serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const int64_t wr0 = (diag ? r0 : r0 + IB + (int64_t)(blockIdx.x - 1) * IB) + 16 * wave;   // this wave's 16 rows
+    // ---- P = (own rows of the panel columns to the left) . Lp^T ----
+    v4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[j][r] = (T)0;
+    {
+        const T *arow = A + min(wr0 + li, n - 1) * lda + (c0 - kin) + lq * SUB;
+        const T *brow = A + (r0 + li) * lda + (c0 - kin) + lq * SUB;
+        for (int k = 0; k < kin; k += EPK) {
+            T fa[SUB], fb[4][SUB];
+            load_frag32<T>(arow + k, fa);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) load_frag32<T>(brow + (int64_t)(16 * j) * lda + k, fb[j]);
+#pragma unroll
+            for (int ss = 0; ss < SUB; ++ss)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = M::mfma(fa[ss], fb[j][ss], acc[j]);
+        }
+    }
+    // ---- R' = R - P, into LDS by rows ----
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int lr = M::row(lane, r);
+            const int64_t gr = wr0 + lr;
+            const T v = (gr < n) ? A[gr * lda + c0 + 16 * j + li] : (T)0;
+            sT[16 * wave + lr][16 * j + li] = v - acc[j][r];
+        }
+    __syncthreads();
+    if (diag) {
+        const int tr = tid >> 4, tc = tid & 15;
+        T a[4][4], x[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int row = 4 * tr + r, col = 4 * tc + c;
+                a[r][c] = (col <= row) ? sT[row][col] : (T)0;
+                x[r][c] = (row == col) ? (T)1 : (T)0;
+            }
+        factor64<T, true>(a, x, IB, r0, info);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int row = 4 * tr + r, col = 4 * tc + c;
+                if (col <= row) A[(r0 + row) * lda + c0 + col] = a[r][c];
+                xinv[row * IB + col] = (col <= row) ? x[r][c] : (T)0;
+            }
+        // publish: every storing wave drains, the workgroup meets, ONE lane releases at agent scope and raises the flag
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(flag, serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    // ---- consumers: wait for X (one relaxed poll loop, then ONE agent-scope acquire, then the barrier) ----
+    if (tid == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != serial && spins < PS_SPIN) {
+            __builtin_amdgcn_s_sleep(16);
+            ++spins;
+        }
+        s_ok = spins < PS_SPIN;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (!s_ok) {
+        if (tid == 0) atomicCAS(info, 0, -7);
+        return;
+    }
+    // ---- Y = R' X^T ----
+    v4 y[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[j][r] = (T)0;
+#pragma unroll
+    for (int k = 0; k < IB; k += EPK) {
+        T fa[SUB], fb[4][SUB];
+#pragma unroll
+        for (int ss = 0; ss < SUB; ++ss) fa[ss] = sT[16 * wave + li][k + lq * SUB + ss];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) load_frag32<T>(xinv + (16 * j + li) * IB + k + lq * SUB, fb[j]);
+#pragma unroll
+        for (int ss = 0; ss < SUB; ++ss)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[j] = M::mfma(fa[ss], fb[j][ss], y[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t gr = wr0 + M::row(lane, r);
+            if (gr < n) A[gr * lda + c0 + 16 * j + li] = y[j][r];
+        }
+}
+
+// scratch of the fused steps: per matrix of a batch one 64 x 64 inverse and one flag word; the flag only ever
+// grows (`serial` is bumped per launch), so nothing is reset between launches
+struct FusedScratch { void *p = nullptr; size_t bytes = 0; int device = -1; int serial = 0; };
+static thread_local FusedScratch g_fscr;
+static int fused_scratch(int nbatch, size_t es, void **xinv, int **flag)
+{
+    int dev = 0;
+    GPX_HIP(hipGetDevice(&dev));
+    const size_t need = (size_t)nbatch * (IB * IB * es + 256);
+    if (g_fscr.device != dev || g_fscr.bytes < need) {
+        if (g_fscr.p && g_fscr.device == dev) { GPX_HIP(hipDeviceSynchronize()); (void)hipFree(g_fscr.p); }
+        g_fscr.p = nullptr; g_fscr.bytes = 0; g_fscr.device = dev;
+        GPX_HIP(hipMalloc(&g_fscr.p, need));
+        GPX_HIP(hipMemset(g_fscr.p, 0, need));
+        g_fscr.bytes = need;
+        g_fscr.serial = 0;
+    }
+    *flag = (int *)g_fscr.p;                                       // nbatch words (256-byte slab per 64 matrices is plenty)
+    *xinv = (char *)g_fscr.p + (((size_t)nbatch * sizeof(int) + 255) / 256) * 256;
+    return GPX_OK;
+}
+
+// OPT-IN (GPX_POTRF_FUSED=<max panel width, e.g. 256>).  Measured on one MI355X (n = 8192, nb = 256): a step
+// takes 50 / 55 / 68 / 74 us alone (kin = 0 .. 192: workgroup 0's D' update reads its operands with
+// un-pipelined global loads, 8 - 12 us per 64 columns) and 95 - 130 us beside the trailing update, against
+// ~50 / ~75 us for the leaf + substitution + update launches it replaces: fit 10.55 -> 11.3 ms, the 64-restart
+// lock-step sweep 0.293 -> 0.322 s.  Off by default until the operand loads are pipelined and the leaf itself
+// (26 us of every step) is faster.
+static int64_t fused_max()
+{
+    static const int64_t v = getenv("GPX_POTRF_FUSED") ? atoll(getenv("GPX_POTRF_FUSED")) : 0;
+    return v;
+}
+
+template <typename T>
+static int potrf_panel_fused(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int64_t kb, int *info_dev,
+                             hipStream_t st, const Batch *bt)
+{
+    const int nbatch = bt ? bt->count : 1;
+    void *xinv = nullptr; int *flag = nullptr;
+    GPX_TRY(fused_scratch(nbatch, sizeof(T), &xinv, &flag));
+    for (int64_t s = 0; s < kb; s += IB) {
+        const int64_t below = n - (r0 + s + IB);
+        dim3 grid((unsigned)(1 + cdiv(std::max<int64_t>(below, 0), IB)), (unsigned)nbatch);
+        ProfScope prof(PC_POTRF_DIAG, ((double)IB * IB * IB / 3.0 + (double)std::max<int64_t>(below, 0) * IB * (2.0 * s + IB)) * nbatch, st);
+        hipLaunchKernelGGL((panel_step_kernel<T>), grid, dim3(256), 0, st, A, lda, n, r0 + s, c0 + s, (int)s, info_dev,
+                           (T *)xinv, flag, ++g_fscr.serial, bt ? bt->sA : (int64_t)0);
+    }
+    GPX_LAUNCH_CHECK();
+    return GPX_OK;
 }
 
 // ---- (c) X[r, 0:jb] <- X[r, 0:jb] * Ljj^-T : one lane per row --------------
@@ -464,6 +690,9 @@ static int potrf_panel_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, i
     const int64_t sM = bt ? bt->sA : 0;              // stride between the matrices of a batch
     if (!inv_slots && tall_route(n - (r0 + kb), kb, lda, sizeof(T), A + r0 * lda + c0, bt))
         return potrf_panel_tall<T>(A, lda, n, r0, c0, kb, info_dev, st, dtype);
+    if (!inv_slots && kb % IB == 0 && kb <= fused_max() && lda % (16 / (int64_t)sizeof(T)) == 0 &&
+        ((uintptr_t)(A + r0 * lda + c0)) % 16 == 0 && c0 % (16 / (int64_t)sizeof(T)) == 0)
+        return potrf_panel_fused<T>(A, lda, n, r0, c0, kb, info_dev, st, bt);
     if (kb <= IB) {
         const int jb = (int)kb;
         T *D = A + r0 * lda + c0;

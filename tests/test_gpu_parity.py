@@ -1053,3 +1053,29 @@ def test_tall_panel_route_opt_in_vs_oracle(monkeypatch):
         np.testing.assert_allclose(g.log_lh, o.log_lh, rtol=1e-10)
         np.testing.assert_allclose(g.Lxx, o.Lxx, rtol=1e-9, atol=1e-12)
         np.testing.assert_allclose(g.inv_Kxx_y, o.inv_Kxx_y, rtol=1e-8, atol=1e-11)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_fused_panel_steps_opt_in_vs_oracle(monkeypatch, dtype):
+    """GPX_POTRF_FUSED (opt-in): one launch per 64 panel columns -- workgroup 0 updates, factors and inverts
+    the diagonal block and raises an agent-scope flag, the other workgroups do their left-looking update
+    meanwhile, poll (bounded) and apply the inverse.  Single matrices and the lock-step batch."""
+    from gaussian_processes_amd import mlii
+    monkeypatch.setenv("GPX_POTRF_FUSED", "256")
+    N, d = 1800, 3
+    X, y, Xo = orc.synth_inputs(N, d, 32)
+    h, w, s = 1.0, 0.5 * np.sqrt(d), 1.0
+    tol = dict(rtol=1e-10) if dtype == "float64" else dict(rtol=1e-4)
+    for nb in ("128", "256"):
+        monkeypatch.setenv("GPX_POTRF_NB", nb)
+        g = gp.GP(gp.GaussianKernel(h, w), X, y, s=s, dtype=dtype)
+        o = orc.OracleGP("gaussian", (h, w), X, y, s)
+        np.testing.assert_allclose(g.log_lh, o.log_lh, **tol)
+        if dtype == "float64":
+            np.testing.assert_allclose(g.Lxx, o.Lxx, rtol=1e-9, atol=1e-12)
+            np.testing.assert_allclose(g.inv_Kxx_y, o.inv_Kxx_y, rtol=1e-8, atol=1e-11)
+    thetas = np.array([[1.0, 0.9, 1.0], [0.7, 1.4, 0.8], [1.0, 50.0, 0.0]])
+    llh = mlii.log_lh_batch(X, y, thetas, dtype=dtype)
+    for i in range(2):
+        np.testing.assert_allclose(llh[i], orc.OracleGP("gaussian", thetas[i, :2], X, y, thetas[i, 2]).log_lh, **tol)
+    assert llh[2] == -np.inf
