@@ -457,7 +457,7 @@ struct GemmMap {
     // batched launches (blockIdx.y = matrix index): element strides between consecutive matrices
     int64_t sA, sB, sC;
     int sflag;    // stride of abort_flag (one info word per matrix)
-    // EXACT enumeration (BM = 128, lower-triangular single-rank maps whose triangle is tile aligned): the
+    // EXACT enumeration (BM = 128, lower-triangular trailing updates whose triangle is tile aligned): the
     // grid holds only tiles that exist -- tile (i, j) with j <= min(eTC - 1, i + eD), i < eTR.  Order: bands
     // of 8 tile rows, column-major inside a band, so that 64 consecutive tiles are an 8 x 8 patch (8 A- and
     // 8 B-slices); chunks of 2^ecl consecutive tiles go to one XCD (chunk c -> blocks with blockIdx % 8 ==
@@ -465,6 +465,9 @@ struct GemmMap {
     // small matrix launched up to 6 x more workgroups than it has tiles (n = 8192, nb = 256: 800 for the
     // 124 tiles of a block-column update), each still passing through the dispatcher.
     int exact, ecl, eT, eD, eTR, eTC, ebands;
+    // block-cyclic ranks (P > 1): local tile column j is GLOBAL tile column j + (j / etpb) * epm1t (etpb = nb / 128
+    // tile columns per block column, epm1t = (P - 1) * etpb); the triangle is tested in global columns
+    int etpb, epm1t;
     int epre[66];
 };
 static unsigned long long *g_gemm_stamps = nullptr;
@@ -514,15 +517,21 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_nt_fast_kernel(int64_t M, int6
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (fm.epre[mid] <= t) lo = mid; else hi = mid; }
         int tt = t - fm.epre[lo];
         const int h = min(8, fm.eTR - 8 * lo);                        // tile rows in this band
-        const int dj = 8 * lo + fm.eD;                                // column j holds rows r >= j - dj
-        const int jfull = max(0, min(fm.eTC, dj + 1));                // columns that hold all h rows
+        const int dj = 8 * lo + fm.eD;                                // column j holds rows r >= g(j) - dj
+        // columns that hold all h rows: local columns whose global column is <= dj
+        int jfull = 0;
+        if (dj >= 0) {
+            const int period = fm.etpb + fm.epm1t, qd = (dj + 1) / period, rem = (dj + 1) - qd * period;
+            jfull = min(fm.eTC, qd * fm.etpb + min(rem, fm.etpb));
+        }
         int j, r;
         if (tt < jfull * h) { j = tt / h; r = tt - j * h; }
         else {
             tt -= jfull * h;
             j = jfull;
             for (;;) {                                                // at most 8 partial columns
-                const int rmin = max(0, j - dj), cnt = max(0, h - rmin);
+                const int gj = j + (j / fm.etpb) * fm.epm1t;
+                const int rmin = max(0, gj - dj), cnt = max(0, h - rmin);
                 if (tt < cnt) { r = rmin + tt; break; }
                 tt -= cnt; ++j;
             }
@@ -977,17 +986,24 @@ int syrk_bc(int dtype, int64_t n, int64_t row_begin, void *Cloc, int64_t ldc, in
             // single rank, triangle aligned to the 128 x 128 tiles: enumerate exactly the tiles that exist
             static const int exact_env = getenv("GPX_GEMM_EXACT") ? atoi(getenv("GPX_GEMM_EXACT")) : 1;
             const int64_t off = row_begin - G0;                       // row origin minus column origin (global)
-            if (exact_env && P == 1 && fast_bm() == 128 && off % 128 == 0 && cdiv(M, 1024) <= 64) {
+            if (exact_env && fast_bm() == 128 && off % 128 == 0 && cdiv(M, 1024) <= 64 && cl0 % nb == 0) {
                 const int TR = (int)cdiv(M, 128), TC = (int)cdiv(Ncols, 128), D = (int)(off / 128);
                 const int bands = (int)cdiv(TR, 8);
+                const int tpb = (int)(nb / 128), pm1t = (P - 1) * tpb;
+                fm.etpb = tpb; fm.epm1t = pm1t;
                 int total = 0;
                 for (int b = 0; b < bands; ++b) {
                     fm.epre[b] = total;
                     const int h = std::min(8, TR - 8 * b), dj = 8 * b + D;
-                    const int jfull = std::max(0, std::min(TC, dj + 1));
+                    int jfull = 0;
+                    if (dj >= 0) {
+                        const int period = tpb + pm1t, qd = (dj + 1) / period, rem = (dj + 1) - qd * period;
+                        jfull = std::min(TC, qd * tpb + std::min(rem, tpb));
+                    }
                     total += jfull * h;
                     for (int j = jfull; j < TC; ++j) {
-                        const int cnt = std::max(0, h - std::max(0, j - dj));
+                        const int gj = j + (j / tpb) * pm1t;
+                        const int cnt = std::max(0, h - std::max(0, gj - dj));
                         if (cnt == 0) break;
                         total += cnt;
                     }
