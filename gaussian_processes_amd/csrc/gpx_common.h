@@ -85,7 +85,11 @@ int make_kparams(int kernel, int member, const double *params, double diag_add, 
 
 // Batched launches: `count` matrices of identical shape; element strides between consecutive
 // matrices for the A / B / C operands of a product (one stride for everything else).
-struct Batch { int count; int64_t sA, sB, sC; };
+// Optional second batch dimension (count2 > 1; launch grid z): matrix (i, i2) sits at i * s + i2 * t.
+struct Batch {
+    int count; int64_t sA, sB, sC;
+    int count2 = 1; int64_t tA = 0, tB = 0, tC = 0;
+};
 
 // internal (non-ABI) helpers shared between translation units
 // C = beta * C + alpha * A * B^T with beta = 1 (default) or 0 (beta0 != 0: C is not read)
@@ -103,8 +107,12 @@ int syrk_bc(int dtype, int64_t n, int64_t row_begin, void *Cloc, int64_t ldc, in
 int potrf_panel(int dtype, void *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int64_t kb,
                 int *info_dev, hipStream_t st, const Batch *bt = nullptr);
 int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t st, const Batch *bt = nullptr);
+// Per-factor block operators of the single-right-hand-side solves (gpx_solve.hip, "operator form"): owned by
+// whoever owns the factor; `valid` must be cleared whenever the factor changes.  nullptr: built per call.
+struct TrsvOps { void *buf = nullptr; size_t bytes = 0; bool valid = false; };
 int trsv_lower(int dtype, const void *L, int64_t n, int64_t ldl, void *b, void *x, int transpose,
-               hipStream_t st, const Batch *bt = nullptr);   // bt: sA = stride of L, sB = stride of b / x
+               hipStream_t st, const Batch *bt = nullptr,   // bt: sA = stride of L, sB = stride of b / x
+               TrsvOps *ops = nullptr);
 int trsm_right_lt(int dtype, const void *L, int64_t n, int64_t ldl, void *X, int64_t m, int64_t ldx,
                   hipStream_t st, int x_upper = 0);
 int logdet_chol(int dtype, const void *L, int64_t n, int64_t ldl, double *out_dev, hipStream_t st, int count = 1,

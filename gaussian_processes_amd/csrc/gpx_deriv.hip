@@ -261,8 +261,8 @@ static int deriv_vectors(DerivState &D)
     for (int i = 0; i <= np; ++i) {
         void *t0 = D.tmp.p, *t1 = (char *)D.tmp.p + (size_t)n * D.es;
         GPX_HIP(hipMemcpyAsync(t0, D.v(i), (size_t)n * D.es, hipMemcpyDeviceToDevice, g->st));
-        GPX_TRY(trsv_lower(g->dtype, g->A, n, g->lda, t0, t1, 0, g->st));
-        GPX_TRY(trsv_lower(g->dtype, g->A, n, g->lda, t1, D.u(i), 1, g->st));
+        GPX_TRY(trsv_lower(g->dtype, g->A, n, g->lda, t0, t1, 0, g->st, nullptr, &g->ops));
+        GPX_TRY(trsv_lower(g->dtype, g->A, n, g->lda, t1, D.u(i), 1, g->st, nullptr, &g->ops));
     }
     return GPX_OK;
 }

@@ -456,6 +456,7 @@ struct GemmMap {
     const int *abort_flag;
     // batched launches (blockIdx.y = matrix index): element strides between consecutive matrices
     int64_t sA, sB, sC;
+    int64_t tA, tB, tC;   // second batch dimension (blockIdx.z)
     int sflag;    // stride of abort_flag (one info word per matrix)
     // EXACT enumeration (BM = 128, lower-triangular trailing updates whose triangle is tile aligned): the
     // grid holds only tiles that exist -- tile (i, j) with j <= min(eTC - 1, i + eD), i < eTR.  Order: bands
@@ -502,9 +503,14 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_nt_fast_kernel(int64_t M, int6
     (void)NTW;
     // requested now, looked at after the prologue's DMA is under way (its latency hides there)
     const int aborted = fm.abort_flag ? fm.abort_flag[(int64_t)blockIdx.y * fm.sflag] : 0;
-    A += (int64_t)blockIdx.y * fm.sA; B += (int64_t)blockIdx.y * fm.sB; C += (int64_t)blockIdx.y * fm.sC;
+    A += (int64_t)blockIdx.y * fm.sA + (int64_t)blockIdx.z * fm.tA;
+    B += (int64_t)blockIdx.y * fm.sB + (int64_t)blockIdx.z * fm.tB;
+    C += (int64_t)blockIdx.y * fm.sC + (int64_t)blockIdx.z * fm.tC;
     const int bid = blockIdx.x;
-    const int xcd = bid & 7, loc = bid >> 3;
+    // hardware XCD = blockIdx.x % 8 (the grid's x extent is a multiple of 8).  In a batched launch every
+    // matrix would send its first patch / chunk to the same XCD -- a batch of small products (one patch each)
+    // then runs on an eighth of the chip -- so the logical XCD is rotated by the matrix index.
+    const int xcd = (bid - (int)blockIdx.y - 3 * (int)blockIdx.z) & 7, loc = bid >> 3;
     constexpr int RSH = BM == 256 ? 2 : 3;                          // log2 of the tile rows per patch
     const int tsh = RSH + fm.csh;
     int patch = (loc >> tsh) * 8 + xcd, within = loc & ((1 << tsh) - 1);
@@ -827,6 +833,8 @@ static int launch_gemm_nt_fast(int64_t M, int64_t N, int64_t K, const void *A, i
     }
     const int nbatch = bt ? bt->count : 1;
     fm.sA = bt ? bt->sA : 0; fm.sB = bt ? bt->sB : 0; fm.sC = bt ? bt->sC : 0;
+    fm.tA = bt ? bt->tA : 0; fm.tB = bt ? bt->tB : 0; fm.tC = bt ? bt->tC : 0;
+    const int nbatch2 = bt ? bt->count2 : 1;
     fm.dbegin = 0x7fffffff; fm.ndiag = 0; fm.bdiag = 0;
     fm.ktri = (ktri == 1 && M == N && N == K) ? 1 : ((ktri == 2 && N == K) ? 2 : 0);
     int64_t dblocks = 0;
@@ -868,8 +876,8 @@ static int launch_gemm_nt_fast(int64_t M, int64_t N, int64_t K, const void *A, i
     int64_t blocks = ablocks + dblocks;
     if (BM == 128 && fm.exact) blocks = cdiv(fm.eT, (int64_t)8 << fm.ecl) * ((int64_t)8 << fm.ecl);
     ProfScope prof(TAG == 1 ? PC_GEMM : (BN == 128 ? PC_GEMM_PANEL : PC_GEMM_SKINNY),
-                   (work >= 0 ? work : 2.0 * (double)K * updated_elements(M, N, tri, row0, col0)) * nbatch, st);
-    hipLaunchKernelGGL((gemm_nt_fast_kernel<T, BN, TAG, BM>), dim3((unsigned)blocks, (unsigned)nbatch), dim3(BM * 2), F_SMEM, st, M, N, K,
+                   (work >= 0 ? work : 2.0 * (double)K * updated_elements(M, N, tri, row0, col0)) * nbatch * nbatch2, st);
+    hipLaunchKernelGGL((gemm_nt_fast_kernel<T, BN, TAG, BM>), dim3((unsigned)blocks, (unsigned)nbatch, (unsigned)nbatch2), dim3(BM * 2), F_SMEM, st, M, N, K,
                        (const T *)A, lda, (const T *)B, ldb, (T *)C, ldc, (T)alpha, tri, row0, col0, fm, beta0);
     GPX_LAUNCH_CHECK();
     return GPX_OK;
@@ -922,6 +930,7 @@ int gemm_nt(int dtype, int64_t M, int64_t N, int64_t K, const void *A, int64_t l
                                           -1.0, beta0, 0, bt);
     }
     if (beta0) { set_error("gemm_nt: beta = 0 needs the aligned fast path"); return GPX_ERR_UNSUPPORTED; }
+    if (bt && bt->count2 > 1) { set_error("gemm_nt: a two-dimensional batch needs the aligned fast path"); return GPX_ERR_UNSUPPORTED; }
     Batch one; one.count = 1; one.sA = one.sB = one.sC = 0;
     if (dtype == GPX_F64)
         return launch_gemm_nt<double>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0, col0, st, bt ? *bt : one);

@@ -153,7 +153,7 @@ int gpx_gp_destroy(gpx_gp_t *g)
     if (!g) return GPX_OK;
     gpx::DeviceGuard guard__(g->device);
     if (g->st) (void)hipStreamSynchronize(g->st);
-    void *bufs[] = {g->x, g->y, g->A, g->alpha, g->t0, g->t1, g->scal, g->bw};
+    void *bufs[] = {g->x, g->y, g->A, g->alpha, g->t0, g->t1, g->scal, g->bw, g->ops.buf};
     for (void *b : bufs) if (b) (void)hipFree(b);
     for (int i = 0; i < 6; ++i) if (g->ev[i]) (void)hipEventDestroy(g->ev[i]);
     if (g->st) (void)hipStreamDestroy(g->st);
@@ -239,8 +239,9 @@ int gpx_gp_fit(gpx_gp_t *g, int *info)
     GPX_HIP(hipEventRecord(g->ev[2], st));
     // inv_Kxx_y = cho_solve((L, True), y) (gp/gp.py:332-334)
     GPX_HIP(hipMemcpyAsync(g->t0, g->y, (size_t)g->n * es, hipMemcpyDeviceToDevice, st));
-    GPX_TRY(trsv_lower(g->dtype, g->A, g->n, g->lda, g->t0, g->t1, 0, st));
-    GPX_TRY(trsv_lower(g->dtype, g->A, g->n, g->lda, g->t1, g->alpha, 1, st));
+    g->ops.valid = false;                                 // a new factor: its block operators are rebuilt once
+    GPX_TRY(trsv_lower(g->dtype, g->A, g->n, g->lda, g->t0, g->t1, 0, st, nullptr, &g->ops));
+    GPX_TRY(trsv_lower(g->dtype, g->A, g->n, g->lda, g->t1, g->alpha, 1, st, nullptr, &g->ops));
     GPX_HIP(hipEventRecord(g->ev[3], st));
     // logdet (replaces slogdet(K), gp_c.pyx:21) and y^T alpha (gp_c.pyx:26)
     GPX_TRY(logdet_chol(g->dtype, g->A, g->n, g->lda, g->scal + 0, st));

@@ -16,6 +16,8 @@ struct gpx_gp {
     float ms[5];
     // fit_batch workspace (grow-only, freed with the handle): the matrices of one chunk + their vectors
     void *bw; size_t bw_bytes; int64_t bw_cap;
+    // block operators of the triangular solves (built once per factor, reused by every later solve)
+    gpx::TrsvOps ops;
 };
 
 namespace gpx {

@@ -11,6 +11,7 @@
 // ONE batched launch (trinv64_kernel); the solve then advances 512 columns per
 // launch (trsv_fwd_fused / trsv_bwd_fused below).
 #include "gpx_common.h"
+#include "gpx_leaf.h"
 
 namespace gpx {
 
@@ -18,40 +19,48 @@ constexpr int SB = 64;
 constexpr int SBP = SB + 1;
 
 // ---- batched inverse of the 64 x 64 diagonal blocks --------------------------
-// One workgroup per block (all blocks in one launch); lane c builds column c of
-// X = inv(L_jj) by forward substitution.  Blocks shorter than 64 are padded with
-// the identity.  Output W[blk][64][64] laid out for coalesced mat-vec reads (lane =
-// output row): FWD  W[c*64 + r] = X[r][c]  (z = X v);  !FWD  W[c*64 + r] = X[c][r]
-// (a = X^T v).
-template <typename T, bool FWD>
-__global__ __launch_bounds__(64) void trinv64_kernel(const T *__restrict__ L, int64_t ldl, int64_t ncols,
-                                                     T *__restrict__ Linv, int64_t bsL, int64_t bsLinv)
+// One 256-thread workgroup per block (all blocks in one launch): the register-resident 4 x 4-tile sweep of the
+// factorisation's leaf in its "L is given" mode (gpx_leaf.h) carries X = inv(L_jj) -- 16 steps of two barriers,
+// ~10 us per block however many there are (the earlier one-lane-per-column forward substitution through LDS took
+// 69 us for the 128 blocks of n = 8192 and 1.16 ms for the 1024 of n = 65536).  Blocks shorter than 64 are
+// padded with the identity.  Outputs (each optional): `out` W[blk][64][64] laid out for coalesced mat-vec
+// reads, transposed != 0: out[i * 64 + c] = X[c][i] (forward sweep, z = X v), else out[i * 64 + c] = X[i][c]
+// (backward, a = X^T v); W / Wt: the diagonal 64-blocks of the 512-block operators (X and X^T).
+template <typename T>
+__global__ __launch_bounds__(256) void inv64_kernel(const T *__restrict__ L, int64_t ldl, int64_t ncols,
+                                                    T *__restrict__ out, int transposed, T *__restrict__ W,
+                                                    T *__restrict__ Wt, int64_t bsL, int64_t bsOut)
 {
     L += (int64_t)blockIdx.y * bsL;                  // batched: matrix blockIdx.y
-    Linv += (int64_t)blockIdx.y * bsLinv;
-    __shared__ T sL[SB * SBP];
-    __shared__ T sX[SB * SBP];
-    const int c = threadIdx.x;
+    const int tid = threadIdx.x, tr = tid >> 4, tc = tid & 15;
     const int64_t k0 = (int64_t)blockIdx.x * SB;
     const int jb = (int)min((int64_t)SB, ncols - k0);
     const T *blk = L + k0 * ldl + k0;
-    for (int i = 0; i < SB; ++i) {
-        T v = (i == c) ? (T)1 : (T)0;
-        if (i < jb && c <= i) v = blk[(int64_t)i * ldl + c];
-        sL[i * SBP + c] = v;
-    }
-    __syncthreads();
-    // column c of X = L^-1: X[c][c] = 1 / L[c][c]; X[i][c] = -(sum_{t=c}^{i-1} L[i][t] X[t][c]) / L[i][i]
-    for (int i = 0; i < c; ++i) sX[i * SBP + c] = (T)0;
-    sX[c * SBP + c] = (T)1 / sL[c * SBP + c];
-    for (int i = c + 1; i < SB; ++i) {
-        T acc = (T)0;
-        for (int t = c; t < i; ++t) acc = fma(sL[i * SBP + t], sX[t * SBP + c], acc);
-        sX[i * SBP + c] = -acc / sL[i * SBP + i];
-    }
-    __syncthreads();
-    T *out = Linv + (int64_t)blockIdx.x * SB * SB;
-    for (int i = 0; i < SB; ++i) out[i * SB + c] = FWD ? sX[c * SBP + i] : sX[i * SBP + c];
+    T a[4][4], x[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int row = 4 * tr + r, col = 4 * tc + c;
+            T v = (row == col) ? (T)1 : (T)0;
+            if (row < jb && col <= row) v = blk[(int64_t)row * ldl + col];
+            a[r][c] = v;
+            x[r][c] = (row == col) ? (T)1 : (T)0;
+        }
+    factor64<T, true, true>(a, x, jb, 0, nullptr);
+    T *o = out ? out + (int64_t)blockIdx.y * bsOut + (int64_t)blockIdx.x * (SB * SB) : nullptr;
+    const int64_t kb = blockIdx.x >> 3, pp = blockIdx.x & 7;
+    T *w = W ? W + kb * (int64_t)(512 * 512) + pp * SB * (512 + 1) : nullptr;
+    T *wt = Wt ? Wt + kb * (int64_t)(512 * 512) + pp * SB * (512 + 1) : nullptr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int row = 4 * tr + r, col = 4 * tc + c;
+            const T v = (col <= row) ? x[r][c] : (T)0;
+            if (o) o[transposed ? col * SB + row : row * SB + col] = v;
+            if (w) { w[(int64_t)row * 512 + col] = v; wt[(int64_t)col * 512 + row] = v; }
+        }
 }
 
 // grow-only device scratch for the block inverses (one per host thread)
@@ -200,6 +209,34 @@ __device__ __forceinline__ void inv_matvec(const T (&li)[8], const T *sv_s, T *r
     __syncthreads();
 }
 
+// far part of the forward sweep: apply the solved block [p0, p0 + pjb) to 64 rows starting at
+// far0 + 64 * slab:  b[r] -= L[r, p0:p0+pjb] . x[p0:p0+pjb]   (whole workgroup of TBT threads; szp: TB + 2 of LDS)
+template <typename T>
+__device__ __forceinline__ void far_fwd(const T *__restrict__ L, int64_t ldl, T *__restrict__ b,
+                                        const T *__restrict__ x, int64_t n, int64_t p0, int pjb, int64_t far0,
+                                        int slab, bool aligned, T *szp)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < TB + 2; i += TBT) szp[i] = (i < pjb) ? x[p0 + i] : (T)0;
+    __syncthreads();
+    T zr[TCH][2];
+#pragma unroll
+    for (int j = 0; j < TCH; ++j) { zr[j][0] = szp[j * 128 + 2 * lane]; zr[j][1] = szp[j * 128 + 2 * lane + 1]; }
+    const int64_t rbeg = far0 + (int64_t)slab * 64, rend = min(n, rbeg + 64);
+    constexpr int RU = 8;
+    for (int64_t r = rbeg + wave * RU; r < rend; r += (TBT / 64) * RU) {
+        T acc[RU];
+        if (pjb == TB) rows_dot<T, RU, true>(L, ldl, p0, pjb, r, rend - 1, zr, lane, aligned, acc);
+        else rows_dot<T, RU, false>(L, ldl, p0, pjb, r, rend - 1, zr, lane, aligned, acc);
+        if (lane < RU && r + lane < rend) {
+            T mine = acc[0];
+#pragma unroll
+            for (int i = 1; i < RU; ++i) mine = (lane == i) ? acc[i] : mine;
+            b[r + lane] -= mine;
+        }
+    }
+}
+
 // forward.  x[p0:p0+pjb] (block p) is final.  Workgroup 0 solves block [k0, k0+jb)
 // from b (nothing when jb == 0); workgroups w >= 1 apply block p to 64 rows each of
 // [far0, n):  b[r] -= L[r, p0:p0+pjb] . x[p0:p0+pjb].
@@ -221,24 +258,7 @@ __global__ __launch_bounds__(TBT) void trsv_fwd_fused(const T *__restrict__ L, i
 
     if (blockIdx.x != 0) {
         if (pjb <= 0 || (ablate & 4)) return;
-        for (int i = tid; i < TB + 2; i += TBT) szp[i] = (i < pjb) ? x[p0 + i] : (T)0;
-        __syncthreads();
-        T zr[TCH][2];
-#pragma unroll
-        for (int j = 0; j < TCH; ++j) { zr[j][0] = szp[j * 128 + 2 * lane]; zr[j][1] = szp[j * 128 + 2 * lane + 1]; }
-        const int64_t rbeg = far0 + (int64_t)(blockIdx.x - 1) * 64, rend = min(n, rbeg + 64);
-        constexpr int RU = 8;
-        for (int64_t r = rbeg + wave * RU; r < rend; r += (TBT / 64) * RU) {
-            T acc[RU];
-            if (pjb == TB) rows_dot<T, RU, true>(L, ldl, p0, pjb, r, rend - 1, zr, lane, aligned, acc);
-            else rows_dot<T, RU, false>(L, ldl, p0, pjb, r, rend - 1, zr, lane, aligned, acc);
-            if (lane < RU && r + lane < rend) {
-                T mine = acc[0];
-#pragma unroll
-                for (int i = 1; i < RU; ++i) mine = (lane == i) ? acc[i] : mine;
-                b[r + lane] -= mine;
-            }
-        }
+        far_fwd<T>(L, ldl, b, x, n, p0, pjb, far0, (int)blockIdx.x - 1, aligned, szp);
         return;
     }
     if (jb == 0) return;
@@ -298,36 +318,21 @@ __global__ __launch_bounds__(TBT) void trsv_fwd_fused(const T *__restrict__ L, i
     }
 }
 
-// backward (L^T a = v).  x[q0:q0+qjb] (block q, below the block being solved) is final.
-// Workgroup 0 solves block [k0, k0+jb) from b (nothing when jb == 0); workgroups
-// w >= 1 apply block q to CW columns each of [c0, c1):  b[c] -= L[q0:q0+qjb, c] . x[q0:q0+qjb].
-// CW = 128 for the streaming far part (1 KiB per row and wave), 32 for the 512 x 512 tile
-// next to the diagonal (16 workgroups instead of 4).
+// far part of the backward sweep: apply the solved row block [q0, q0 + qjb) to CW columns starting at
+// c0 + CW * slab:  b[c] -= L[q0:q0+qjb, c] . x[q0:q0+qjb]   (sa: TB, red: 2 * TB of LDS)
 template <typename T, int CW>
-__global__ __launch_bounds__(TBT) void trsv_bwd_fused(const T *__restrict__ L, int64_t ldl,
-                                                      const T *__restrict__ Linv, T *__restrict__ b,
-                                                      T *__restrict__ x, int64_t k0, int jb, int64_t q0,
-                                                      int qjb, int64_t c0, int64_t c1, int aligned_i, int ablate,
-                                                      int64_t bsL, int64_t bsLinv, int64_t bsv)
+__device__ __forceinline__ void far_bwd(const T *__restrict__ L, int64_t ldl, T *__restrict__ b,
+                                        const T *__restrict__ x, int64_t q0, int qjb, int64_t c0, int64_t c1,
+                                        int slab, bool aligned, T *sa, T *red)
 {
-    L += (int64_t)blockIdx.y * bsL; Linv += (int64_t)blockIdx.y * bsLinv;
-    b += (int64_t)blockIdx.y * bsv; x += (int64_t)blockIdx.y * bsv;
-    __shared__ T sa[TB];            // far workgroups: solution of block q
-    __shared__ T sv[TB];
-    __shared__ T sz[SB];
-    __shared__ T red[2 * TB];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool aligned = aligned_i != 0;
-
-    if (blockIdx.x != 0) {
-        if (qjb <= 0 || (ablate & 4)) return;
+    const int tid = threadIdx.x;
         constexpr int LP = CW / 2;                  // lanes (column pairs) per row
         constexpr int NG = TBT / LP;                // row groups
         constexpr int PER = TB / NG;                // rows per thread
         constexpr int BU = PER < 32 ? PER : 32;     // loads in flight per thread and batch
         for (int i = tid; i < TB; i += TBT) sa[i] = (i < qjb) ? x[q0 + i] : (T)0;
         __syncthreads();
-        const int64_t cbeg = c0 + (int64_t)(blockIdx.x - 1) * CW, cend = min(c1, cbeg + CW);
+        const int64_t cbeg = c0 + (int64_t)slab * CW, cend = min(c1, cbeg + CW);
         const int lp = tid % LP, g = tid / LP;
         const int64_t c = min(cbeg + 2 * lp, cend - 1);
         const bool pair = c + 1 < cend;
@@ -358,6 +363,32 @@ __global__ __launch_bounds__(TBT) void trsv_bwd_fused(const T *__restrict__ L, i
             for (int q = 1; q < NG; ++q) sum += red[q * CW + tid];
             b[cbeg + tid] -= sum;
         }
+}
+
+// backward (L^T a = v).  x[q0:q0+qjb] (block q, below the block being solved) is final.
+// Workgroup 0 solves block [k0, k0+jb) from b (nothing when jb == 0); workgroups
+// w >= 1 apply block q to CW columns each of [c0, c1):  b[c] -= L[q0:q0+qjb, c] . x[q0:q0+qjb].
+// CW = 128 for the streaming far part (1 KiB per row and wave), 32 for the 512 x 512 tile
+// next to the diagonal (16 workgroups instead of 4).
+template <typename T, int CW>
+__global__ __launch_bounds__(TBT) void trsv_bwd_fused(const T *__restrict__ L, int64_t ldl,
+                                                      const T *__restrict__ Linv, T *__restrict__ b,
+                                                      T *__restrict__ x, int64_t k0, int jb, int64_t q0,
+                                                      int qjb, int64_t c0, int64_t c1, int aligned_i, int ablate,
+                                                      int64_t bsL, int64_t bsLinv, int64_t bsv)
+{
+    L += (int64_t)blockIdx.y * bsL; Linv += (int64_t)blockIdx.y * bsLinv;
+    b += (int64_t)blockIdx.y * bsv; x += (int64_t)blockIdx.y * bsv;
+    __shared__ T sa[TB];            // far workgroups: solution of block q
+    __shared__ T sv[TB];
+    __shared__ T sz[SB];
+    __shared__ T red[2 * TB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool aligned = aligned_i != 0;
+
+    if (blockIdx.x != 0) {
+        if (qjb <= 0 || (ablate & 4)) return;
+        far_bwd<T, CW>(L, ldl, b, x, q0, qjb, c0, c1, (int)blockIdx.x - 1, aligned, sa, red);
         return;
     }
     if (jb == 0) return;
@@ -409,9 +440,183 @@ __global__ __launch_bounds__(TBT) void trsv_bwd_fused(const T *__restrict__ L, i
     }
 }
 
+// ---- operator form of the block steps ---------------------------------------------------------------
+// The sweep above needs two dependent launches per 512-column block: the near tile (previous block's solution
+// into this block's rows) and the in-block chain (8 sub-steps of a 64-wide mat-vec by ONE workgroup, 19 - 31 us:
+// at n = 8192 that chain, not bandwidth, is the whole solve).  With per-block operators, precomputed once per
+// factor on the MFMA kernel,
+//     W_k  = inv(L_kk)             (512 x 512, from the 64 x 64 inverses by recursive doubling, batched over k)
+//     Tf_k = W_k L_{k,k-1}         forward :  x_k = W_k  w_k - Tf_k x_{k-1}
+//     Tb_k = W_k^T L_{k+1,k}^T     backward:  a_k = W_k^T z_k - Tb_k a_{k+1}
+// a block step is ONE launch with no dependency inside it: 8 workgroups do the two 512-wide mat-vecs of block k
+// (64 rows each, 8 lanes per row, whole 128-byte lines), all others stream the far panel of the neighbour block
+// exactly as before.  w_k / z_k already hold every far contribution (blocks two or more away were streamed by
+// earlier launches); the neighbour's contribution comes through Tf / Tb.  A ragged last block (n % 512) keeps
+// the old kernels.  Cost of the operators: 2 (n / 512) products of 512^3 + the doubling, ~1.3 ms at n = 65536.
+constexpr int OB = 512;
+
+// LT_k[j][m] = L[(OB k + m), OB (k - 1) + j]   for k = 1 .. nfull - 1  (grid: (OB / 64)^2 tiles, k - 1)
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_subdiag_kernel(const T *__restrict__ L, int64_t ldl, T *__restrict__ LT)
+{
+    __shared__ T tile[64][65];
+    const int64_t k = blockIdx.y + 1;
+    const int tm = blockIdx.x >> 3, tj = blockIdx.x & 7;            // tile of rows m (of L), columns j
+    const T *src = L + (k * OB + tm * 64) * ldl + (k - 1) * OB + tj * 64;
+    for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
+        const int r = idx >> 6, c = idx & 63;
+        tile[r][c] = src[(int64_t)r * ldl + c];
+    }
+    __syncthreads();
+    T *dst = LT + k * (int64_t)(OB * OB) + (int64_t)(tj * 64) * OB + tm * 64;
+    for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
+        const int r = idx >> 6, c = idx & 63;
+        dst[(int64_t)r * OB + c] = tile[c][r];
+    }
+}
+
+// one block step: workgroups [0, nchain) solve block k (rows k0 ..), the others stream the neighbour's far panel
+template <typename T, bool FWD>
+__global__ __launch_bounds__(TBT) void trsv_op_kernel(const T *__restrict__ Wk, const T *__restrict__ Tk,
+                                                      const T *__restrict__ L, int64_t ldl, T *__restrict__ rhs,
+                                                      T *__restrict__ x, int64_t n, int64_t k0, int64_t p0, int pjb,
+                                                      int64_t f0, int64_t f1, int nchain, int aligned_i)
+{
+    __shared__ T szp[TB + 2];
+    __shared__ T sv[TB];
+    __shared__ T red[2 * TB];
+    const int tid = threadIdx.x;
+    const bool aligned = aligned_i != 0;
+    if ((int)blockIdx.x >= nchain) {
+        if (pjb <= 0) return;
+        if (FWD) far_fwd<T>(L, ldl, rhs, x, n, p0, pjb, f0, (int)blockIdx.x - nchain, aligned, szp);
+        else far_bwd<T, 128>(L, ldl, rhs, x, p0, pjb, f0, f1, (int)blockIdx.x - nchain, aligned, szp, red);
+        return;
+    }
+    for (int i = tid; i < TB; i += TBT) {
+        sv[i] = rhs[k0 + i];
+        szp[i] = (Tk && i < pjb) ? x[p0 + i] : (T)0;
+    }
+    __syncthreads();
+    const int r = tid >> 3, part = tid & 7;
+    const int row = 64 * (int)blockIdx.x + r;
+    const T *wrow = Wk + (int64_t)row * OB, *trow = Tk ? Tk + (int64_t)row * OB : nullptr;
+    T acc = (T)0;
+    // branch-free on purpose (the zero half of the triangular W_k is read too): with a per-row triangle test
+    // the loads cannot be batched and every iteration pays a memory round trip (measured 30 us instead of 8)
+    if (trow) {
+#pragma unroll 8
+        for (int i = 0; i < OB / 16; ++i) {
+            const int c = 16 * i + 2 * part;
+            T w0, w1, t0, t1;
+            load2(wrow + c, true, w0, w1);
+            load2(trow + c, true, t0, t1);
+            acc = fma(w0, sv[c], acc);
+            acc = fma(w1, sv[c + 1], acc);
+            acc = fma(-t0, szp[c], acc);
+            acc = fma(-t1, szp[c + 1], acc);
+        }
+    } else {
+#pragma unroll 8
+        for (int i = 0; i < OB / 16; ++i) {
+            const int c = 16 * i + 2 * part;
+            T w0, w1;
+            load2(wrow + c, true, w0, w1);
+            acc = fma(w0, sv[c], acc);
+            acc = fma(w1, sv[c + 1], acc);
+        }
+    }
+    acc = lanes8_sum(acc);
+    if (part == 0) x[k0 + row] = acc;
+}
+
+// thread-local, grow-only home of the operators when the caller brings no cache of its own
+struct OpsScratch { void *p = nullptr; size_t bytes = 0; int device = -1; };
+static thread_local OpsScratch g_ops;
+static int ops_scratch(size_t bytes, void **out)
+{
+    int dev = 0;
+    GPX_HIP(hipGetDevice(&dev));
+    if (g_ops.device != dev || g_ops.bytes < bytes) {
+        if (g_ops.p && g_ops.device == dev) { GPX_HIP(hipDeviceSynchronize()); (void)hipFree(g_ops.p); }
+        g_ops.p = nullptr; g_ops.bytes = 0; g_ops.device = dev;
+        GPX_HIP(hipMalloc(&g_ops.p, bytes));
+        g_ops.bytes = bytes;
+    }
+    *out = g_ops.p;
+    return GPX_OK;
+}
+
+size_t trsv_ops_bytes(int dtype, int64_t n)
+{
+    const int64_t nfull = n / OB;
+    return (size_t)(5 * nfull * (int64_t)OB * OB + nfull * 8 * (int64_t)SB * SB) * esize(dtype) + 256;
+}
+
+// build W, Wt, Tf, Tb for the leading nfull = n / 512 blocks of L into `buf` (trsv_ops_bytes)
+template <typename T>
+static int trsv_ops_prepare(const T *L, int64_t n, int64_t ldl, void *buf, hipStream_t st, int dtype)
+{
+    const int64_t nfull = n / OB, rag = n - nfull * OB;
+    const int64_t BS = (int64_t)OB * OB;
+    T *W = (T *)buf, *Wt = W + nfull * BS, *P = Wt + nfull * BS, *Tf = P + nfull * BS, *Tb = Tf + nfull * BS,
+      *inv64 = Tb + nfull * BS;
+    (void)inv64;
+    GPX_HIP(hipMemsetAsync(W, 0, (size_t)2 * nfull * BS * sizeof(T), st));
+    hipLaunchKernelGGL((inv64_kernel<T>), dim3((unsigned)(nfull * 8)), dim3(256), 0, st, L, ldl, nfull * OB, (T *)nullptr, 0,
+                       W, Wt, (int64_t)0, (int64_t)0);
+    GPX_LAUNCH_CHECK();
+    const int64_t dLk = (int64_t)OB * (ldl + 1);                     // L_kk -> L_{k+1,k+1}
+    for (int64_t s2 = SB; s2 < OB; s2 *= 2) {
+        Batch b;
+        b.count = (int)nfull; b.count2 = (int)(OB / (2 * s2));
+        const int64_t tW = 2 * s2 * OB + 2 * s2, tL = 2 * s2 * ldl + 2 * s2;
+        // Pt = W11^T L21^T
+        b.sA = BS; b.sB = dLk; b.sC = BS; b.tA = tW; b.tB = tL; b.tC = tW;
+        GPX_TRY(gemm_nt(dtype, s2, s2, s2, Wt, OB, L + s2 * ldl, ldl, P, OB, 1.0, GPX_FULL, 0, 0, st, 1, 0, &b));
+        // W21 = -W22 Pt^T
+        b.sA = BS; b.sB = BS; b.sC = BS; b.tA = tW; b.tB = tW; b.tC = tW;
+        GPX_TRY(gemm_nt(dtype, s2, s2, s2, W + s2 * OB + s2, OB, P, OB, W + s2 * OB, OB, -1.0, GPX_FULL, 0, 0, st, 1, 0, &b));
+        // (W^T)12 = -Pt W22^T
+        GPX_TRY(gemm_nt(dtype, s2, s2, s2, P, OB, W + s2 * OB + s2, OB, Wt + s2, OB, -1.0, GPX_FULL, 0, 0, st, 1, 0, &b));
+    }
+    if (nfull > 1) {
+        hipLaunchKernelGGL((transpose_subdiag_kernel<T>), dim3(64, (unsigned)(nfull - 1)), dim3(256), 0, st, L, ldl, P);
+        GPX_LAUNCH_CHECK();
+        Batch b;
+        b.count = (int)(nfull - 1);
+        // Tf_k = W_k L_{k,k-1} = W_k LT_k^T,  k = 1 .. nfull - 1
+        b.sA = BS; b.sB = BS; b.sC = BS;
+        GPX_TRY(gemm_nt(dtype, OB, OB, OB, W + BS, OB, P + BS, OB, Tf + BS, OB, 1.0, GPX_FULL, 0, 0, st, 1, 0, &b));
+        // Tb_k = W_k^T L_{k+1,k}^T,  k = 0 .. nfull - 2
+        b.sA = BS; b.sB = dLk; b.sC = BS;
+        GPX_TRY(gemm_nt(dtype, OB, OB, OB, Wt, OB, L + (int64_t)OB * ldl, ldl, Tb, OB, 1.0, GPX_FULL, 0, 0, st, 1, 0, &b));
+    }
+    if (rag > 0) {                                                   // the last full block against the ragged one
+        T *tb = Tb + (nfull - 1) * BS;
+        GPX_HIP(hipMemsetAsync(tb, 0, (size_t)BS * sizeof(T), st));
+        GPX_TRY(gemm_nt(dtype, OB, rag, OB, Wt + (nfull - 1) * BS, OB, L + nfull * OB * ldl + (nfull - 1) * OB, ldl, tb, OB,
+                        1.0, GPX_FULL, 0, 0, st, 1, 0));
+    }
+    return GPX_OK;
+}
+
+static bool trsv_ops_enabled()
+{
+    static const bool on = !(getenv("GPX_TRSV_OPS") && atoi(getenv("GPX_TRSV_OPS")) == 0);
+    return on;
+}
+// below this the ~0.7 ms of operator products (11 under-filled launches) costs what the shorter steps save
+// (n = 8192: 1.17 vs 1.10 ms for both sweeps; n = 16384: 1.78 vs 2.49; n = 65536: 9.7 vs 12.1)
+static int64_t trsv_ops_min_n()
+{
+    static const int64_t v = getenv("GPX_TRSV_OPS_MIN") ? std::max<int64_t>(2 * OB, atoll(getenv("GPX_TRSV_OPS_MIN"))) : 10240;
+    return v;
+}
+
 template <typename T>
 static int trsv_t(const T *L, int64_t n, int64_t ldl, T *b, T *x, int transpose, hipStream_t st,
-                  int64_t ncols = -1, const Batch *bt = nullptr)
+                  int64_t ncols = -1, const Batch *bt = nullptr, TrsvOps *ops = nullptr, int dtype = GPX_F64)
 {
     // bt: bt->count systems solved by the same launches; sA = stride of L, sB = stride of b and x
     const unsigned nbt = (unsigned)(bt ? bt->count : 1);
@@ -430,12 +635,71 @@ static int trsv_t(const T *L, int64_t n, int64_t ldl, T *b, T *x, int transpose,
     static const int ablate = getenv("GPX_TRSV_ABLATE") ? atoi(getenv("GPX_TRSV_ABLATE")) : 0;   // timing diagnostics only
     const int64_t nb = cdiv(ncols, TB);
     auto width = [&](int64_t blk) { return (int)std::min<int64_t>(TB, ncols - blk * TB); };
+    // operator form: square systems of at least two full blocks, aligned rows, one system
+    if (trsv_ops_enabled() && !bt && ncols == n && n >= trsv_ops_min_n() && aligned && ldl % (16 / (int64_t)sizeof(T)) == 0 &&
+        ((uintptr_t)L) % 16 == 0) {
+        const int64_t nfull = n / OB, rag = n - nfull * OB, BS = (int64_t)OB * OB;
+        void *buf = nullptr;
+        bool fresh = true;
+        if (ops) {                                                   // the caller's cache (one factor, many solves)
+            if (!ops->buf || ops->bytes < trsv_ops_bytes(dtype, n)) {
+                if (ops->buf) { GPX_HIP(hipStreamSynchronize(st)); (void)hipFree(ops->buf); ops->buf = nullptr; }
+                GPX_HIP(hipMalloc(&ops->buf, trsv_ops_bytes(dtype, n)));
+                ops->bytes = trsv_ops_bytes(dtype, n);
+                ops->valid = false;
+            }
+            buf = ops->buf;
+            fresh = !ops->valid;
+        } else {
+            GPX_TRY(ops_scratch(trsv_ops_bytes(dtype, n), &buf));
+        }
+        if (fresh) GPX_TRY(trsv_ops_prepare<T>(L, n, ldl, buf, st, dtype));
+        if (ops) ops->valid = true;
+        const T *W = (const T *)buf, *Wt = W + nfull * BS, *Tf = Wt + 2 * nfull * BS, *Tb = Tf + nfull * BS;
+        constexpr int NCH = OB / 64;
+        if (!transpose) {
+            for (int64_t k = 0; k < nfull; ++k) {
+                const int64_t k0 = k * OB, far0 = k0 + OB;
+                const int64_t nfar = k > 0 ? cdiv(n - far0, 64) : 0;
+                hipLaunchKernelGGL((trsv_op_kernel<T, true>), dim3((unsigned)(NCH + nfar)), dim3(TBT), 0, st, W + k * BS,
+                                   k > 0 ? Tf + k * BS : (const T *)nullptr, L, ldl, b, x, n, k0, k0 - OB, k > 0 ? OB : 0, far0, n,
+                                   NCH, aligned);
+            }
+            if (rag > 0) {                                           // ragged last block: the near tile, then the old chain
+                const int64_t k0 = nfull * OB, p0 = k0 - OB;
+                hipLaunchKernelGGL((inv64_kernel<T>), dim3((unsigned)nblk, nbt), dim3(256), 0, st, L, ldl, ncols, Linv, 1,
+                                   (T *)nullptr, (T *)nullptr, sL, sLinv);
+                hipLaunchKernelGGL((trsv_fwd_fused<T>), dim3((unsigned)(1 + cdiv(rag, 64))), dim3(TBT), 0, st, L, ldl, Linv, b, x,
+                                   n, k0, 0, p0, OB, k0, aligned, ablate, sL, sLinv, sv);
+                hipLaunchKernelGGL((trsv_fwd_fused<T>), dim3(1), dim3(TBT), 0, st, L, ldl, Linv, b, x, n, k0, (int)rag, p0, OB, n,
+                                   aligned, ablate, sL, sLinv, sv);
+            }
+        } else {
+            if (rag > 0) {
+                const int64_t k0 = nfull * OB;
+                hipLaunchKernelGGL((inv64_kernel<T>), dim3((unsigned)nblk, nbt), dim3(256), 0, st, L, ldl, ncols, Linv, 0,
+                                   (T *)nullptr, (T *)nullptr, sL, sLinv);
+                hipLaunchKernelGGL((trsv_bwd_fused<T, 128>), dim3(1), dim3(TBT), 0, st, L, ldl, Linv, b, x, k0, (int)rag, k0 + OB, 0,
+                                   (int64_t)0, k0, aligned, ablate, sL, sLinv, sv);
+            }
+            for (int64_t k = nfull - 1; k >= 0; --k) {
+                const int64_t k0 = k * OB, q0 = k0 + OB;
+                const int qjb = (k + 1 < nfull) ? OB : (int)rag;
+                const int64_t nfar = qjb > 0 ? cdiv(k0, 128) : 0;
+                hipLaunchKernelGGL((trsv_op_kernel<T, false>), dim3((unsigned)(NCH + nfar)), dim3(TBT), 0, st, Wt + k * BS,
+                                   qjb > 0 ? Tb + k * BS : (const T *)nullptr, L, ldl, b, x, n, k0, q0, qjb, (int64_t)0, k0, NCH,
+                                   aligned);
+            }
+        }
+        GPX_LAUNCH_CHECK();
+        return GPX_OK;
+    }
     // Per block two launches: (N) the 512 x 512 tile that carries the previous block's
     // solution into this block's rows/columns, spread over 8-16 workgroups; (F) workgroup 0
     // solves the block while the other workgroups stream the previous block's far panel.
     if (!transpose) {
-        hipLaunchKernelGGL((trinv64_kernel<T, true>), dim3((unsigned)nblk, nbt), dim3(64), 0, st, L, ldl, ncols, Linv,
-                           sL, sLinv);
+        hipLaunchKernelGGL((inv64_kernel<T>), dim3((unsigned)nblk, nbt), dim3(256), 0, st, L, ldl, ncols, Linv, 1,
+                           (T *)nullptr, (T *)nullptr, sL, sLinv);
         for (int64_t blk = 0; blk < nb; ++blk) {
             const int64_t k0 = blk * TB, p0 = std::max<int64_t>(blk - 1, 0) * TB;
             const int jb = width(blk), pjb = blk > 0 ? TB : 0;
@@ -451,8 +715,8 @@ static int trsv_t(const T *L, int64_t n, int64_t ldl, T *b, T *x, int transpose,
                                ldl, Linv, b, x, n, ncols, 0, (nb - 1) * TB, width(nb - 1), ncols, aligned, ablate,
                                sL, sLinv, sv);
     } else {
-        hipLaunchKernelGGL((trinv64_kernel<T, false>), dim3((unsigned)nblk, nbt), dim3(64), 0, st, L, ldl, ncols, Linv,
-                           sL, sLinv);
+        hipLaunchKernelGGL((inv64_kernel<T>), dim3((unsigned)nblk, nbt), dim3(256), 0, st, L, ldl, ncols, Linv, 0,
+                           (T *)nullptr, (T *)nullptr, sL, sLinv);
         for (int64_t blk = nb - 1; blk >= 0; --blk) {
             const int64_t k0 = blk * TB, q0 = k0 + TB;
             const int jb = width(blk), qjb = blk + 1 < nb ? width(blk + 1) : 0;
@@ -469,12 +733,12 @@ static int trsv_t(const T *L, int64_t n, int64_t ldl, T *b, T *x, int transpose,
 }
 
 int trsv_lower(int dtype, const void *L, int64_t n, int64_t ldl, void *b, void *x, int transpose,
-               hipStream_t st, const Batch *bt)
+               hipStream_t st, const Batch *bt, TrsvOps *ops)
 {
     if (n <= 0) return GPX_OK;
     if (dtype == GPX_F64)
-        return trsv_t<double>((const double *)L, n, ldl, (double *)b, (double *)x, transpose, st, -1, bt);
-    return trsv_t<float>((const float *)L, n, ldl, (float *)b, (float *)x, transpose, st, -1, bt);
+        return trsv_t<double>((const double *)L, n, ldl, (double *)b, (double *)x, transpose, st, -1, bt, ops, dtype);
+    return trsv_t<float>((const float *)L, n, ldl, (float *)b, (float *)x, transpose, st, -1, bt, ops, dtype);
 }
 
 int trsv_lower_cols(int dtype, const void *L, int64_t n, int64_t ldl, int64_t ncols, void *b, void *x,
@@ -482,8 +746,8 @@ int trsv_lower_cols(int dtype, const void *L, int64_t n, int64_t ldl, int64_t nc
 {
     if (n <= 0 || ncols <= 0) return GPX_OK;
     if (dtype == GPX_F64)
-        return trsv_t<double>((const double *)L, n, ldl, (double *)b, (double *)x, 0, st, ncols);
-    return trsv_t<float>((const float *)L, n, ldl, (float *)b, (float *)x, 0, st, ncols);
+        return trsv_t<double>((const double *)L, n, ldl, (double *)b, (double *)x, 0, st, ncols, nullptr, nullptr, dtype);
+    return trsv_t<float>((const float *)L, n, ldl, (float *)b, (float *)x, 0, st, ncols, nullptr, nullptr, dtype);
 }
 
 // y[c] -= sum_r Lp[r, c] * x[r]   (c < ncols <= 1024, r < rows): the transposed

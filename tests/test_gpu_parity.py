@@ -1079,3 +1079,38 @@ def test_fused_panel_steps_opt_in_vs_oracle(monkeypatch, dtype):
     for i in range(2):
         np.testing.assert_allclose(llh[i], orc.OracleGP("gaussian", thetas[i, :2], X, y, thetas[i, 2]).log_lh, **tol)
     assert llh[2] == -np.inf
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("n", [1024, 2048, 2600, 3071, 5632])
+def test_trsv_operator_form_vs_numpy(dtype, n, monkeypatch):
+    """The operator form of the single-right-hand-side solves (W_k = inv(L_kk) by recursive doubling, Tf / Tb by
+    batched 512^3 products, one launch per 512-block step), forced at small n by GPX_TRSV_OPS_MIN: exact
+    multiples of 512, a ragged last block (40 / 511 columns), two and eleven full blocks; both directions
+    against scipy, NaNs above the diagonal must never be read."""
+    monkeypatch.setenv("GPX_TRSV_OPS_MIN", "1024")
+    npdt, did, tol = (np.float64, _lib.F64, 1e-11) if dtype == "f64" else (np.float32, _lib.F32, 3e-4)
+    rng = np.random.RandomState(n)
+    ld = ((n + 15) // 16) * 16
+    Lh = rng.uniform(-1, 1, (n, ld)) / n ** 0.5
+    Lh[:, n:] = np.nan
+    for i in range(n):
+        Lh[i, i] = 1.0 + rng.rand()
+        Lh[i, i + 1:n] = np.nan
+    y = rng.randn(n)
+    lib = _lib.load()
+    dL = DeviceBuffer.from_host(Lh.astype(npdt))
+    tri = np.tril(Lh[:n, :n]).astype(npdt).astype(np.float64)
+    z_ref = scipy.linalg.solve_triangular(tri, y.astype(npdt).astype(np.float64), lower=True)
+    db = DeviceBuffer.from_host(y.astype(npdt))
+    dz = DeviceBuffer((n,), npdt).zero()
+    _lib.check(lib.gpx_d_trsv_lower(did, dL.ptr, n, ld, db.ptr, dz.ptr, 0, None))
+    sync()
+    z = dz.to_host().astype(np.float64)
+    np.testing.assert_allclose(z, z_ref, rtol=tol, atol=tol * np.abs(z_ref).max())
+    a_ref = scipy.linalg.solve_triangular(tri.T, z, lower=False)
+    dzc = DeviceBuffer.from_host(dz.to_host())
+    da = DeviceBuffer((n,), npdt).zero()
+    _lib.check(lib.gpx_d_trsv_lower(did, dL.ptr, n, ld, dzc.ptr, da.ptr, 1, None))
+    sync()
+    np.testing.assert_allclose(da.to_host().astype(np.float64), a_ref, rtol=tol, atol=tol * np.abs(a_ref).max())
