@@ -30,7 +30,8 @@ __device__ __forceinline__ void factor64(T (&a)[4][4], T (&x)[4][4], int jb, int
 {
     __shared__ T sD[4][4];            // factored diagonal tile of the step (lower part)
     __shared__ T sR[4];               // its reciprocal pivots
-    __shared__ T pan[IB][4];          // the step's 4 finished columns of L, rows below the diagonal tile
+    __shared__ T pan[IB][5];          // pitch 5: the column-tile reads pan[4 tc + c][k] of 16 lanes (stride 4 rows) spread
+                                      // over the banks (pitch 4: 128-byte stride, 8-way conflicts)          // the step's 4 finished columns of L, rows below the diagonal tile
     __shared__ T xrow[4][IB];         // INV: the step's 4 finished rows of X
     const int tid = threadIdx.x;
     const int tr = tid >> 4, tc = tid & 15;
@@ -136,6 +137,151 @@ __device__ __forceinline__ void factor64(T (&a)[4][4], T (&x)[4][4], int jb, int
         }
         // (no barrier: the next step's A touches only its own registers and sD / sR, which
         //  nobody reads in C; pan / xrow are rewritten only after the next step's first barrier)
+    }
+}
+
+
+// ---- the same leaf with a dedicated PIVOT WAVE (320 threads: waves 0-3 as above, wave 4 owns the 16 diagonal
+// tiles, lane t the tile (t, t)).  The dependent chain of the leaf -- the four pivots of a diagonal tile, each a
+// reciprocal square root plus its updates, ~150 cycles a pivot -- used to sit between the two barriers of every
+// step with 255 threads waiting for one; here the pivot wave runs ONE STEP AHEAD of the others:
+//   waves 0-3, step jt:  [barrier 1]  B: column jt's tiles against sD(jt) -> pan(jt), X rows -> xrow(jt)
+//                        [barrier 2]  C: rank-4 update of their off-diagonal tiles (and of X) with pan(jt) / xrow(jt)
+//   wave 4,    step jt:  [barrier 1]  --                                       [barrier 2]  rank-4 update of the diagonal
+//                        tiles t > jt with pan(jt), then lane jt + 1 factors ITS tile -> sD(jt + 1), under the others' C.
+// A step costs max(C, diagonal update + 4 pivots) + B instead of their sum.
+template <typename T, bool INV>
+__device__ __forceinline__ void factor64_pipe(T (&a)[4][4], T (&x)[4][4], int jb, int64_t j0, int *__restrict__ info,
+                                              int nsteps = IB / 4, unsigned long long *stamps = nullptr)
+{
+    // a: waves 0-3: this thread's OFF-diagonal tile (tr, tc), tc < tr (others unused); wave 4, lane t < 16: the
+    // diagonal tile (t, t).  x: waves 0-3 as in factor64 (tile (tr, tc) of X); unused by wave 4.
+    __shared__ T sD[4][4];
+    __shared__ T sR[4];
+    __shared__ T pan[IB][5];          // pitch 5: the column-tile reads pan[4 tc + c][k] of 16 lanes (stride 4 rows) spread
+                                      // over the banks (pitch 4: 128-byte stride, 8-way conflicts)
+    __shared__ T xrow[4][IB];
+    const int tid = threadIdx.x;
+    const bool pivot = tid >= 256;
+    const int tr = tid >> 4, tc = tid & 15;           // waves 0-3
+    const int t = tid - 256;                          // wave 4: diagonal tile index (lanes 0..15)
+    auto factor_tile = [&](int jt) {                  // by wave 4, lane jt: the four pivots of tile (jt, jt)
+        T rk[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const T piv = a[k][k];
+            if (4 * jt + k < jb && !(piv > (T)0)) {
+                if (*info == 0) *info = (int)(j0 + 4 * jt + k + 1);
+            }
+            const T rinv = fast_rsqrt(piv);
+            rk[k] = rinv;
+            a[k][k] = piv * rinv;
+#pragma unroll
+            for (int r = k + 1; r < 4; ++r) a[r][k] *= rinv;
+#pragma unroll
+            for (int c = k + 1; c < 4; ++c)
+#pragma unroll
+                for (int r = c; r < 4; ++r) a[r][c] = fma(-a[r][k], a[c][k], a[r][c]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sR[r] = rk[r];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) sD[r][c] = (c <= r) ? a[r][c] : (T)0;
+        }
+    };
+    if (pivot && t == 0) factor_tile(0);
+#pragma unroll 1
+    for (int jt = 0; jt < nsteps; ++jt) {             // nsteps < 16: timing diagnostics only (GPX_LEAF_ABLATE)
+        __syncthreads();                              // barrier 1: sD(jt), sR(jt) are in
+        if (stamps && (tid & 63) == 0) stamps[((tid >> 6) * 16 + jt) * 4 + 0] = __builtin_amdgcn_s_memtime();
+        if (!pivot) {
+            // ---- B ----
+            if (tc == jt && tr > jt) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        T v = a[r][c];
+#pragma unroll
+                        for (int k = 0; k < c; ++k) v = fma(-a[r][k], sD[c][k], v);
+                        a[r][c] = v * sR[c];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) pan[4 * tr + r][c] = a[r][c];
+            }
+            if (INV && tr == jt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        T v = x[r][c];
+#pragma unroll
+                        for (int k = 0; k < r; ++k) v = fma(-sD[r][k], x[k][c], v);
+                        x[r][c] = v * sR[r];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) xrow[r][4 * tc + c] = x[r][c];
+            }
+        }
+        if (stamps && (tid & 63) == 0) stamps[((tid >> 6) * 16 + jt) * 4 + 1] = __builtin_amdgcn_s_memtime();
+        __syncthreads();                              // barrier 2: pan(jt), xrow(jt) are in
+        if (stamps && (tid & 63) == 0) stamps[((tid >> 6) * 16 + jt) * 4 + 2] = __builtin_amdgcn_s_memtime();
+        if (pivot) {
+            // diagonal tiles below the step: a_tt -= P_t P_t^T (lower part), then the next tile's pivots
+            if (t > jt && t < IB / 4) {
+                T lr[4][4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) lr[r][k] = pan[4 * t + r][k];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int r = c; r < 4; ++r)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) a[r][c] = fma(-lr[r][k], lr[c][k], a[r][c]);
+                if (t == jt + 1) factor_tile(jt + 1);
+            }
+        } else if (tr > jt) {
+            // ---- C ----
+            T lr[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) lr[r][k] = pan[4 * tr + r][k];
+            if (tc > jt && tc < tr) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    T lc[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) lc[k] = pan[4 * tc + c][k];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) a[r][c] = fma(-lr[r][k], lc[k], a[r][c]);
+                }
+            }
+            if (INV) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    T xs[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) xs[k] = xrow[k][4 * tc + c];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) x[r][c] = fma(-lr[r][k], xs[k], x[r][c]);
+                }
+            }
+        }
+        if (stamps && (tid & 63) == 0) stamps[((tid >> 6) * 16 + jt) * 4 + 3] = __builtin_amdgcn_s_memtime();
     }
 }
 

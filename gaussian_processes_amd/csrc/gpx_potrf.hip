@@ -85,6 +85,50 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(T *__restrict__ blk, in
         }
 }
 
+static unsigned long long *g_leaf_stamps = nullptr;     // diagnostic (gpx_debug_leaf_stamps): 5 waves x 16 steps x 4 stamps
+// the leaf with the pivot wave (gpx_leaf.h): 320 threads
+template <typename T, bool INV>
+__global__ __launch_bounds__(320) void potrf_diag_pipe_kernel(T *__restrict__ blk, int64_t lda, int64_t j0, int jb,
+                                                              int *__restrict__ info, T *__restrict__ inv, int64_t sblk,
+                                                              int nsteps, unsigned long long *stamps)
+{
+    blk += (int64_t)blockIdx.x * sblk;
+    info += blockIdx.x;
+    if (INV) inv += (int64_t)blockIdx.x * (IB * IB);
+    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x;
+    __shared__ int s_abort;
+    if (tid == 0) s_abort = *info;
+    __syncthreads();
+    if (s_abort != 0) return;
+    const bool pivot = tid >= 256;
+    // tile coordinates: waves 0-3 own (tr, tc); wave 4 lane t owns (t, t) (lanes >= 16 idle)
+    const int tr = pivot ? (tid - 256) : (tid >> 4), tc = pivot ? (tid - 256) : (tid & 15);
+    const bool live = !pivot || (tid - 256) < IB / 4;
+    T a[4][4], x[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int row = 4 * tr + r, col = 4 * tc + c;
+            T v = (row == col) ? (T)1 : (T)0;
+            if (live && row < jb && col <= row) v = blk[(int64_t)row * lda + col];
+            a[r][c] = v;
+            x[r][c] = (row == col) ? (T)1 : (T)0;
+        }
+    factor64_pipe<T, INV>(a, x, jb, j0, info, nsteps, stamps);
+    if (!live) return;
+    const bool own_a = pivot || tc < tr;              // waves 0-3 own the strictly-lower tiles, wave 4 the diagonal ones
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int row = 4 * tr + r, col = 4 * tc + c;
+            if (own_a && row < jb && col <= row) blk[(int64_t)row * lda + col] = a[r][c];
+            if (INV && !pivot) inv[row * IB + col] = (col <= row) ? x[r][c] : (T)0;
+        }
+}
+
 // ---- fused panel step: one launch per 64 columns of a panel ---------------------------------------
 // Replaces, per 64-column step of a panel, the chain  leaf -> row substitution -> in-panel update(s)  (3 - 4
 // dependent launches of 12 - 30 us each beside a running trailing update) by ONE launch, left-looking inside
@@ -587,7 +631,16 @@ static int potrf_panel_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, i
         }
         {
             ProfScope prof(PC_POTRF_DIAG, (double)jb * jb * jb / 3.0 * nbatch, st);
-            if (inv)
+            static const bool pipe = !(getenv("GPX_LEAF_PIPE") && atoi(getenv("GPX_LEAF_PIPE")) == 0);
+            static const int nsteps = getenv("GPX_LEAF_ABLATE") ? atoi(getenv("GPX_LEAF_ABLATE")) : IB / 4;   // timing only
+            if (pipe) {
+                if (inv)
+                    hipLaunchKernelGGL((potrf_diag_pipe_kernel<T, true>), dim3(nbatch), dim3(320), 0, st, D, lda, r0, jb,
+                                       info_dev, inv, sM, nsteps, g_leaf_stamps);
+                else
+                    hipLaunchKernelGGL((potrf_diag_pipe_kernel<T, false>), dim3(nbatch), dim3(320), 0, st, D, lda, r0, jb,
+                                       info_dev, inv, sM, nsteps, g_leaf_stamps);
+            } else if (inv)
                 hipLaunchKernelGGL((potrf_diag_kernel<T, true>), dim3(nbatch), dim3(256), 0, st, D, lda, r0, jb,
                                    info_dev, inv, sM);
             else
@@ -766,6 +819,12 @@ int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t
 }  // namespace gpx
 
 using namespace gpx;
+
+extern "C" int gpx_debug_leaf_stamps(void *dev_buffer)
+{
+    gpx::g_leaf_stamps = (unsigned long long *)dev_buffer;
+    return GPX_OK;
+}
 
 extern "C" {
 
