@@ -109,6 +109,10 @@ __global__ __launch_bounds__(256) void kmat_kernel(const T *__restrict__ x1, int
     const int cbase = lane * VEC;
     const T c1 = (T)kp.c[0], c2 = (T)kp.c[1], c3 = (T)kp.c[2], c4 = (T)kp.c[3];
     const T dadd = (T)kp.diag_add;
+    // workgroup-uniform: all 64 x TN entries exist, stores are 16-byte aligned, the diagonal (where diag_add
+    // goes) does not cross the tile
+    const bool interior = aligned && row0 + KM_ROWS <= n && col0 + TN <= m &&
+                          (kp.diag_add == 0.0 || col0 >= row0 + KM_ROWS || col0 + TN <= row0);
 
 #pragma unroll 1
     for (int rb = 0; rb < 16; rb += KM_RB) {
@@ -147,6 +151,29 @@ __global__ __launch_bounds__(256) void kmat_kernel(const T *__restrict__ x1, int
             }
         }
 
+        if (interior) {
+            // the tile lies strictly inside the matrix and off the diagonal: no row / column bounds, no
+            // diagonal test, one 16-byte store per lane and row (the guarded path below costs ~30 more vector
+            // instructions per entry: per-element predicates and the byte-wise assembly of a partial store)
+#pragma unroll
+            for (int r = 0; r < KM_RB; ++r) {
+                typename Vec<T>::type pk;
+                T *pv = reinterpret_cast<T *>(&pk);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    if (MODE <= 2) {
+                        pv[v] = gaussian_entry<T, MODE>(acc[r][v], c1, c2, c3, c4);
+                    } else if (MODE == 3) {
+                        const T h = (T)kp.c[0], w = (T)kp.c[1];
+                        pv[v] = (h * h) * dev_exp<T>((T)-2.0 * acc[r][v] / (w * w));
+                    } else {
+                        pv[v] = periodic_entry<T>(kp.member, acc[r][v], (T)kp.c[0], (T)kp.c[1], (T)kp.c[2]);
+                    }
+                }
+                *reinterpret_cast<typename Vec<T>::type *>(out + (row0 + rloc + r) * ld + col0 + cbase) = pk;
+            }
+            continue;
+        }
 #pragma unroll
         for (int r = 0; r < KM_RB; ++r) {
             const int64_t gi = row0 + rloc + r;
