@@ -85,6 +85,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(T *__restrict__ blk, in
         }
 }
 
+static thread_local bool g_leaf_pipe = false;            // set by potrf(): CUs are reserved for the panel stream
 static unsigned long long *g_leaf_stamps = nullptr;     // diagnostic (gpx_debug_leaf_stamps): 5 waves x 16 steps x 4 stamps
 // the leaf with the pivot wave (gpx_leaf.h): 320 threads
 template <typename T, bool INV>
@@ -634,7 +635,11 @@ static int potrf_panel_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, i
         }
         {
             ProfScope prof(PC_POTRF_DIAG, (double)jb * jb * jb / 3.0 * nbatch, st);
-            static const bool pipe = !(getenv("GPX_LEAF_PIPE") && atoi(getenv("GPX_LEAF_PIPE")) == 0);
+            // the 320-thread pivot-wave leaf wins where CUs are set aside for the panel stream (n <= 12288: 30.4 -> 27 us)
+            // and loses where it has to wait for a slot among the trailing update's workgroups (fp64 n = 16384:
+            // potrf 37.2 -> 40.2 ms, n = 24576: 94.4 -> 98.1): GPX_LEAF_PIPE = 1 always, 0 never, default by reservation
+            static const int pipe_env = getenv("GPX_LEAF_PIPE") ? atoi(getenv("GPX_LEAF_PIPE")) : -1;
+            const bool pipe = pipe_env < 0 ? g_leaf_pipe : pipe_env != 0;
             static const int nsteps = getenv("GPX_LEAF_ABLATE") ? atoi(getenv("GPX_LEAF_ABLATE")) : IB / 4;   // timing only
             if (pipe) {
                 if (inv)
@@ -778,6 +783,7 @@ int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t
     const int64_t nblk = cdiv(n, nb);
     const size_t es = esize(dtype);
     static const bool no_la = getenv("GPX_POTRF_NO_LOOKAHEAD") != nullptr;
+    g_leaf_pipe = false;
     if (nblk <= 1) return potrf_panel(dtype, A, lda, n, 0, 0, n, info_dev, st, bt);
     auto at = [&](int64_t r, int64_t c) { return (char *)A + (r * lda + c) * es; };
     if (no_la) {
@@ -802,6 +808,7 @@ int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t
         if (masked) {
             st = masked;
             GPX_HIP(hipStreamWaitEvent(st, e, 0));
+            g_leaf_pipe = true;
         }
     }
     GPX_TRY(potrf_panel(dtype, A, lda, n, 0, 0, std::min(nb, n), info_dev, q, bt));
@@ -829,6 +836,7 @@ int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t
         GPX_HIP(hipEventRecord(e, st));
         GPX_HIP(hipStreamWaitEvent(user, e, 0));
     }
+    g_leaf_pipe = false;
     return GPX_OK;
 }
 
