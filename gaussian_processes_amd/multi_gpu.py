@@ -577,6 +577,8 @@ def bench_distributed(args, X, y, Xo, params, s, dtype_id, residual_check=None):
     local_rank = int(os.environ.get("LOCAL_RANK", rank))
     if os.environ.get("GPX_BENCH_SINGLE_DEVICE"):      # rehearsal on a 1-GPU box
         local_rank = 0
+    if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")     # one node: do not depend on the hostname resolving
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     lib = _lib.load()
     backend = "callbacks" if os.environ.get("GPX_DIST_BACKEND", "nccl") == "gloo" else "rccl"
