@@ -22,6 +22,7 @@
 namespace gpx {
 
 constexpr int IBP = IB + 1;   // LDS pitch (elements): conflict-free column walks
+constexpr int LEAN_TMAX = 3;  // lean panel route: at most 3 blocks of 64 columns to the right of a step (panels <= 256 wide)
 
 // ---- (b) diagonal block: right-looking Cholesky in 4-column steps, register resident ----
 // 256 threads hold the 64 x 64 block as 16 x 16 register tiles of 4 x 4 (thread
@@ -39,15 +40,30 @@ constexpr int IBP = IB + 1;   // LDS pitch (elements): conflict-free column walk
 // then subtracted, times L, from the rows below) and stores it as a dense 64 x 64
 // row-major block: the row substitution below the leaf then becomes one small MFMA
 // product X_rows * inv(L)^T.
+// lean panel route: the leaf also saves the rows below its block that are the NEXT diagonal blocks of the panel
+// (rd_rows of them, 64 columns) as they are BEFORE the substitution, so that every workgroup of the row kernel
+// can recompute their substituted values without racing against the workgroup that stores them in place
+template <typename T>
+__device__ __forceinline__ void copy_rows_below(const T *__restrict__ blk, int64_t lda, T *__restrict__ rd, int rd_rows)
+{
+    if (!rd || rd_rows <= 0) return;
+    rd += (int64_t)blockIdx.x * (LEAN_TMAX * IB * IB);
+    for (int idx = threadIdx.x; idx < rd_rows * IB; idx += blockDim.x) {
+        const int r = idx / IB, c = idx - r * IB;
+        rd[idx] = blk[(int64_t)(IB + r) * lda + c];
+    }
+}
+
 template <typename T, bool INV>
 __global__ __launch_bounds__(256) void potrf_diag_kernel(T *__restrict__ blk, int64_t lda, int64_t j0,
                                                          int jb, int *__restrict__ info, T *__restrict__ inv,
-                                                         int64_t sblk)
+                                                         int64_t sblk, T *__restrict__ rd = nullptr, int rd_rows = 0)
 {
     // batched launches: workgroup b factors the block of matrix b (stride sblk), own info word and inverse
     blk += (int64_t)blockIdx.x * sblk;
     info += blockIdx.x;
     if (INV) inv += (int64_t)blockIdx.x * (IB * IB);
+    copy_rows_below<T>(blk, lda, rd, rd_rows);
     // blk: the jb x jb diagonal block; j0: its global (0-based) index, for `info`
     // this one workgroup is the critical path of the whole panel and usually shares its CU with
     // trailing-update workgroups of the other stream: take the instruction arbiter's top priority
@@ -91,11 +107,13 @@ static unsigned long long *g_leaf_stamps = nullptr;     // diagnostic (gpx_debug
 template <typename T, bool INV>
 __global__ __launch_bounds__(320) void potrf_diag_pipe_kernel(T *__restrict__ blk, int64_t lda, int64_t j0, int jb,
                                                               int *__restrict__ info, T *__restrict__ inv, int64_t sblk,
-                                                              int nsteps, unsigned long long *stamps)
+                                                              int nsteps, unsigned long long *stamps,
+                                                              T *__restrict__ rd = nullptr, int rd_rows = 0)
 {
     blk += (int64_t)blockIdx.x * sblk;
     info += blockIdx.x;
     if (INV) inv += (int64_t)blockIdx.x * (IB * IB);
+    copy_rows_below<T>(blk, lda, rd, rd_rows);
     __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x;
     __shared__ int s_abort;
@@ -293,6 +311,134 @@ __global__ __launch_bounds__(256) void panel_step_kernel(T *__restrict__ A, int6
             const int64_t gr = wr0 + M::row(lane, r);
             if (gr < n) A[gr * lda + c0 + 16 * j + li] = y[j][r];
         }
+}
+
+// ---- lean panel route: two launches per 64 panel columns, right-looking inside the panel ------------------
+// After the leaf (L_ss, X = inv(L_ss), and the saved rows Rd of the next diagonal blocks), ONE row kernel does for 64
+// rows per workgroup what used to be the substitution launch plus one to three in-panel update launches:
+//   Y = R X^T                              (its rows of the step's 64 columns; stored in place)
+//   for every block t of 64 columns to the right within the panel:
+//       Yd_t = Rd_t X^T                    (the step's columns of that block's DIAGONAL rows -- recomputed by every
+//                                           workgroup from the saved copy: 64^3 flops instead of a launch boundary)
+//       A[rows, block t] -= Y Yd_t^T
+// Operands go global / L2 -> registers in MFMA fragment layout; Y and Yd_t pass through LDS to become operands.
+template <typename T>
+__global__ __launch_bounds__(256) void panel_rows_kernel(T *__restrict__ A, int64_t lda, int64_t n, int64_t rb,
+                                                         int64_t c0, int tblocks, const T *__restrict__ xinv,
+                                                         const T *__restrict__ rd, int64_t sM)
+{
+    typedef PM<T> M;
+    typedef typename M::v4 v4;
+    constexpr int EPK = M::EPK, SUB = M::SUB, NCH = IB / EPK;
+    A += (int64_t)blockIdx.y * sM;
+    xinv += (int64_t)blockIdx.y * (IB * IB);
+    rd += (int64_t)blockIdx.y * (LEAN_TMAX * IB * IB);
+    __shared__ T sY[IB][IB + 2];
+    __shared__ T sYd[IB][IB + 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int64_t wr0 = rb + (int64_t)blockIdx.x * IB + 16 * wave;          // this wave's 16 rows
+    // X as B operand: rows 16 j + li, kept in registers for all products of the workgroup
+    T xb[NCH][4][SUB];
+#pragma unroll
+    for (int kc = 0; kc < NCH; ++kc)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) load_frag32<T>(xinv + (16 * j + li) * IB + kc * EPK + lq * SUB, xb[kc][j]);
+    // ---- Y = R X^T ----
+    v4 y[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[j][r] = (T)0;
+    {
+        const T *arow = A + min(wr0 + li, n - 1) * lda + c0 + lq * SUB;
+        T fa[NCH][SUB];
+#pragma unroll
+        for (int kc = 0; kc < NCH; ++kc) load_frag32<T>(arow + kc * EPK, fa[kc]);
+#pragma unroll
+        for (int kc = 0; kc < NCH; ++kc)
+#pragma unroll
+            for (int ss = 0; ss < SUB; ++ss)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) y[j] = M::mfma(fa[kc][ss], xb[kc][j][ss], y[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int lr = M::row(lane, r);
+            const int64_t gr = wr0 + lr;
+            if (gr < n) A[gr * lda + c0 + 16 * j + li] = y[j][r];
+            sY[16 * wave + lr][16 * j + li] = y[j][r];
+        }
+    // ---- in-panel updates ----
+    for (int t = 0; t < tblocks; ++t) {
+        v4 yd[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) yd[j][r] = (T)0;
+        {
+            const T *drow = rd + (int64_t)(IB * t + 16 * wave + li) * IB + lq * SUB;
+            T fa[NCH][SUB];
+#pragma unroll
+            for (int kc = 0; kc < NCH; ++kc) load_frag32<T>(drow + kc * EPK, fa[kc]);
+#pragma unroll
+            for (int kc = 0; kc < NCH; ++kc)
+#pragma unroll
+                for (int ss = 0; ss < SUB; ++ss)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) yd[j] = M::mfma(fa[kc][ss], xb[kc][j][ss], yd[j]);
+        }
+        __syncthreads();                                   // the previous block's sYd has been consumed; sY is complete
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sYd[16 * wave + M::row(lane, r)][16 * j + li] = yd[j][r];
+        __syncthreads();
+        v4 u[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) u[j][r] = (T)0;
+#pragma unroll
+        for (int kc = 0; kc < NCH; ++kc) {
+            T fa[SUB], fb[4][SUB];
+#pragma unroll
+            for (int ss = 0; ss < SUB; ++ss) fa[ss] = sY[16 * wave + li][kc * EPK + lq * SUB + ss];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int ss = 0; ss < SUB; ++ss) fb[j][ss] = sYd[16 * j + li][kc * EPK + lq * SUB + ss];
+#pragma unroll
+            for (int ss = 0; ss < SUB; ++ss)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) u[j] = M::mfma(fa[ss], fb[j][ss], u[j]);
+        }
+        const int64_t cu = c0 + (int64_t)IB * (t + 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t gr = wr0 + M::row(lane, r);
+                if (gr < n) A[gr * lda + cu + 16 * j + li] -= u[j][r];
+            }
+    }
+}
+
+// OPT-IN (GPX_POTRF_LEAN=256).  Measured (n = 8192, nb = 256): the row kernel takes 56 / 36 / 26 / 14 us alone for
+// 3 / 2 / 1 / 0 blocks to the right (its LDS fragment reads are element-wise and nothing is software-pipelined:
+// 4 x the matrix-pipe time) and up to 155 us beside the trailing update, against 12 - 17 us + 14 - 30 us for the
+// substitution and update launches of the tuned GEMM kernel it replaces: potrf 10.3 -> 12.1 ms.  Off by default.
+static int64_t lean_max()
+{
+    static const int64_t v = getenv("GPX_POTRF_LEAN") ? atoll(getenv("GPX_POTRF_LEAN")) : 0;
+    return std::min<int64_t>(v, (LEAN_TMAX + 1) * IB);
+}
+static int64_t lean_rows_max()
+{
+    static const int64_t v = getenv("GPX_POTRF_LEAN_ROWS") ? atoll(getenv("GPX_POTRF_LEAN_ROWS")) : 16384;
+    return v;
 }
 
 // scratch of the fused steps: per matrix of a batch one 64 x 64 inverse and one flag word; the flag only ever
@@ -603,6 +749,41 @@ static bool tall_route(int64_t below, int64_t kb, int64_t lda, size_t es, const 
     return lda % (16 / (int64_t)es) == 0 && ((uintptr_t)base) % 16 == 0;
 }
 
+// lean panel route (kb <= 256, a multiple of 64): per 64 columns the leaf, then one row kernel
+template <typename T>
+static int potrf_panel_lean(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int64_t kb, int *info_dev,
+                            hipStream_t st, const Batch *bt)
+{
+    const int nbatch = bt ? bt->count : 1;
+    const int64_t sM = bt ? bt->sA : 0;
+    void *p = nullptr;
+    GPX_TRY(leaf_scratch((size_t)nbatch * (1 + LEAN_TMAX) * IB * IB * sizeof(T), &p));
+    T *inv = (T *)p, *rd = inv + (size_t)nbatch * IB * IB;
+    static const int pipe_env = getenv("GPX_LEAF_PIPE") ? atoi(getenv("GPX_LEAF_PIPE")) : -1;
+    const bool pipe = pipe_env < 0 ? g_leaf_pipe : pipe_env != 0;
+    for (int64_t s = 0; s < kb; s += IB) {
+        const int tb = (int)((kb - s - IB) / IB);                   // 64-column blocks to the right, inside the panel
+        T *D = A + (r0 + s) * lda + c0 + s;
+        {
+            ProfScope prof(PC_POTRF_DIAG, (double)IB * IB * IB / 3.0 * nbatch, st);
+            if (pipe)
+                hipLaunchKernelGGL((potrf_diag_pipe_kernel<T, true>), dim3(nbatch), dim3(320), 0, st, D, lda, r0 + s, IB,
+                                   info_dev, inv, sM, IB / 4, (unsigned long long *)nullptr, rd, tb * IB);
+            else
+                hipLaunchKernelGGL((potrf_diag_kernel<T, true>), dim3(nbatch), dim3(256), 0, st, D, lda, r0 + s, IB, info_dev,
+                                   inv, sM, rd, tb * IB);
+        }
+        const int64_t rb = r0 + s + IB, below = n - rb;
+        if (below > 0) {
+            ProfScope prof(PC_TRSM_ROWS, (double)below * IB * IB * (1.0 + 2.0 * tb) * nbatch, st);
+            hipLaunchKernelGGL((panel_rows_kernel<T>), dim3((unsigned)cdiv(below, IB), (unsigned)nbatch), dim3(256), 0, st, A, lda, n,
+                               rb, c0 + s, tb, (const T *)inv, (const T *)rd, sM);
+        }
+    }
+    GPX_LAUNCH_CHECK();
+    return GPX_OK;
+}
+
 template <typename T>
 static int potrf_panel_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int64_t kb, int *info_dev,
                          hipStream_t st, int dtype, const Batch *bt, T *inv_slots, int64_t pc0)
@@ -614,6 +795,9 @@ static int potrf_panel_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, i
     if (!inv_slots && kb % IB == 0 && kb <= fused_max() && lda % (16 / (int64_t)sizeof(T)) == 0 &&
         ((uintptr_t)(A + r0 * lda + c0)) % 16 == 0 && c0 % (16 / (int64_t)sizeof(T)) == 0)
         return potrf_panel_fused<T>(A, lda, n, r0, c0, kb, info_dev, st, bt);
+    if (!inv_slots && kb % IB == 0 && kb <= lean_max() && n - r0 <= lean_rows_max() && lda % (16 / (int64_t)sizeof(T)) == 0 &&
+        ((uintptr_t)(A + r0 * lda + c0)) % 16 == 0 && c0 % (16 / (int64_t)sizeof(T)) == 0)
+        return potrf_panel_lean<T>(A, lda, n, r0, c0, kb, info_dev, st, bt);
     if (kb <= IB) {
         const int jb = (int)kb;
         T *D = A + r0 * lda + c0;

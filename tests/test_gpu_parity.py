@@ -1056,6 +1056,25 @@ def test_tall_panel_route_opt_in_vs_oracle(monkeypatch):
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_lean_panel_route_opt_in_vs_oracle(monkeypatch, dtype):
+    """GPX_POTRF_LEAN (opt-in): per 64 panel columns the leaf (which also saves the next diagonal blocks' rows) and ONE
+    row kernel doing the substitution and every in-panel update of its 64 rows (the diagonal rows' substituted values
+    recomputed by each workgroup from the saved copy)."""
+    monkeypatch.setenv("GPX_POTRF_LEAN", "256")
+    N, d = 1800, 3
+    X, y, Xo = orc.synth_inputs(N, d, 32)
+    h, w, s = 1.0, 0.5 * np.sqrt(d), 1.0
+    tol = dict(rtol=1e-10) if dtype == "float64" else dict(rtol=1e-4)
+    for nb in ("128", "256"):
+        monkeypatch.setenv("GPX_POTRF_NB", nb)
+        g = gp.GP(gp.GaussianKernel(h, w), X, y, s=s, dtype=dtype)
+        o = orc.OracleGP("gaussian", (h, w), X, y, s)
+        np.testing.assert_allclose(g.log_lh, o.log_lh, **tol)
+        if dtype == "float64":
+            np.testing.assert_allclose(g.Lxx, o.Lxx, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_fused_panel_steps_opt_in_vs_oracle(monkeypatch, dtype):
     """GPX_POTRF_FUSED (opt-in): one launch per 64 panel columns -- workgroup 0 updates, factors and inverts
     the diagonal block and raises an agent-scope flag, the other workgroups do their left-looking update
