@@ -617,7 +617,10 @@ static int leaf_scratch(size_t bytes, void **out)
     int dev = 0;
     GPX_HIP(hipGetDevice(&dev));
     if (g_leaf.device != dev || g_leaf.bytes < bytes) {
-        g_leaf.p = nullptr;                      // a previous device's block is left to that context
+        // growing on the same device: the old block may still be in use by queued leaves (a previous device's
+        // block is left to that context)
+        if (g_leaf.p && g_leaf.device == dev) { GPX_HIP(hipDeviceSynchronize()); (void)hipFree(g_leaf.p); }
+        g_leaf.p = nullptr;
         GPX_HIP(hipMalloc(&g_leaf.p, std::max<size_t>(bytes, IB * IB * 8)));
         g_leaf.bytes = std::max<size_t>(bytes, IB * IB * 8);
         g_leaf.device = dev;
