@@ -285,4 +285,30 @@ __device__ __forceinline__ void factor64_pipe(T (&a)[4][4], T (&x)[4][4], int jb
     }
 }
 
+// ---- small MFMA products of the panel kernels: 16 x 16 output tiles, operands read as 32-byte runs of k ----
+// (lane (li, lq) holds k = lq * SUB .. + SUB of a chunk of EPK values for row li of A and of B; both operands use the
+//  same permutation of k, so the product is unchanged)
+template <typename T> struct PM;
+template <> struct PM<double> {
+    typedef double v4 __attribute__((ext_vector_type(4)));
+    static constexpr int EPK = 16, SUB = 4;
+    __device__ static __forceinline__ v4 mfma(double a, double b, v4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    __device__ static __forceinline__ int row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
+};
+template <> struct PM<float> {
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    static constexpr int EPK = 32, SUB = 8;
+    __device__ static __forceinline__ v4 mfma(float a, float b, v4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    __device__ static __forceinline__ int row(int lane, int reg) { return 4 * (lane >> 4) + reg; }
+};
+
+template <typename T>
+__device__ __forceinline__ void load_frag32(const T *__restrict__ p, T (&f)[PM<T>::SUB])
+{
+    struct alignas(16) Q { unsigned w[4]; };
+    const Q a = reinterpret_cast<const Q *>(p)[0], b = reinterpret_cast<const Q *>(p)[1];
+    memcpy(&f[0], &a, 16);
+    memcpy(&f[PM<T>::SUB / 2], &b, 16);
+}
+
 }  // namespace gpx

@@ -1,0 +1,309 @@
+// gpx_panel.hip -- the RESIDENT panel kernel: ONE launch factors a panel of up to 256 columns.
+//
+// The panel chain of the blocked factorisation (gpx_potrf.hip) used to be, per 64 panel columns, the leaf, the
+// row substitution and one to three in-panel updates: 3 - 5 dependent launches of 12 - 30 us each, ~ 325 us per
+// 256-column panel, which is what bounds every factorisation with n <= 16384 and the panel owner's critical path
+// of the multi-GPU schedule.  Here the panel lives in REGISTERS for the whole launch:
+//
+//   workgroup w owns rows r0 + 64 w .. + 64 of the panel; wave v of it keeps its 16 rows x kb columns as MFMA
+//   accumulator tiles (kb = 256 fp64: 64 doubles a lane), loaded once and stored once.
+//   Step j (64 columns, right-looking inside the panel):
+//     workgroup j   (the diagonal block, fully updated by the steps before) passes the block through LDS into
+//                   the leaf's thread-tile layout, factors it and forms W = inv(L_jj) (factor64, gpx_leaf.h),
+//                   stores L_jj, publishes W and raises flag W_j; it is done.
+//     workgroup w>j waits for W_j (one lane polls, bounded), stages W through LDS, X = P_j W^T on the MFMA pipe
+//                   (its rows of column block j: final, stored), keeps X in LDS as an operand and updates its
+//                   blocks c > j:  P_c -= X X_c^T, where X_c -- the same step's rows of the diagonal block c --
+//                   is its own X when c == w and otherwise published by workgroup c (flag X_cj).
+//   The only serial chain is  W_j -> (workgroup j+1: X, own update, leaf) -> W_{j+1}: the leaf plus two 64^3
+//   products and one flag hand-off per 64 columns.
+//
+// Hand-off between workgroups (possibly on different XCDs, whose L2s are not coherent with each other): payload
+// and flags are written with agent-scope (sc1, write-through) stores and read with agent-scope loads; the writer
+// drains its stores (s_waitcnt vmcnt(0)), the workgroup meets, one lane stores the flag; the reader polls the
+// flag, then loads.  No L2-wide write-back or invalidate is issued -- the trailing update of the previous panel
+// runs on the same L2s with gigabytes of dirty tiles.  Flags hold a per-launch serial, nothing is reset.
+// Producers have the lowest workgroup ids of their matrix and workgroups are dispatched in id order, so a
+// producer is resident (or finished) before any of its consumers exists; should that ever fail the spin is
+// bounded and the panel reports info = -7 instead of hanging.
+#include "gpx_common.h"
+#include "gpx_leaf.h"
+
+#include <algorithm>
+#include <stdlib.h>
+
+namespace gpx {
+
+constexpr int RES_MAXSTEPS = 4;                   // panels of up to 256 columns
+constexpr int RES_SLOTS = 10;                     // W_0..3, X_10, X_20, X_21, X_30, X_31, X_32
+constexpr int RES_FLAGS = 16;                     // flag words per matrix (10 used)
+constexpr int RES_SPIN = 1 << 22;                 // polls (~0.1 us each): gives up after ~0.5 s
+
+__device__ __forceinline__ int res_xslot(int c, int j) { return 4 + c * (c - 1) / 2 + j; }
+
+template <typename T> struct ResPitch { static constexpr int v = IB + 16 / (int)sizeof(T); };
+
+// agent-scope element accesses of the published blocks
+template <typename T> __device__ __forceinline__ void pub_store(T *p, T v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T> __device__ __forceinline__ T pub_load(const T *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// all of this workgroup's published stores are on their way: drain them, meet, raise the flag
+__device__ __forceinline__ void res_raise(int *flag, int serial)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// one lane polls; everybody learns the outcome through LDS (the caller's next barrier orders the payload loads)
+__device__ __forceinline__ void res_wait(const int *flag, int serial, int *s_ok, int naps)
+{
+    if (threadIdx.x == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != serial && spins < RES_SPIN) {
+            __builtin_amdgcn_s_sleep(2);
+            if (naps) __builtin_amdgcn_s_sleep(8);
+            ++spins;
+        }
+        if (spins >= RES_SPIN) *s_ok = 0;
+        asm volatile("" ::: "memory");
+    }
+}
+
+// stage a published 64 x 64 row-major block into LDS (pitch PT)
+template <typename T, int PT>
+__device__ __forceinline__ void res_stage(const T *__restrict__ src, T (*dst)[PT])
+{
+    constexpr int PER = IB * IB / 256;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        dst[idx / IB][idx % IB] = pub_load(src + idx);
+    }
+}
+
+// acc[0..3] (+)= (+-) sa[16 wave + li][:] . sb[16 jj + li][:]^T over the 64 columns
+template <typename T, int PT, bool NEG>
+__device__ __forceinline__ void res_prod(const T (*sa)[PT], const T (*sb)[PT], typename PM<T>::v4 (&acc)[4], int wave, int li, int lq)
+{
+    typedef PM<T> M;
+    constexpr int EPK = M::EPK, SUB = M::SUB, NCH = IB / EPK;
+#pragma unroll
+    for (int kc = 0; kc < NCH; ++kc) {
+        T fa[SUB], fb[4][SUB];
+        load_frag32<T>(&sa[16 * wave + li][kc * EPK + lq * SUB], fa);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) load_frag32<T>(&sb[16 * jj + li][kc * EPK + lq * SUB], fb[jj]);
+        if (NEG) {
+#pragma unroll
+            for (int ss = 0; ss < SUB; ++ss) fa[ss] = -fa[ss];
+        }
+#pragma unroll
+        for (int ss = 0; ss < SUB; ++ss)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) acc[jj] = M::mfma(fa[ss], fb[jj][ss], acc[jj]);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void panel_res_kernel(T *__restrict__ A, int64_t lda, int64_t n, int64_t r0, int64_t c0,
+                                                           int nsteps, int *__restrict__ info, T *__restrict__ pub,
+                                                           int *__restrict__ flags, int serial, int64_t sM)
+{
+    typedef PM<T> M;
+    typedef typename M::v4 v4;
+    constexpr int PT = ResPitch<T>::v;
+    __shared__ __attribute__((aligned(16))) T sA[IB][PT];      // X of the step (A operand; B operand of the own-diagonal update)
+    __shared__ __attribute__((aligned(16))) T sB[IB][PT];      // staged published block
+    __shared__ int s_ok;
+    A += (int64_t)blockIdx.y * sM;
+    info += blockIdx.y;
+    pub += (int64_t)blockIdx.y * (RES_SLOTS * IB * IB);
+    flags += (int64_t)blockIdx.y * RES_FLAGS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int w = blockIdx.x;
+    const bool future_diag = w < nsteps;
+    if (future_diag) __builtin_amdgcn_s_setprio(3);
+    if (tid == 0) s_ok = (*info == 0);
+    __syncthreads();
+    if (!s_ok) {
+        // an earlier panel failed: nobody computes, but nobody may be left waiting either
+        if (future_diag && tid < RES_FLAGS) __hip_atomic_store(flags + tid, serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const int64_t wr0 = r0 + (int64_t)w * IB + 16 * wave;      // this wave's 16 rows
+    // ---- the panel rows into accumulator tiles: acc[c][jj] = rows x columns 64 c + 16 jj .. ----
+    v4 acc[RES_MAXSTEPS][4];
+#pragma unroll
+    for (int c = 0; c < RES_MAXSTEPS; ++c) {
+        const bool have = c < nsteps && (!future_diag || c <= w);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t gr = wr0 + M::row(lane, r);
+                acc[c][jj][r] = have ? A[(gr < n ? gr : n - 1) * lda + c0 + IB * c + 16 * jj + li] : (T)0;
+            }
+    }
+#pragma unroll
+    for (int j = 0; j < RES_MAXSTEPS; ++j) {
+        if (j >= nsteps) break;
+        __syncthreads();                                        // sA / sB of the previous step are consumed
+        // column block j of my rows -> LDS by rows (operand of the substitution, or the leaf's input)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sA[16 * wave + M::row(lane, r)][16 * jj + li] = acc[j][jj][r];
+        if (w == j) {
+            // ---- the diagonal block: leaf ----
+            __syncthreads();
+            const int tr = tid >> 4, tc = tid & 15;
+            T a[4][4], x[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int row = 4 * tr + r, col = 4 * tc + c;
+                    a[r][c] = (col <= row) ? sA[row][col] : (T)0;
+                    x[r][c] = (row == col) ? (T)1 : (T)0;
+                }
+            factor64<T, true>(a, x, IB, c0 + (int64_t)IB * j, info);
+            T *W = pub + (int64_t)j * (IB * IB);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int row = 4 * tr + r, col = 4 * tc + c;
+                    pub_store(W + row * IB + col, (col <= row) ? x[r][c] : (T)0);
+                }
+            res_raise(flags + j, serial);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int row = 4 * tr + r, col = 4 * tc + c;
+                    if (col <= row) A[(r0 + (int64_t)IB * j + row) * lda + c0 + IB * j + col] = a[r][c];
+                }
+            return;
+        }
+        // ---- rows below the diagonal block ----
+        res_wait(flags + j, serial, &s_ok, !future_diag);
+        __syncthreads();
+        if (!s_ok) {
+            if (tid == 0) atomicCAS(info, 0, -7);
+            if (future_diag && tid < RES_FLAGS) __hip_atomic_store(flags + tid, serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        res_stage<T, PT>(pub + (int64_t)j * (IB * IB), sB);
+        __syncthreads();
+        v4 x[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[jj][r] = (T)0;
+        res_prod<T, PT, false>(sA, sB, x, wave, li, lq);
+        // X is final: store it, keep it in LDS as an operand, publish it when these are the rows of a later diagonal block
+        T *Xp = future_diag ? pub + (int64_t)res_xslot(w, j) * (IB * IB) : nullptr;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int lr = 16 * wave + M::row(lane, r);
+                sA[lr][16 * jj + li] = x[jj][r];
+                if (future_diag) pub_store(Xp + lr * IB + 16 * jj + li, x[jj][r]);
+            }
+        __syncthreads();                                        // sA is complete
+        // ---- right-looking updates inside the panel; the own diagonal block first (it is the chain), and the
+        // publication's drain hides under its MFMAs ----
+        if (future_diag) {
+#pragma unroll
+            for (int c = 1; c < RES_MAXSTEPS; ++c)
+                if (c == w) res_prod<T, PT, true>(sA, sA, acc[c], wave, li, lq);
+            res_raise(flags + res_xslot(w, j), serial);
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t gr = wr0 + M::row(lane, r);
+                if (gr < n) A[gr * lda + c0 + IB * j + 16 * jj + li] = x[jj][r];
+            }
+#pragma unroll
+        for (int c = j + 1; c < RES_MAXSTEPS; ++c) {
+            if (c >= nsteps || (future_diag && c >= w)) break;
+            res_wait(flags + res_xslot(c, j), serial, &s_ok, 1);
+            __syncthreads();                                    // also: the previous block's sB has been consumed
+            if (!s_ok) {
+                if (tid == 0) atomicCAS(info, 0, -7);
+                if (future_diag && tid < RES_FLAGS) __hip_atomic_store(flags + tid, serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+            res_stage<T, PT>(pub + (int64_t)res_xslot(c, j) * (IB * IB), sB);
+            __syncthreads();
+            res_prod<T, PT, true>(sA, sB, acc[c], wave, li, lq);
+        }
+    }
+}
+
+// per host thread and device: the published blocks and flag words of every matrix of a batch
+struct ResScratch { void *p = nullptr; size_t bytes = 0; int device = -1; int nbatch = 0; int serial = 0; };
+static thread_local ResScratch g_res;
+static int res_scratch(int nbatch, size_t es, void **pub, int **flags)
+{
+    int dev = 0;
+    GPX_HIP(hipGetDevice(&dev));
+    const size_t fbytes = ((size_t)nbatch * RES_FLAGS * sizeof(int) + 255) / 256 * 256;
+    const size_t need = fbytes + (size_t)nbatch * RES_SLOTS * IB * IB * 8;
+    if (g_res.device != dev || g_res.bytes < need) {
+        if (g_res.p && g_res.device == dev) { GPX_HIP(hipDeviceSynchronize()); (void)hipFree(g_res.p); }
+        g_res.p = nullptr; g_res.bytes = 0; g_res.device = dev;
+        GPX_HIP(hipMalloc(&g_res.p, need));
+        GPX_HIP(hipMemset(g_res.p, 0, need));
+        GPX_HIP(hipDeviceSynchronize());
+        g_res.bytes = need;
+        g_res.serial = 0;
+    }
+    (void)es;
+    *flags = (int *)g_res.p;
+    *pub = (char *)g_res.p + fbytes;
+    return GPX_OK;
+}
+
+int64_t panel_res_max()
+{
+    static const int64_t v = getenv("GPX_POTRF_RES") ? atoll(getenv("GPX_POTRF_RES")) : (int64_t)RES_MAXSTEPS * IB;
+    return std::min<int64_t>(v, (int64_t)RES_MAXSTEPS * IB);
+}
+
+template <typename T>
+static int panel_res_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int64_t kb, int *info_dev, hipStream_t st,
+                       const Batch *bt)
+{
+    const int nbatch = bt ? bt->count : 1;
+    void *pub = nullptr; int *flags = nullptr;
+    GPX_TRY(res_scratch(nbatch, sizeof(T), &pub, &flags));
+    const int64_t rows = n - r0;
+    dim3 grid((unsigned)cdiv(rows, IB), (unsigned)nbatch);
+    const double kd = (double)kb;
+    ProfScope prof(PC_POTRF_DIAG, (kd * kd * kd / 3.0 + (double)(rows - kb) * kd * kd) * nbatch, st);
+    hipLaunchKernelGGL((panel_res_kernel<T>), grid, dim3(256), 0, st, A, lda, n, r0, c0, (int)(kb / IB), info_dev, (T *)pub,
+                       flags, ++g_res.serial, bt ? bt->sA : (int64_t)0);
+    GPX_LAUNCH_CHECK();
+    return GPX_OK;
+}
+
+int potrf_panel_res(int dtype, void *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int64_t kb, int *info_dev,
+                    hipStream_t st, const Batch *bt)
+{
+    if (dtype == GPX_F64) return panel_res_t<double>((double *)A, lda, n, r0, c0, kb, info_dev, st, bt);
+    return panel_res_t<float>((float *)A, lda, n, r0, c0, kb, info_dev, st, bt);
+}
+
+}  // namespace gpx

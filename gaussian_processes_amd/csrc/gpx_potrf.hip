@@ -161,29 +161,6 @@ __global__ __launch_bounds__(320) void potrf_diag_pipe_kernel(T *__restrict__ bl
 // Operands go global/L2 -> registers directly in MFMA fragment layout (each is used by one wave only).
 // Workgroup 0 is dispatched first, so the producer is resident before any consumer can spin; should that
 // ever fail the spin is bounded and the step reports info = -7 instead of hanging.
-template <typename T> struct PM;
-template <> struct PM<double> {
-    typedef double v4 __attribute__((ext_vector_type(4)));
-    static constexpr int EPK = 16, SUB = 4;
-    __device__ static __forceinline__ v4 mfma(double a, double b, v4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
-    __device__ static __forceinline__ int row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
-};
-template <> struct PM<float> {
-    typedef float v4 __attribute__((ext_vector_type(4)));
-    static constexpr int EPK = 32, SUB = 8;
-    __device__ static __forceinline__ v4 mfma(float a, float b, v4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-    __device__ static __forceinline__ int row(int lane, int reg) { return 4 * (lane >> 4) + reg; }
-};
-
-template <typename T>
-__device__ __forceinline__ void load_frag32(const T *__restrict__ p, T (&f)[PM<T>::SUB])
-{
-    struct alignas(16) Q { unsigned w[4]; };
-    const Q a = reinterpret_cast<const Q *>(p)[0], b = reinterpret_cast<const Q *>(p)[1];
-    memcpy(&f[0], &a, 16);
-    memcpy(&f[PM<T>::SUB / 2], &b, 16);
-}
-
 constexpr int PS_SPIN = 1 << 21;          // polls of ~0.3 us: gives up after ~0.6 s
 
 template <typename T>
@@ -793,6 +770,8 @@ static int potrf_panel_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, i
 {
     const int nbatch = bt ? bt->count : 1;
     const int64_t sM = bt ? bt->sA : 0;              // stride between the matrices of a batch
+    if (!inv_slots && kb % IB == 0 && kb <= panel_res_max() && r0 == c0)
+        return potrf_panel_res(dtype, A, lda, n, r0, c0, kb, info_dev, st, bt);
     if (!inv_slots && tall_route(n - (r0 + kb), kb, lda, sizeof(T), A + r0 * lda + c0, bt))
         return potrf_panel_tall<T>(A, lda, n, r0, c0, kb, info_dev, st, dtype);
     if (!inv_slots && kb % IB == 0 && kb <= fused_max() && lda % (16 / (int64_t)sizeof(T)) == 0 &&
