@@ -105,12 +105,13 @@ int syrk_bc(int dtype, int64_t n, int64_t row_begin, void *Cloc, int64_t ldc, in
             hipStream_t st, const int *abort_flag = nullptr, const Batch *bt = nullptr);
 // factor rows [r0, n) x columns [c0, c0 + kb) of A whose diagonal block sits at (r0, c0)
 int potrf_panel(int dtype, void *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int64_t kb,
-                int *info_dev, hipStream_t st, const Batch *bt = nullptr);
+                int *info_dev, hipStream_t st, const Batch *bt = nullptr, int64_t kpre = 0);   // kpre: see potrf_panel_res
 int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t st, const Batch *bt = nullptr);
 // the same panel in ONE launch (gpx_panel.hip): kb a multiple of 64, at most panel_res_max()
 int potrf_panel_res(int dtype, void *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int64_t kb, int *info_dev,
-                    hipStream_t st, const Batch *bt = nullptr);
+                    hipStream_t st, const Batch *bt = nullptr, int64_t kpre = 0);
 int64_t panel_res_max();
+bool panel_res_fold(int64_t rows, int64_t kpre, int64_t kb, size_t es, int64_t lda, const void *base);
 // Per-factor block operators of the single-right-hand-side solves (gpx_solve.hip, "operator form"): owned by
 // whoever owns the factor; `valid` must be cleared whenever the factor changes.  nullptr: built per call.
 struct TrsvOps { void *buf = nullptr; size_t bytes = 0; bool valid = false; };

@@ -88,6 +88,22 @@ __device__ __forceinline__ void res_stage(const T *__restrict__ src, T (*dst)[PT
     }
 }
 
+// stage 64 rows x 64 columns of the matrix (rows lda apart, 16-byte aligned; rows >= nvalid repeat the last valid one)
+// into LDS.  Offsets inside the block fit 32 bits whatever the matrix size.
+template <typename T, int PT>
+__device__ __forceinline__ void res_stage_rows(const T *__restrict__ src, int lda, int nvalid, T (*dst)[PT])
+{
+    constexpr int E = 16 / (int)sizeof(T), RPW = 256 / (IB / E), PER = IB / RPW;     // elements per 16 bytes; rows per pass
+    struct alignas(16) Q { unsigned u[4]; };
+    const int row0 = threadIdx.x / (IB / E), col = (threadIdx.x % (IB / E)) * E;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int row = row0 + RPW * i;
+        const int rr = row < nvalid ? row : nvalid - 1;
+        *reinterpret_cast<Q *>(&dst[row][col]) = *reinterpret_cast<const Q *>(src + (unsigned)(rr * lda + col));
+    }
+}
+
 // acc[0..3] (+)= (+-) sa[16 wave + li][:] . sb[16 jj + li][:]^T over the 64 columns
 template <typename T, int PT, bool NEG>
 __device__ __forceinline__ void res_prod(const T (*sa)[PT], const T (*sb)[PT], typename PM<T>::v4 (&acc)[4], int wave, int li, int lq)
@@ -114,7 +130,7 @@ __device__ __forceinline__ void res_prod(const T (*sa)[PT], const T (*sb)[PT], t
 template <typename T>
 __global__ __launch_bounds__(256, 2) void panel_res_kernel(T *__restrict__ A, int64_t lda, int64_t n, int64_t r0, int64_t c0,
                                                            int nsteps, int *__restrict__ info, T *__restrict__ pub,
-                                                           int *__restrict__ flags, int serial, int64_t sM)
+                                                           int *__restrict__ flags, int serial, int64_t sM, int kpre)
 {
     typedef PM<T> M;
     typedef typename M::v4 v4;
@@ -151,6 +167,33 @@ __global__ __launch_bounds__(256, 2) void panel_res_kernel(T *__restrict__ A, in
                 const int64_t gr = wr0 + M::row(lane, r);
                 acc[c][jj][r] = have ? A[(gr < n ? gr : n - 1) * lda + c0 + IB * c + 16 * jj + li] : (T)0;
             }
+    }
+    // ---- left-looking pre-update with the kpre blocks of 64 columns immediately to the left of the panel (the
+    // previous panel of a small factorisation, or the left half of a wider panel): what used to be one more
+    // dependent GEMM launch in front of every panel.  P_c -= R R_c^T, R = my rows, R_c = the rows of diagonal block c.
+    // Workgroup 0 needs block 0 only (its own rows are R_0): kpre short products before the first leaf can start;
+    // the later diagonal blocks' longer pre-updates run under the leaves before them. ----
+    if (kpre > 0) {
+        const int nvalid = (int)(n - (r0 + (int64_t)w * IB) < IB ? n - (r0 + (int64_t)w * IB) : IB);
+        const T *mine = A + (r0 + (int64_t)w * IB) * lda;      // my 64 rows, column 0
+        for (int kc = 0; kc < kpre; ++kc) {
+            const int64_t pc = c0 - (int64_t)IB * (kpre - kc);
+            __syncthreads();
+            res_stage_rows<T, PT>(mine + pc, (int)lda, nvalid, sA);
+#pragma unroll
+            for (int c = 0; c < RES_MAXSTEPS; ++c) {
+                if (c >= nsteps || (future_diag && c > w)) break;
+                if (c == w) {
+                    __syncthreads();
+                    res_prod<T, PT, true>(sA, sA, acc[c], wave, li, lq);
+                    continue;
+                }
+                __syncthreads();                                // sA is in; the previous block's sB has been consumed
+                res_stage_rows<T, PT>(A + (r0 + (int64_t)IB * c) * lda + pc, (int)lda, IB, sB);
+                __syncthreads();
+                res_prod<T, PT, true>(sA, sB, acc[c], wave, li, lq);
+            }
+        }
     }
 #pragma unroll
     for (int j = 0; j < RES_MAXSTEPS; ++j) {
@@ -284,7 +327,7 @@ int64_t panel_res_max()
 
 template <typename T>
 static int panel_res_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int64_t kb, int *info_dev, hipStream_t st,
-                       const Batch *bt)
+                       const Batch *bt, int64_t kpre)
 {
     const int nbatch = bt ? bt->count : 1;
     void *pub = nullptr; int *flags = nullptr;
@@ -292,18 +335,30 @@ static int panel_res_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int
     const int64_t rows = n - r0;
     dim3 grid((unsigned)cdiv(rows, IB), (unsigned)nbatch);
     const double kd = (double)kb;
-    ProfScope prof(PC_POTRF_DIAG, (kd * kd * kd / 3.0 + (double)(rows - kb) * kd * kd) * nbatch, st);
+    ProfScope prof(PC_POTRF_DIAG, (kd * kd * kd / 3.0 + (double)(rows - kb) * kd * kd + 2.0 * (double)rows * kd * (double)kpre) * nbatch, st);
     hipLaunchKernelGGL((panel_res_kernel<T>), grid, dim3(256), 0, st, A, lda, n, r0, c0, (int)(kb / IB), info_dev, (T *)pub,
-                       flags, ++g_res.serial, bt ? bt->sA : (int64_t)0);
+                       flags, ++g_res.serial, bt ? bt->sA : (int64_t)0, (int)(kpre / IB));
     GPX_LAUNCH_CHECK();
     return GPX_OK;
 }
 
+// kpre (a multiple of 64, <= c0): that many columns immediately to the left of the panel, rows [r0, n), are applied to
+// it first (P -= R R_d^T); the caller then omits that update
 int potrf_panel_res(int dtype, void *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int64_t kb, int *info_dev,
-                    hipStream_t st, const Batch *bt)
+                    hipStream_t st, const Batch *bt, int64_t kpre)
 {
-    if (dtype == GPX_F64) return panel_res_t<double>((double *)A, lda, n, r0, c0, kb, info_dev, st, bt);
-    return panel_res_t<float>((float *)A, lda, n, r0, c0, kb, info_dev, st, bt);
+    if (dtype == GPX_F64) return panel_res_t<double>((double *)A, lda, n, r0, c0, kb, info_dev, st, bt, kpre);
+    return panel_res_t<float>((float *)A, lda, n, r0, c0, kb, info_dev, st, bt, kpre);
+}
+
+// fold the update by the columns to the left into the panel kernel?  (short panels only: a tall panel's workgroups
+// run in several rounds and the tuned GEMM does the same update faster than they do)
+bool panel_res_fold(int64_t rows, int64_t kpre, int64_t kb, size_t es, int64_t lda, const void *base)
+{
+    static const int64_t rows_max = getenv("GPX_POTRF_FOLD_ROWS") ? atoll(getenv("GPX_POTRF_FOLD_ROWS")) : 16384;
+    static const int64_t kpre_max = getenv("GPX_POTRF_FOLD_K") ? atoll(getenv("GPX_POTRF_FOLD_K")) : 256;
+    return kb % IB == 0 && kb <= panel_res_max() && kpre % IB == 0 && kpre > 0 && kpre <= kpre_max && rows <= rows_max &&
+           lda % (16 / (int64_t)es) == 0 && ((uintptr_t)base) % 16 == 0;
 }
 
 }  // namespace gpx

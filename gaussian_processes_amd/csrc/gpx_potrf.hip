@@ -579,9 +579,12 @@ static int64_t outer_block(int64_t n, bool batched = false)
     // measured per factorisation (v8): n = 8192: 128 / 256 / 512 -> 12.6 / 11.5 / 12.5 ms; n = 16384:
     // 256 / 512 -> 42.4 / 40.8; n = 24576: 256 / 512 / 1024 -> 106 / 98 / 102; n = 32768: 228 / 203 / 204;
     // n = 65536: 512 / 1024 -> 1445 / 1416 ms
+    // with the resident panel kernel (gpx_panel.hip): n = 8192: 256 / 512 -> 8.77 / 8.89 ms; n = 12288: 18.4 / 17.5;
+    // n = 16384: 36.3 / 32.8; n = 20480: 512 / 1024 -> 56.2 / 55.8; n = 24576: 89.9 / 87.8; n = 32768: 195.7 / 191.1
+    // (fp32: 105.9 / 100.5)
     if (n <= 2048) return 128;
-    if (n <= 12288) return 256;
-    if (n <= 32768) return 512;
+    if (n <= 8192) return 256;
+    if (n <= 20480) return 512;
     return 1024;
 }
 
@@ -614,7 +617,7 @@ static int leaf_scratch(size_t bytes, void **out)
 // row substitution below it.
 template <typename T>
 static int potrf_panel_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int64_t kb, int *info_dev,
-                         hipStream_t st, int dtype, const Batch *bt, T *inv_slots = nullptr, int64_t pc0 = 0);
+                         hipStream_t st, int dtype, const Batch *bt, T *inv_slots = nullptr, int64_t pc0 = 0, int64_t kpre = 0);
 
 template <typename T>
 __global__ void place_inv_kernel(const T *__restrict__ slots, T *__restrict__ W, T *__restrict__ Wt, int64_t ld)
@@ -766,12 +769,13 @@ static int potrf_panel_lean(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0
 
 template <typename T>
 static int potrf_panel_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int64_t kb, int *info_dev,
-                         hipStream_t st, int dtype, const Batch *bt, T *inv_slots, int64_t pc0)
+                         hipStream_t st, int dtype, const Batch *bt, T *inv_slots, int64_t pc0, int64_t kpre)
 {
     const int nbatch = bt ? bt->count : 1;
     const int64_t sM = bt ? bt->sA : 0;              // stride between the matrices of a batch
     if (!inv_slots && kb % IB == 0 && kb <= panel_res_max() && r0 == c0)
-        return potrf_panel_res(dtype, A, lda, n, r0, c0, kb, info_dev, st, bt);
+        return potrf_panel_res(dtype, A, lda, n, r0, c0, kb, info_dev, st, bt, kpre);
+    if (kpre != 0) { set_error("potrf_panel: a folded update needs the resident panel route"); return GPX_ERR_ARG; }
     if (!inv_slots && tall_route(n - (r0 + kb), kb, lda, sizeof(T), A + r0 * lda + c0, bt))
         return potrf_panel_tall<T>(A, lda, n, r0, c0, kb, info_dev, st, dtype);
     if (!inv_slots && kb % IB == 0 && kb <= fused_max() && lda % (16 / (int64_t)sizeof(T)) == 0 &&
@@ -838,15 +842,19 @@ static int potrf_panel_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, i
     const int64_t h = ((kb / IB + 1) / 2) * IB;          // left half, a multiple of 64
     GPX_TRY(potrf_panel_t<T>(A, lda, n, r0, c0, h, info_dev, st, dtype, bt, inv_slots, pc0));
     T *R = A + (r0 + h) * lda + c0;                       // rows below the left half's diagonal block
+    // the right half takes the left half's update itself when it is one resident-kernel launch over few rows
+    if (!inv_slots && r0 == c0 && panel_res_fold(n - (r0 + h), h, kb - h, sizeof(T), lda, A))
+        return potrf_panel_t<T>(A, lda, n, r0 + h, c0 + h, kb - h, info_dev, st, dtype, bt, inv_slots, pc0, h);
     GPX_TRY(gemm_nt(dtype, n - (r0 + h), kb - h, h, R, lda, R, lda, R + h, lda, -1.0, GPX_LOWER, 0, 0, st, 0, 0, bt));
     return potrf_panel_t<T>(A, lda, n, r0 + h, c0 + h, kb - h, info_dev, st, dtype, bt, inv_slots, pc0);
 }
 
 int potrf_panel(int dtype, void *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int64_t kb,
-                int *info_dev, hipStream_t st, const Batch *bt)
+                int *info_dev, hipStream_t st, const Batch *bt, int64_t kpre)
 {
-    if (dtype == GPX_F64) return potrf_panel_t<double>((double *)A, lda, n, r0, c0, kb, info_dev, st, dtype, bt);
-    return potrf_panel_t<float>((float *)A, lda, n, r0, c0, kb, info_dev, st, dtype, bt);
+    if (dtype == GPX_F64)
+        return potrf_panel_t<double>((double *)A, lda, n, r0, c0, kb, info_dev, st, dtype, bt, nullptr, 0, kpre);
+    return potrf_panel_t<float>((float *)A, lda, n, r0, c0, kb, info_dev, st, dtype, bt, nullptr, 0, kpre);
 }
 
 // side stream + event pool for the look-ahead (one set per host thread and device)
@@ -968,29 +976,41 @@ int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t
     GPX_HIP(hipStreamWaitEvent(q, e, 0));
     hipStream_t user = st;
     const int reserve = bt ? reserve_cus_batch(n, bt->count) : reserve_cus(n);
+    hipStream_t masked = nullptr;
     if (reserve > 0) {
-        hipStream_t masked = nullptr;
-        GPX_TRY(trailing_stream(reserve, &masked));             // the updates go to the masked stream
-        if (masked) {
-            st = masked;
-            GPX_HIP(hipStreamWaitEvent(st, e, 0));
-            g_leaf_pipe = true;
-        }
+        GPX_TRY(trailing_stream(reserve, &masked));             // the updates go to the masked stream ...
+        if (masked) g_leaf_pipe = true;
     }
+    // ... once the step is bound by the panel chain: while the trailing update is the longer of the two (many
+    // rows left) it keeps the whole chip
+    static const int64_t reserve_below = getenv("GPX_POTRF_RESERVE_BELOW") ? atoll(getenv("GPX_POTRF_RESERVE_BELOW")) : 8192;
+    auto switch_to = [&](hipStream_t want) -> int {
+        if (want == st) return GPX_OK;
+        hipEvent_t es;
+        GPX_TRY(g_la.get(&es));
+        GPX_HIP(hipEventRecord(es, st));
+        GPX_HIP(hipStreamWaitEvent(want, es, 0));
+        st = want;
+        return GPX_OK;
+    };
+    if (masked && n <= reserve_below) GPX_TRY(switch_to(masked));
     GPX_TRY(potrf_panel(dtype, A, lda, n, 0, 0, std::min(nb, n), info_dev, q, bt));
     GPX_TRY(g_la.get(&ep));
     GPX_HIP(hipEventRecord(ep, q));
     for (int64_t k0 = 0; k0 < n; k0 += nb) {
         const int64_t kb = std::min(nb, n - k0), r = k0 + kb;
+        if (masked && n - r <= reserve_below) GPX_TRY(switch_to(masked));
         GPX_HIP(hipStreamWaitEvent(st, ep, 0));                 // panel k is factored
         if (r >= n) break;
         const int64_t kb1 = std::min(nb, n - r);
-        // block column k + 1 first, so that its panel can start ...
-        GPX_TRY(syrk_bc(dtype, n, r, A, lda, r, r + kb1, at(k0, k0), lda, k0, kb, nb, 1, 0, st, info_dev, bt));
+        // block column k + 1 first, so that its panel can start ... (small n: the panel kernel applies panel k to its
+        // own columns itself, and only has to wait for the trailing update of step k - 1)
+        const bool fold = panel_res_fold(n - r, kb, kb1, es, lda, A);
+        if (!fold) GPX_TRY(syrk_bc(dtype, n, r, A, lda, r, r + kb1, at(k0, k0), lda, k0, kb, nb, 1, 0, st, info_dev, bt));
         GPX_TRY(g_la.get(&e));
         GPX_HIP(hipEventRecord(e, st));
         GPX_HIP(hipStreamWaitEvent(q, e, 0));
-        GPX_TRY(potrf_panel(dtype, A, lda, n, r, r, kb1, info_dev, q, bt));
+        GPX_TRY(potrf_panel(dtype, A, lda, n, r, r, kb1, info_dev, q, bt, fold ? kb : 0));
         GPX_TRY(g_la.get(&ep));
         GPX_HIP(hipEventRecord(ep, q));
         // ... while the rest of the trailing matrix is updated underneath it
