@@ -581,10 +581,19 @@ static int64_t outer_block(int64_t n, bool batched = false)
     // n = 65536: 512 / 1024 -> 1445 / 1416 ms
     // with the resident panel kernel (gpx_panel.hip): n = 8192: 256 / 512 -> 8.77 / 8.89 ms; n = 12288: 18.4 / 17.5;
     // n = 16384: 36.3 / 32.8; n = 20480: 512 / 1024 -> 56.2 / 55.8; n = 24576: 89.9 / 87.8; n = 32768: 195.7 / 191.1
-    // (fp32: 105.9 / 100.5)
-    if (n <= 2048) return 128;
-    if (n <= 8192) return 256;
-    if (n <= 20480) return 512;
+    // (fp32: 105.9 / 100.5).  The width is re-evaluated per panel with the rows that are left (potrf()), thresholds
+    // (rows for 128 / 256 / 512) measured with that taper: 128 never pays with the one-launch panel (n = 2048:
+    // 1.45 -> 1.35 ms), 512 -> 1024 above 12288 (n = 16384: 31.6 -> 31.3 ms, n = 32768 fp32: 101.1 -> 99.9)
+    static int64_t thr[3] = {1, 8192, 12288};
+    static const bool thr_env = [] {
+        const char *e = getenv("GPX_POTRF_WIDTHS");            // "rows128,rows256,rows512"
+        if (e) { long long a, b, c; if (sscanf(e, "%lld,%lld,%lld", &a, &b, &c) == 3) { thr[0] = a; thr[1] = b; thr[2] = c; } }
+        return e != nullptr;
+    }();
+    (void)thr_env;
+    if (n <= thr[0]) return 128;
+    if (n <= thr[1]) return 256;
+    if (n <= thr[2]) return 512;
     return 1024;
 }
 
@@ -994,28 +1003,43 @@ int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t
         return GPX_OK;
     };
     if (masked && n <= reserve_below) GPX_TRY(switch_to(masked));
-    GPX_TRY(potrf_panel(dtype, A, lda, n, 0, 0, std::min(nb, n), info_dev, q, bt));
+    // Tapered outer block: the width that suits a factorisation of the rows that are LEFT (wide while the trailing
+    // update is the longer of the two, narrow once the step is bound by the panel chain); widths only ever shrink
+    // and each divides the one before, so every panel stays aligned to its own width.  Lock-step batches and a
+    // forced GPX_POTRF_NB keep one width.
+    static const bool taper = !(getenv("GPX_POTRF_TAPER") && atoi(getenv("GPX_POTRF_TAPER")) == 0) && !getenv("GPX_POTRF_NB");
+    auto nominal = [&](int64_t k0) -> int64_t { return (taper && !bt) ? std::min(nb, outer_block(n - k0)) : nb; };
+    int64_t k0 = 0, kb = std::min(nominal(0), n);
+    GPX_TRY(potrf_panel(dtype, A, lda, n, 0, 0, kb, info_dev, q, bt));
     GPX_TRY(g_la.get(&ep));
     GPX_HIP(hipEventRecord(ep, q));
-    for (int64_t k0 = 0; k0 < n; k0 += nb) {
-        const int64_t kb = std::min(nb, n - k0), r = k0 + kb;
+    hipEvent_t e_rest = nullptr;                                // fires when the trailing update of the step before is done
+    while (true) {
+        const int64_t r = k0 + kb;
         if (masked && n - r <= reserve_below) GPX_TRY(switch_to(masked));
         GPX_HIP(hipStreamWaitEvent(st, ep, 0));                 // panel k is factored
         if (r >= n) break;
-        const int64_t kb1 = std::min(nb, n - r);
+        const int64_t w1 = nominal(r), kb1 = std::min(w1, n - r);
         // block column k + 1 first, so that its panel can start ... (small n: the panel kernel applies panel k to its
-        // own columns itself, and only has to wait for the trailing update of step k - 1)
+        // own columns itself -- it then only waits for the trailing update of step k - 1, not for this stream's turn)
         const bool fold = panel_res_fold(n - r, kb, kb1, es, lda, A);
-        if (!fold) GPX_TRY(syrk_bc(dtype, n, r, A, lda, r, r + kb1, at(k0, k0), lda, k0, kb, nb, 1, 0, st, info_dev, bt));
-        GPX_TRY(g_la.get(&e));
-        GPX_HIP(hipEventRecord(e, st));
-        GPX_HIP(hipStreamWaitEvent(q, e, 0));
+        if (!fold) {
+            GPX_TRY(syrk_bc(dtype, n, r, A, lda, r, r + kb1, at(k0, k0), lda, k0, kb, w1, 1, 0, st, info_dev, bt));
+            GPX_TRY(g_la.get(&e));
+            GPX_HIP(hipEventRecord(e, st));
+            GPX_HIP(hipStreamWaitEvent(q, e, 0));
+        } else if (e_rest) {
+            GPX_HIP(hipStreamWaitEvent(q, e_rest, 0));
+        }
         GPX_TRY(potrf_panel(dtype, A, lda, n, r, r, kb1, info_dev, q, bt, fold ? kb : 0));
         GPX_TRY(g_la.get(&ep));
         GPX_HIP(hipEventRecord(ep, q));
         // ... while the rest of the trailing matrix is updated underneath it
         if (r + kb1 < n)
-            GPX_TRY(syrk_bc(dtype, n, r, A, lda, r + kb1, n, at(k0, k0), lda, k0, kb, nb, 1, 0, st, info_dev, bt));
+            GPX_TRY(syrk_bc(dtype, n, r, A, lda, r + kb1, n, at(k0, k0), lda, k0, kb, w1, 1, 0, st, info_dev, bt));
+        GPX_TRY(g_la.get(&e_rest));
+        GPX_HIP(hipEventRecord(e_rest, st));
+        k0 = r; kb = kb1;
     }
     if (st != user) {
         GPX_TRY(g_la.get(&e));
