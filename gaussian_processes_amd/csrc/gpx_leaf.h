@@ -7,12 +7,14 @@ namespace gpx {
 
 constexpr int IB = 64;
 
+// 1 / sqrt(p).  v_rsq_f64 is good to 2^-24.2 on gfx950 (tools/rsq_probe.hip); ONE third-order step
+// y (1 + u/2 + 3u^2/8), u = 1 - p y^2, brings that to 2^-52.7 (1.2 ulp; two Newton steps: 2^-51.9) in a
+// dependent chain of 5 instead of 7 operations -- this sits on the critical path of every pivot.
 __device__ __forceinline__ double fast_rsqrt(double p)
 {
-    double y = __builtin_amdgcn_rsq(p);
-    y = y * fma(-0.5 * p * y, y, 1.5);
-    y = y * fma(-0.5 * p * y, y, 1.5);
-    return y;
+    const double y = __builtin_amdgcn_rsq(p);
+    const double u = fma(-(p * y), y, 1.0);
+    return fma(fma(0.375, u, 0.5), u * y, y);
 }
 __device__ __forceinline__ float fast_rsqrt(float p)
 {
@@ -150,21 +152,45 @@ __device__ __forceinline__ void factor64(T (&a)[4][4], T (&x)[4][4], int jb, int
 //   wave 4,    step jt:  [barrier 1]  --                                       [barrier 2]  rank-4 update of the diagonal
 //                        tiles t > jt with pan(jt), then lane jt + 1 factors ITS tile -> sD(jt + 1), under the others' C.
 // A step costs max(C, diagonal update + 4 pivots) + B instead of their sum.
+// Who a thread is in factor64_pipe.  Non-pivot threads own tile (tr, tc) of the block: its strictly-lower part of
+// A when tc < tr, its part of X when tc <= tr; pivot lane t < 16 owns the diagonal tile (t, t) of A.  Threads
+// without a tile (tr = -1, tc = 99 / t >= 16) only keep the barriers.
+struct LeafRole { int tr, tc; bool pivot; int t; };
+// 320 threads: waves 0-3 the full 16 x 16 grid of tiles, wave 4 the pivots
+__device__ __forceinline__ LeafRole leaf_role_320(int tid)
+{
+    LeafRole r; r.pivot = tid >= 256; r.t = tid - 256; r.tr = r.pivot ? -1 : (tid >> 4); r.tc = r.pivot ? 99 : (tid & 15);
+    return r;
+}
+// 256 threads: waves 0-2 the 120 strictly-lower tiles (row by row) and the 16 diagonal tiles of X, wave 3 the pivots
+__device__ __forceinline__ LeafRole leaf_role_256(int tid)
+{
+    LeafRole r; r.pivot = tid >= 192; r.t = tid - 192; r.tr = -1; r.tc = 99;
+    if (tid < 120) {
+        int tr = 1;
+        while ((tr + 1) * tr / 2 <= tid) ++tr;
+        r.tr = tr; r.tc = tid - tr * (tr - 1) / 2;
+    } else if (tid < 136) {
+        r.tr = r.tc = tid - 120;
+    }
+    return r;
+}
+
 template <typename T, bool INV>
 __device__ __forceinline__ void factor64_pipe(T (&a)[4][4], T (&x)[4][4], int jb, int64_t j0, int *__restrict__ info,
-                                              int nsteps = IB / 4, unsigned long long *stamps = nullptr)
+                                              const LeafRole ro, int nsteps = IB / 4, unsigned long long *stamps = nullptr)
 {
-    // a: waves 0-3: this thread's OFF-diagonal tile (tr, tc), tc < tr (others unused); wave 4, lane t < 16: the
-    // diagonal tile (t, t).  x: waves 0-3 as in factor64 (tile (tr, tc) of X); unused by wave 4.
+    // a: non-pivot threads: their OFF-diagonal tile (tr, tc), tc < tr (others unused); pivot lane t < 16: the
+    // diagonal tile (t, t).  x: non-pivot threads: tile (tr, tc) of X, tc <= tr; unused by the pivot wave.
     __shared__ T sD[4][4];
     __shared__ T sR[4];
     __shared__ T pan[IB][5];          // pitch 5: the column-tile reads pan[4 tc + c][k] of 16 lanes (stride 4 rows) spread
                                       // over the banks (pitch 4: 128-byte stride, 8-way conflicts)
     __shared__ T xrow[4][IB];
     const int tid = threadIdx.x;
-    const bool pivot = tid >= 256;
-    const int tr = tid >> 4, tc = tid & 15;           // waves 0-3
-    const int t = tid - 256;                          // wave 4: diagonal tile index (lanes 0..15)
+    const bool pivot = ro.pivot;
+    const int tr = ro.tr, tc = ro.tc;
+    const int t = ro.t;
     auto factor_tile = [&](int jt) {                  // by wave 4, lane jt: the four pivots of tile (jt, jt)
         T rk[4];
 #pragma unroll
@@ -268,7 +294,7 @@ __device__ __forceinline__ void factor64_pipe(T (&a)[4][4], T (&x)[4][4], int jb
                         for (int k = 0; k < 4; ++k) a[r][c] = fma(-lr[r][k], lc[k], a[r][c]);
                 }
             }
-            if (INV) {
+            if (INV && tc <= jt) {                    // (rows 4jt.. of X are zero to the right of column tile jt)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     T xs[4];

@@ -130,7 +130,8 @@ __device__ __forceinline__ void res_prod(const T (*sa)[PT], const T (*sb)[PT], t
 template <typename T>
 __global__ __launch_bounds__(256, 2) void panel_res_kernel(T *__restrict__ A, int64_t lda, int64_t n, int64_t r0, int64_t c0,
                                                            int nsteps, int *__restrict__ info, T *__restrict__ pub,
-                                                           int *__restrict__ flags, int serial, int64_t sM, int kpre)
+                                                           int *__restrict__ flags, int serial, int64_t sM, int kpre,
+                                                           unsigned long long *__restrict__ stamps)
 {
     typedef PM<T> M;
     typedef typename M::v4 v4;
@@ -146,6 +147,12 @@ __global__ __launch_bounds__(256, 2) void panel_res_kernel(T *__restrict__ A, in
     const int li = lane & 15, lq = lane >> 4;
     const int w = blockIdx.x;
     const bool future_diag = w < nsteps;
+    // diagnostic (gpx_debug_panel_stamps): 8 words per workgroup: start, pre-update done, steps 0..3 done, end, hardware id
+    auto stamp = [&](int slot) {
+        if (stamps && tid == 0 && blockIdx.y == 0) stamps[(size_t)w * 8 + slot] = __builtin_amdgcn_s_memrealtime();
+    };
+    stamp(0);
+    if (stamps && tid == 0 && blockIdx.y == 0) stamps[(size_t)w * 8 + 7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
     if (future_diag) __builtin_amdgcn_s_setprio(3);
     if (tid == 0) s_ok = (*info == 0);
     __syncthreads();
@@ -195,9 +202,11 @@ __global__ __launch_bounds__(256, 2) void panel_res_kernel(T *__restrict__ A, in
             }
         }
     }
+    stamp(1);
 #pragma unroll
     for (int j = 0; j < RES_MAXSTEPS; ++j) {
         if (j >= nsteps) break;
+        if (j > 0) stamp(1 + j);
         __syncthreads();                                        // sA / sB of the previous step are consumed
         // column block j of my rows -> LDS by rows (operand of the substitution, or the leaf's input)
 #pragma unroll
@@ -207,33 +216,44 @@ __global__ __launch_bounds__(256, 2) void panel_res_kernel(T *__restrict__ A, in
         if (w == j) {
             // ---- the diagonal block: leaf ----
             __syncthreads();
-            const int tr = tid >> 4, tc = tid & 15;
+            // the leaf with the pivot wave (gpx_leaf.h): waves 0-2 hold the strictly-lower tiles and X, wave 3 the
+            // diagonal tiles, factored one step ahead of the others' rank-4 update
+            static_assert(IB == 64, "leaf roles assume a 64 x 64 block");
+            const LeafRole ro = leaf_role_256(tid);
+            const bool own_a = ro.pivot ? ro.t < IB / 4 : ro.tc < ro.tr;
+            const bool own_x = !ro.pivot && ro.tr >= 0;
+            const int tr = ro.pivot ? ro.t : ro.tr, tc = ro.pivot ? ro.t : ro.tc;
             T a[4][4], x[4][4];
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const int row = 4 * tr + r, col = 4 * tc + c;
-                    a[r][c] = (col <= row) ? sA[row][col] : (T)0;
+                    a[r][c] = (own_a && col <= row) ? sA[row][col] : (T)0;
                     x[r][c] = (row == col) ? (T)1 : (T)0;
                 }
-            factor64<T, true>(a, x, IB, c0 + (int64_t)IB * j, info);
+            factor64_pipe<T, true>(a, x, IB, c0 + (int64_t)IB * j, info, ro);
             T *W = pub + (int64_t)j * (IB * IB);
+            if (own_x) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int row = 4 * tr + r, col = 4 * tc + c;
-                    pub_store(W + row * IB + col, (col <= row) ? x[r][c] : (T)0);
-                }
+                    for (int c = 0; c < 4; ++c) {
+                        const int row = 4 * tr + r, col = 4 * tc + c;
+                        pub_store(W + row * IB + col, (col <= row) ? x[r][c] : (T)0);     // (tiles above the diagonal: zero
+                    }                                                                      //  since the buffer was cleared)
+            }
             res_raise(flags + j, serial);
+            if (own_a) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int row = 4 * tr + r, col = 4 * tc + c;
-                    if (col <= row) A[(r0 + (int64_t)IB * j + row) * lda + c0 + IB * j + col] = a[r][c];
-                }
+                    for (int c = 0; c < 4; ++c) {
+                        const int row = 4 * tr + r, col = 4 * tc + c;
+                        if (col <= row) A[(r0 + (int64_t)IB * j + row) * lda + c0 + IB * j + col] = a[r][c];
+                    }
+            }
+            stamp(6);
             return;
         }
         // ---- rows below the diagonal block ----
@@ -293,7 +313,11 @@ __global__ __launch_bounds__(256, 2) void panel_res_kernel(T *__restrict__ A, in
             res_prod<T, PT, true>(sA, sB, acc[c], wave, li, lq);
         }
     }
+    stamp(6);
 }
+
+static unsigned long long *g_res_stamps = nullptr;             // diagnostic: the launch `g_res_stamp_at` launches from now records
+static int g_res_stamp_at = -1;
 
 // per host thread and device: the published blocks and flag words of every matrix of a batch
 struct ResScratch { void *p = nullptr; size_t bytes = 0; int device = -1; int nbatch = 0; int serial = 0; };
@@ -302,20 +326,26 @@ static int res_scratch(int nbatch, size_t es, void **pub, int **flags)
 {
     int dev = 0;
     GPX_HIP(hipGetDevice(&dev));
-    const size_t fbytes = ((size_t)nbatch * RES_FLAGS * sizeof(int) + 255) / 256 * 256;
-    const size_t need = fbytes + (size_t)nbatch * RES_SLOTS * IB * IB * 8;
-    if (g_res.device != dev || g_res.bytes < need) {
+    if (g_res.device != dev || g_res.nbatch < nbatch) {
         if (g_res.p && g_res.device == dev) { GPX_HIP(hipDeviceSynchronize()); (void)hipFree(g_res.p); }
-        g_res.p = nullptr; g_res.bytes = 0; g_res.device = dev;
+        g_res.p = nullptr; g_res.bytes = 0; g_res.device = dev; g_res.nbatch = 0;
+        const size_t fbytes = ((size_t)nbatch * RES_FLAGS * sizeof(int) + 255) / 256 * 256;
+        const size_t region = (size_t)nbatch * RES_SLOTS * IB * IB * 8;
+        const size_t need = fbytes + region + region / 2;
         GPX_HIP(hipMalloc(&g_res.p, need));
         GPX_HIP(hipMemset(g_res.p, 0, need));
         GPX_HIP(hipDeviceSynchronize());
         g_res.bytes = need;
+        g_res.nbatch = nbatch;
         g_res.serial = 0;
     }
-    (void)es;
+    // the layout follows the CAPACITY, not this call's batch: a slot keeps its address and its role for the life of
+    // the buffer (fp64 blocks first, the fp32 ones behind them) -- the tiles above a W block's diagonal are zero from
+    // the initial clear and never rewritten
+    const size_t fbytes = ((size_t)g_res.nbatch * RES_FLAGS * sizeof(int) + 255) / 256 * 256;
+    const size_t region = (size_t)g_res.nbatch * RES_SLOTS * IB * IB * 8;
     *flags = (int *)g_res.p;
-    *pub = (char *)g_res.p + fbytes;
+    *pub = (char *)g_res.p + fbytes + (es == 8 ? 0 : region);
     return GPX_OK;
 }
 
@@ -337,7 +367,8 @@ static int panel_res_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int
     const double kd = (double)kb;
     ProfScope prof(PC_POTRF_DIAG, (kd * kd * kd / 3.0 + (double)(rows - kb) * kd * kd + 2.0 * (double)rows * kd * (double)kpre) * nbatch, st);
     hipLaunchKernelGGL((panel_res_kernel<T>), grid, dim3(256), 0, st, A, lda, n, r0, c0, (int)(kb / IB), info_dev, (T *)pub,
-                       flags, ++g_res.serial, bt ? bt->sA : (int64_t)0, (int)(kpre / IB));
+                       flags, ++g_res.serial, bt ? bt->sA : (int64_t)0, (int)(kpre / IB),
+                       (g_res_stamps && g_res_stamp_at-- == 0) ? g_res_stamps : (unsigned long long *)nullptr);
     GPX_LAUNCH_CHECK();
     return GPX_OK;
 }
@@ -362,3 +393,11 @@ bool panel_res_fold(int64_t rows, int64_t kpre, int64_t kb, size_t es, int64_t l
 }
 
 }  // namespace gpx
+
+// diagnostic: the `at`-th resident panel launch from now stores 8 words per workgroup into dev_buffer (tools/panel_stamps.py)
+extern "C" int gpx_debug_panel_stamps(void *dev_buffer, int at)
+{
+    gpx::g_res_stamps = (unsigned long long *)dev_buffer;
+    gpx::g_res_stamp_at = at;
+    return GPX_OK;
+}

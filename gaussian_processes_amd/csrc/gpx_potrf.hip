@@ -135,7 +135,7 @@ __global__ __launch_bounds__(320) void potrf_diag_pipe_kernel(T *__restrict__ bl
             a[r][c] = v;
             x[r][c] = (row == col) ? (T)1 : (T)0;
         }
-    factor64_pipe<T, INV>(a, x, jb, j0, info, nsteps, stamps);
+    factor64_pipe<T, INV>(a, x, jb, j0, info, leaf_role_320(tid), nsteps, stamps);
     if (!live) return;
     const bool own_a = pivot || tc < tr;              // waves 0-3 own the strictly-lower tiles, wave 4 the diagonal ones
 #pragma unroll

@@ -1,0 +1,33 @@
+"""tools/panel_stamps.py -- per-workgroup timeline of ONE resident-panel launch inside a fit: N [launch index]
+(s_memrealtime, 100 MHz: dispatch delay, pre-update, the four steps, end; diagnostic)."""
+import sys, os, ctypes, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gaussian_processes_amd import _lib, gp, kernels
+from gaussian_processes_amd.device import DeviceBuffer, sync
+lib = _lib.load()
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+at = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+d = 8
+rng = np.random.RandomState(0)
+X = rng.uniform(-10, 10, (N, d)); y = np.sin(X.sum(1) / np.sqrt(d)) + 0.1 * rng.randn(N)
+g = gp.GP(kernels.GaussianKernel(1.0, 0.5 * np.sqrt(d)), X, y, s=1.0)
+_ = g.log_lh                                           # warm
+st = DeviceBuffer((2048 * 8,), np.uint64).zero()
+lib.gpx_debug_panel_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+lib.gpx_debug_panel_stamps(st.ptr, at)
+g.s = 1.0001
+_ = g.log_lh
+sync()
+lib.gpx_debug_panel_stamps(None, -1)
+s = st.to_host().reshape(-1, 8).astype(np.int64)
+live = np.nonzero(s[:, 0])[0]
+t0 = s[live, 0].min()
+print("launch %d of the fit: %d workgroups; times in us after the first workgroup's start" % (at, len(live)))
+print("  wg   start  preupd   step0   step1   step2   step3     end   xcc/cu")
+for w in live:
+    r = s[w]
+    f = lambda v: "%7.1f" % ((v - t0) / 100.0) if v else "      -"
+    if w < 8 or w % 8 == 0 or w == live[-1]:
+        print("%4d %s %s %s %s %s %s %s   %x" % (w, f(r[0]), f(r[1]), f(r[2]), f(r[3]), f(r[4]), f(r[5]), f(r[6]), r[7]))
+ends = (s[live, 6] - t0) / 100.0; starts = (s[live, 0] - t0) / 100.0
+print("last start %.1f us, last end %.1f us (workgroup %d)" % (starts.max(), ends.max(), live[ends.argmax()]))
