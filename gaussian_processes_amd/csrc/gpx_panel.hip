@@ -76,6 +76,71 @@ __device__ __forceinline__ void res_wait(const int *flag, int serial, int *s_ok,
     }
 }
 
+// 16-byte agent-scope (sc1) accesses: half as many requests as the 8-byte atomics for the same block.  The compiler
+// does not count inline-asm loads: pub_wait() both waits and makes every later use depend on it.
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4v pub_load16(const void *p)
+{
+    uint4v v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void pub_store16(void *p, uint4v v)
+{
+    // (s_nop 1: gfx940+ needs two wait states between a store of more than 64 bits and a VALU write to its data
+    //  registers; the compiler's hazard recogniser does not look inside inline asm)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+}
+template <int N> __device__ __forceinline__ void pub_wait(uint4v (&v)[N])
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(v[i]));
+}
+
+// stage the 16 x 16 tiles on and below the diagonal of a published W = inv(L) (row-major 64 x 64; fp64: the tiles
+// above are never read by res_prod_w) into LDS: 10 of 16 tiles, 16-byte loads
+template <typename T, int PT>
+__device__ __forceinline__ void res_stage_w(const T *__restrict__ src, T (*dst)[PT])
+{
+    constexpr int E = 16 / (int)sizeof(T), UPR = 16 / E, UPT = 16 * UPR, TOTAL = 10 * UPT, PER = (TOTAL + 255) / 256;
+    uint4v v[PER];
+    int row[PER], col[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        int u = threadIdx.x + 256 * i;
+        if (u >= TOTAL) u = TOTAL - 1;                          // (duplicates the last unit: harmless)
+        const int tile = u / UPT, w = u % UPT;
+        // tiles (ti, tj), tj <= ti, numbered row by row: 0:(0,0) 1:(1,0) 2:(1,1) 3:(2,0) ...
+        const int ti = tile < 1 ? 0 : tile < 3 ? 1 : tile < 6 ? 2 : 3, tj = tile - ti * (ti + 1) / 2;
+        row[i] = 16 * ti + w / UPR; col[i] = 16 * tj + (w % UPR) * E;
+        v[i] = pub_load16(src + row[i] * IB + col[i]);
+    }
+    pub_wait<PER>(v);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) *reinterpret_cast<uint4v *>(&dst[row[i]][col[i]]) = v[i];
+}
+
+// x[0..3] += sa[16 wave + li][:] . W^T with W lower triangular (fp64: one k-chunk = one tile, tile (jj, kc) is zero for kc > jj)
+template <typename T, int PT>
+__device__ __forceinline__ void res_prod_w(const T (*sa)[PT], const T (*sb)[PT], typename PM<T>::v4 (&acc)[4], int wave, int li, int lq)
+{
+    typedef PM<T> M;
+    constexpr int EPK = M::EPK, SUB = M::SUB, NCH = IB / EPK;
+    static_assert(EPK == 16, "one k-chunk per 16 x 16 tile");
+#pragma unroll
+    for (int kc = 0; kc < NCH; ++kc) {
+        T fa[SUB], fb[4][SUB];
+        load_frag32<T>(&sa[16 * wave + li][kc * EPK + lq * SUB], fa);
+#pragma unroll
+        for (int jj = kc; jj < 4; ++jj) load_frag32<T>(&sb[16 * jj + li][kc * EPK + lq * SUB], fb[jj]);
+#pragma unroll
+        for (int ss = 0; ss < SUB; ++ss)
+#pragma unroll
+            for (int jj = kc; jj < 4; ++jj) acc[jj] = M::mfma(fa[ss], fb[jj][ss], acc[jj]);
+    }
+}
+
 // stage a published 64 x 64 row-major block into LDS (pitch PT)
 template <typename T, int PT>
 __device__ __forceinline__ void res_stage(const T *__restrict__ src, T (*dst)[PT])
@@ -149,10 +214,10 @@ __global__ __launch_bounds__(256, 2) void panel_res_kernel(T *__restrict__ A, in
     const bool future_diag = w < nsteps;
     // diagnostic (gpx_debug_panel_stamps): 8 words per workgroup: start, pre-update done, steps 0..3 done, end, hardware id
     auto stamp = [&](int slot) {
-        if (stamps && tid == 0 && blockIdx.y == 0) stamps[(size_t)w * 8 + slot] = __builtin_amdgcn_s_memrealtime();
+        if (stamps && tid == 0 && blockIdx.y == 0) stamps[(size_t)w * 16 + slot] = __builtin_amdgcn_s_memrealtime();
     };
     stamp(0);
-    if (stamps && tid == 0 && blockIdx.y == 0) stamps[(size_t)w * 8 + 7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+    if (stamps && tid == 0 && blockIdx.y == 0) stamps[(size_t)w * 16 + 7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
     if (future_diag) __builtin_amdgcn_s_setprio(3);
     if (tid == 0) s_ok = (*info == 0);
     __syncthreads();
@@ -234,14 +299,19 @@ __global__ __launch_bounds__(256, 2) void panel_res_kernel(T *__restrict__ A, in
                 }
             factor64_pipe<T, true>(a, x, IB, c0 + (int64_t)IB * j, info, ro);
             T *W = pub + (int64_t)j * (IB * IB);
-            if (own_x) {
+            if (own_x) {                                         // (tiles above the diagonal: zero since the buffer was cleared)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < 4; ++r) {
+                    T rowv[4];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const int row = 4 * tr + r, col = 4 * tc + c;
-                        pub_store(W + row * IB + col, (col <= row) ? x[r][c] : (T)0);     // (tiles above the diagonal: zero
-                    }                                                                      //  since the buffer was cleared)
+                    for (int c = 0; c < 4; ++c) rowv[c] = (4 * tc + c <= 4 * tr + r) ? x[r][c] : (T)0;
+                    constexpr int E = 16 / (int)sizeof(T);
+#pragma unroll
+                    for (int h = 0; h < 4 / E; ++h) {
+                        uint4v q; memcpy(&q, &rowv[h * E], 16);
+                        pub_store16(W + (4 * tr + r) * IB + 4 * tc + h * E, q);
+                    }
+                }
             }
             res_raise(flags + j, serial);
             if (own_a) {
@@ -259,19 +329,25 @@ __global__ __launch_bounds__(256, 2) void panel_res_kernel(T *__restrict__ A, in
         // ---- rows below the diagonal block ----
         res_wait(flags + j, serial, &s_ok, !future_diag);
         __syncthreads();
+        if (w == j + 1) stamp(8);
         if (!s_ok) {
             if (tid == 0) atomicCAS(info, 0, -7);
             if (future_diag && tid < RES_FLAGS) __hip_atomic_store(flags + tid, serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
         }
-        res_stage<T, PT>(pub + (int64_t)j * (IB * IB), sB);
+        // everybody wants W_j at once; only workgroup j + 1 is the chain: the others give its loads a head start
+        if (!future_diag) __builtin_amdgcn_s_sleep(48);
+        if constexpr (sizeof(T) == 8) res_stage_w<T, PT>(pub + (int64_t)j * (IB * IB), sB);
+        else res_stage<T, PT>(pub + (int64_t)j * (IB * IB), sB);
         __syncthreads();
+        if (w == j + 1) stamp(9);
         v4 x[4];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
             for (int r = 0; r < 4; ++r) x[jj][r] = (T)0;
-        res_prod<T, PT, false>(sA, sB, x, wave, li, lq);
+        if constexpr (sizeof(T) == 8) res_prod_w<T, PT>(sA, sB, x, wave, li, lq);
+        else res_prod<T, PT, false>(sA, sB, x, wave, li, lq);
         // X is final: store it, keep it in LDS as an operand, publish it when these are the rows of a later diagonal block
         T *Xp = future_diag ? pub + (int64_t)res_xslot(w, j) * (IB * IB) : nullptr;
 #pragma unroll
@@ -283,13 +359,16 @@ __global__ __launch_bounds__(256, 2) void panel_res_kernel(T *__restrict__ A, in
                 if (future_diag) pub_store(Xp + lr * IB + 16 * jj + li, x[jj][r]);
             }
         __syncthreads();                                        // sA is complete
+        if (w == j + 1) stamp(10);
         // ---- right-looking updates inside the panel; the own diagonal block first (it is the chain), and the
         // publication's drain hides under its MFMAs ----
         if (future_diag) {
 #pragma unroll
             for (int c = 1; c < RES_MAXSTEPS; ++c)
                 if (c == w) res_prod<T, PT, true>(sA, sA, acc[c], wave, li, lq);
+            if (w == j + 1) stamp(11);
             res_raise(flags + res_xslot(w, j), serial);
+            if (w == j + 1) stamp(12);
         }
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)

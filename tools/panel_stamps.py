@@ -12,14 +12,14 @@ rng = np.random.RandomState(0)
 X = rng.uniform(-10, 10, (N, d)); y = np.sin(X.sum(1) / np.sqrt(d)) + 0.1 * rng.randn(N)
 g = gp.GP(kernels.GaussianKernel(1.0, 0.5 * np.sqrt(d)), X, y, s=1.0)
 _ = g.log_lh                                           # warm
-st = DeviceBuffer((2048 * 8,), np.uint64).zero()
+st = DeviceBuffer((2048 * 16,), np.uint64).zero()
 lib.gpx_debug_panel_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 lib.gpx_debug_panel_stamps(st.ptr, at)
 g.s = 1.0001
 _ = g.log_lh
 sync()
 lib.gpx_debug_panel_stamps(None, -1)
-s = st.to_host().reshape(-1, 8).astype(np.int64)
+s = st.to_host().reshape(-1, 16).astype(np.int64)
 live = np.nonzero(s[:, 0])[0]
 t0 = s[live, 0].min()
 print("launch %d of the fit: %d workgroups; times in us after the first workgroup's start" % (at, len(live)))
@@ -29,5 +29,9 @@ for w in live:
     f = lambda v: "%7.1f" % ((v - t0) / 100.0) if v else "      -"
     if w < 8 or w % 8 == 0 or w == live[-1]:
         print("%4d %s %s %s %s %s %s %s   %x" % (w, f(r[0]), f(r[1]), f(r[2]), f(r[3]), f(r[4]), f(r[5]), f(r[6]), r[7]))
+print("chain hand-offs (workgroup j+1 at step j): flag seen, W staged, X done (+LDS), own update done, X flag raised")
+for w in live[:4]:
+    r = s[w]
+    if r[8]: print("  wg %d: %s" % (w, "  ".join("%7.1f" % ((r[k] - t0) / 100.0) for k in range(8, 13))))
 ends = (s[live, 6] - t0) / 100.0; starts = (s[live, 0] - t0) / 100.0
 print("last start %.1f us, last end %.1f us (workgroup %d)" % (starts.max(), ends.max(), live[ends.argmax()]))
