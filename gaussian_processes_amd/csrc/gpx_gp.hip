@@ -543,7 +543,9 @@ int gpx_gp_fit_batch(gpx_gp_t *g, const double *thetas, int64_t B, double *log_l
         GPX_TRY(dot(g->dtype, g->y, al.p, n, (double *)sc.p + 1, st, cnt, 0, sV, 2));
         GPX_HIP(hipMemcpyAsync(hs.data(), sc.p, (size_t)cnt * 2 * sizeof(double), hipMemcpyDeviceToHost, st));
         GPX_HIP(hipMemcpyAsync(hi.data(), inf.p, (size_t)cnt * sizeof(int), hipMemcpyDeviceToHost, st));
+        if (getenv("GPX_TRACE")) { fprintf(stderr, "[gpx] fit_batch: chunk of %d enqueued, waiting\n", cnt); fflush(stderr); }
         GPX_HIP(hipStreamSynchronize(st));
+        if (getenv("GPX_TRACE")) { fprintf(stderr, "[gpx] fit_batch: chunk done\n"); fflush(stderr); }
         for (int i = 0; i < cnt; ++i) {
             const double logdet = hs[2 * i], yta = hs[2 * i + 1];
             double v;

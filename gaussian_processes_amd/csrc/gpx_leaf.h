@@ -47,7 +47,9 @@ __device__ __forceinline__ void factor64(T (&a)[4][4], T (&x)[4][4], int jb, int
                 const T piv = a[k][k];
                 if (GIVEN) { rk[k] = (T)1 / piv; continue; }
                 if (4 * jt + k < jb && !(piv > (T)0)) {              // also catches NaN
-                    if (*info == 0) *info = (int)(j0 + 4 * jt + k + 1);
+                    // first failure wins; an atomic because the leaves of one resident-panel launch run in
+                    // workgroups on different XCDs (a plain store would sit in one L2)
+                    atomicCAS(info, 0, (int)(j0 + 4 * jt + k + 1));
                 }
                 // 1/sqrt(piv) by v_rsq + Newton steps (error ~1 ulp), sqrt(piv) = piv * rinv
                 const T rinv = fast_rsqrt(piv);
@@ -196,9 +198,7 @@ __device__ __forceinline__ void factor64_pipe(T (&a)[4][4], T (&x)[4][4], int jb
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const T piv = a[k][k];
-            if (4 * jt + k < jb && !(piv > (T)0)) {
-                if (*info == 0) *info = (int)(j0 + 4 * jt + k + 1);
-            }
+            if (4 * jt + k < jb && !(piv > (T)0)) atomicCAS(info, 0, (int)(j0 + 4 * jt + k + 1));   // first failure wins
             const T rinv = fast_rsqrt(piv);
             rk[k] = rinv;
             a[k][k] = piv * rinv;

@@ -401,19 +401,23 @@ static int g_res_stamp_at = -1;
 // per host thread and device: the published blocks and flag words of every matrix of a batch
 struct ResScratch { void *p = nullptr; size_t bytes = 0; int device = -1; int nbatch = 0; int serial = 0; };
 static thread_local ResScratch g_res;
+#define RES_TRACE(...) do { if (getenv("GPX_TRACE")) { fprintf(stderr, "[gpx] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
 static int res_scratch(int nbatch, size_t es, void **pub, int **flags)
 {
     int dev = 0;
     GPX_HIP(hipGetDevice(&dev));
     if (g_res.device != dev || g_res.nbatch < nbatch) {
+        RES_TRACE("res_scratch: grow %d -> %d matrices (device %d, old %p)", g_res.nbatch, nbatch, dev, g_res.p);
         if (g_res.p && g_res.device == dev) { GPX_HIP(hipDeviceSynchronize()); (void)hipFree(g_res.p); }
         g_res.p = nullptr; g_res.bytes = 0; g_res.device = dev; g_res.nbatch = 0;
         const size_t fbytes = ((size_t)nbatch * RES_FLAGS * sizeof(int) + 255) / 256 * 256;
         const size_t region = (size_t)nbatch * RES_SLOTS * IB * IB * 8;
         const size_t need = fbytes + region + region / 2;
+        RES_TRACE("res_scratch: old block released");
         GPX_HIP(hipMalloc(&g_res.p, need));
         GPX_HIP(hipMemset(g_res.p, 0, need));
         GPX_HIP(hipDeviceSynchronize());
+        RES_TRACE("res_scratch: new block %p, %zu bytes, cleared", g_res.p, need);
         g_res.bytes = need;
         g_res.nbatch = nbatch;
         g_res.serial = 0;
@@ -430,7 +434,7 @@ static int res_scratch(int nbatch, size_t es, void **pub, int **flags)
 
 int64_t panel_res_max()
 {
-    static const int64_t v = getenv("GPX_POTRF_RES") ? atoll(getenv("GPX_POTRF_RES")) : (int64_t)RES_MAXSTEPS * IB;
+    const int64_t v = getenv("GPX_POTRF_RES") ? atoll(getenv("GPX_POTRF_RES")) : (int64_t)RES_MAXSTEPS * IB;   // (read per call: tests switch it)
     return std::min<int64_t>(v, (int64_t)RES_MAXSTEPS * IB);
 }
 
@@ -444,6 +448,8 @@ static int panel_res_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int
     const int64_t rows = n - r0;
     dim3 grid((unsigned)cdiv(rows, IB), (unsigned)nbatch);
     const double kd = (double)kb;
+    RES_TRACE("panel_res: n %lld r0 %lld kb %lld kpre %lld batch %d grid %u serial %d", (long long)n, (long long)r0, (long long)kb,
+              (long long)kpre, nbatch, grid.x, g_res.serial + 1);
     ProfScope prof(PC_POTRF_DIAG, (kd * kd * kd / 3.0 + (double)(rows - kb) * kd * kd + 2.0 * (double)rows * kd * (double)kpre) * nbatch, st);
     hipLaunchKernelGGL((panel_res_kernel<T>), grid, dim3(256), 0, st, A, lda, n, r0, c0, (int)(kb / IB), info_dev, (T *)pub,
                        flags, ++g_res.serial, bt ? bt->sA : (int64_t)0, (int)(kpre / IB),
@@ -465,8 +471,8 @@ int potrf_panel_res(int dtype, void *A, int64_t lda, int64_t n, int64_t r0, int6
 // run in several rounds and the tuned GEMM does the same update faster than they do)
 bool panel_res_fold(int64_t rows, int64_t kpre, int64_t kb, size_t es, int64_t lda, const void *base)
 {
-    static const int64_t rows_max = getenv("GPX_POTRF_FOLD_ROWS") ? atoll(getenv("GPX_POTRF_FOLD_ROWS")) : 16384;
-    static const int64_t kpre_max = getenv("GPX_POTRF_FOLD_K") ? atoll(getenv("GPX_POTRF_FOLD_K")) : 256;
+    const int64_t rows_max = getenv("GPX_POTRF_FOLD_ROWS") ? atoll(getenv("GPX_POTRF_FOLD_ROWS")) : 16384;
+    const int64_t kpre_max = getenv("GPX_POTRF_FOLD_K") ? atoll(getenv("GPX_POTRF_FOLD_K")) : 256;
     return kb % IB == 0 && kb <= panel_res_max() && kpre % IB == 0 && kpre > 0 && kpre <= kpre_max && rows <= rows_max &&
            lda % (16 / (int64_t)es) == 0 && ((uintptr_t)base) % 16 == 0;
 }

@@ -409,12 +409,12 @@ __global__ __launch_bounds__(256) void panel_rows_kernel(T *__restrict__ A, int6
 // substitution and update launches of the tuned GEMM kernel it replaces: potrf 10.3 -> 12.1 ms.  Off by default.
 static int64_t lean_max()
 {
-    static const int64_t v = getenv("GPX_POTRF_LEAN") ? atoll(getenv("GPX_POTRF_LEAN")) : 0;
+    const int64_t v = getenv("GPX_POTRF_LEAN") ? atoll(getenv("GPX_POTRF_LEAN")) : 0;       // (read per call: tests switch it)
     return std::min<int64_t>(v, (LEAN_TMAX + 1) * IB);
 }
 static int64_t lean_rows_max()
 {
-    static const int64_t v = getenv("GPX_POTRF_LEAN_ROWS") ? atoll(getenv("GPX_POTRF_LEAN_ROWS")) : 16384;
+    const int64_t v = getenv("GPX_POTRF_LEAN_ROWS") ? atoll(getenv("GPX_POTRF_LEAN_ROWS")) : 16384;
     return v;
 }
 
@@ -448,7 +448,7 @@ static int fused_scratch(int nbatch, size_t es, void **xinv, int **flag)
 // (26 us of every step) is faster.
 static int64_t fused_max()
 {
-    static const int64_t v = getenv("GPX_POTRF_FUSED") ? atoll(getenv("GPX_POTRF_FUSED")) : 0;
+    const int64_t v = getenv("GPX_POTRF_FUSED") ? atoll(getenv("GPX_POTRF_FUSED")) : 0;
     return v;
 }
 
@@ -734,7 +734,7 @@ static bool tall_route(int64_t below, int64_t kb, int64_t lda, size_t es, const 
     // 5 - 8 dependent small launches to the panel chain (n = 8192: fit 10.6 -> 13.8 ms; n = 16384: 37.9 -> 45.3;
     // n = 32768 fp32: 108 -> 116) and at n = 65536, where the chain is hidden anyway, the fit is unchanged
     // (1.383 vs 1.389 s).  Kept because it is the shape a fused inverse kernel would slot into.
-    static const int64_t env = getenv("GPX_POTRF_TALL") ? atoll(getenv("GPX_POTRF_TALL")) : 0;
+    const int64_t env = getenv("GPX_POTRF_TALL") ? atoll(getenv("GPX_POTRF_TALL")) : 0;
     if (!env || bt) return false;
     if (kb < 2 * IB || (kb & (kb - 1)) != 0) return false;                 // 128, 256, 512, 1024
     if (below < 2 * kb || below < env) return false;
@@ -870,11 +870,22 @@ int potrf_panel(int dtype, void *A, int64_t lda, int64_t n, int64_t r0, int64_t 
 struct LookAhead {
     int device = -1;
     hipStream_t q = nullptr;
-    hipStream_t t = nullptr;      // trailing-update stream that leaves `reserved` CUs to the panel stream
-    int reserved = 0;
-    // a CU-masked stream that is still alive when the process tears down crashes rocprofv3's
-    // finaliser: give it back when the owning thread ends
-    ~LookAhead() { if (t) { (void)hipStreamSynchronize(t); (void)hipStreamDestroy(t); t = nullptr; } }
+    // trailing-update streams that leave `reserved` CUs to the panel stream, one per reservation ever asked for.
+    // They live until the owning thread ends: pooled events keep referring to the stream they were last recorded
+    // on, and a factorisation that alternates between reservations (single fits: 32, small lock-step batches: 16)
+    // must not destroy a stream under them (seen as an intermittent hang of the next fit).  At thread end they are
+    // given back -- a CU-masked stream that is still alive at process teardown crashes rocprofv3's finaliser.
+    static constexpr int MAXT = 8;
+    hipStream_t t[MAXT] = {};
+    int reserved[MAXT] = {};
+    int nt = 0;
+    void drop_streams()
+    {
+        for (int i = 0; i < nt; ++i)
+            if (t[i]) { (void)hipStreamSynchronize(t[i]); (void)hipStreamDestroy(t[i]); t[i] = nullptr; }
+        nt = 0;
+    }
+    ~LookAhead() { drop_streams(); }
     std::vector<hipEvent_t> ev;
     size_t next = 0;
     int get(hipEvent_t *e)
@@ -895,8 +906,8 @@ static int lookahead_setup()
     int dev = 0;
     GPX_HIP(hipGetDevice(&dev));
     if (g_la.device != dev) {
-        if (g_la.t) { (void)hipStreamSynchronize(g_la.t); (void)hipStreamDestroy(g_la.t); g_la.t = nullptr; }
-        g_la.q = nullptr; g_la.ev.clear(); g_la.reserved = 0;
+        g_la.drop_streams();
+        g_la.q = nullptr; g_la.ev.clear();
         g_la.device = dev;
         // the panel is on the critical path of the NEXT step: give its stream the highest
         // priority so that its workgroups get the CUs that trailing-update workgroups free up
@@ -916,21 +927,22 @@ static int lookahead_setup()
 // the panel stream keeps the whole chip.
 static int trailing_stream(int reserve, hipStream_t *out)
 {
-    if (g_la.t && g_la.reserved == reserve) { *out = g_la.t; return GPX_OK; }
-    if (g_la.t) { GPX_HIP(hipStreamSynchronize(g_la.t)); (void)hipStreamDestroy(g_la.t); g_la.t = nullptr; }
+    for (int i = 0; i < g_la.nt; ++i)
+        if (g_la.reserved[i] == reserve) { *out = g_la.t[i]; return GPX_OK; }
+    *out = nullptr;
+    if (g_la.nt == LookAhead::MAXT) return GPX_OK;              // (more distinct reservations than anyone asks for: share the chip)
     hipDeviceProp_t prop;
     GPX_HIP(hipGetDeviceProperties(&prop, g_la.device));
     const int ncu = prop.multiProcessorCount;
     std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
     for (int i = reserve; i < ncu; ++i) mask[i / 32] |= 1u << (i % 32);
-    if (hipExtStreamCreateWithCUMask(&g_la.t, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+    hipStream_t t = nullptr;
+    if (hipExtStreamCreateWithCUMask(&t, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
         (void)hipGetLastError();                                // masks unsupported here: share the chip as for large n
-        g_la.t = nullptr; g_la.reserved = 0;
-        *out = nullptr;
         return GPX_OK;
     }
-    g_la.reserved = reserve;
-    *out = g_la.t;
+    g_la.t[g_la.nt] = t; g_la.reserved[g_la.nt] = reserve; ++g_la.nt;
+    *out = t;
     return GPX_OK;
 }
 

@@ -1042,6 +1042,7 @@ def test_native_mg_world_on_one_gpu_vs_oracle(tmp_path, world, N, nb, dtype_id):
 def test_tall_panel_route_opt_in_vs_oracle(monkeypatch):
     """GPX_POTRF_TALL (opt-in): diagonal block first, W = inv(L11) by recursive doubling (batched s x s x s
     products), all rows below in one product with the lower-triangular k-loop cut (ktri = 2)."""
+    monkeypatch.setenv("GPX_POTRF_RES", "0")          # (the resident panel kernel would take the 128-wide panels first)
     monkeypatch.setenv("GPX_POTRF_TALL", "1")
     N, d = 2600, 3
     X, y, Xo = orc.synth_inputs(N, d, 32)
@@ -1060,6 +1061,7 @@ def test_lean_panel_route_opt_in_vs_oracle(monkeypatch, dtype):
     """GPX_POTRF_LEAN (opt-in): per 64 panel columns the leaf (which also saves the next diagonal blocks' rows) and ONE
     row kernel doing the substitution and every in-panel update of its 64 rows (the diagonal rows' substituted values
     recomputed by each workgroup from the saved copy)."""
+    monkeypatch.setenv("GPX_POTRF_RES", "0")          # (the resident panel kernel would take these panels first)
     monkeypatch.setenv("GPX_POTRF_LEAN", "256")
     N, d = 1800, 3
     X, y, Xo = orc.synth_inputs(N, d, 32)
@@ -1080,6 +1082,7 @@ def test_fused_panel_steps_opt_in_vs_oracle(monkeypatch, dtype):
     the diagonal block and raises an agent-scope flag, the other workgroups do their left-looking update
     meanwhile, poll (bounded) and apply the inverse.  Single matrices and the lock-step batch."""
     from gaussian_processes_amd import mlii
+    monkeypatch.setenv("GPX_POTRF_RES", "0")          # (the resident panel kernel would take these panels first)
     monkeypatch.setenv("GPX_POTRF_FUSED", "256")
     N, d = 1800, 3
     X, y, Xo = orc.synth_inputs(N, d, 32)
@@ -1133,3 +1136,83 @@ def test_trsv_operator_form_vs_numpy(dtype, n, monkeypatch):
     _lib.check(lib.gpx_d_trsv_lower(did, dL.ptr, n, ld, dzc.ptr, da.ptr, 1, None))
     sync()
     np.testing.assert_allclose(da.to_host().astype(np.float64), a_ref, rtol=tol, atol=tol * np.abs(a_ref).max())
+
+
+# ---- resident panel kernel (gpx_panel.hip): the default route of every panel of <= 256 columns ----
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("N,nb", [(1990, "256"), (1990, "128"), (2048, "256"), (4171, "512"), (700, "256"), (64, "256"), (130, "128")])
+def test_resident_panel_vs_launch_chain_and_oracle(monkeypatch, dtype, N, nb):
+    """One launch per panel (rows in MFMA accumulators, leaf + inverse by the diagonal workgroup, sc1 hand-off of
+    W = inv(L_jj) and of the diagonal rows' X blocks, left-looking pre-update by the columns to the left) against
+    (a) the oracle and (b) the launch chain it replaces (GPX_POTRF_RES=0: leaf, substitution and update kernels),
+    with the folded update on and off: ragged last workgroup, ragged last panel (old route), 1 - 4 steps,
+    panels narrower than the matrix, a matrix smaller than one panel."""
+    d = 3
+    X, y, Xo = orc.synth_inputs(N, d, 16)
+    h, w, s = 1.0, 0.5 * np.sqrt(d), 0.9
+    o = orc.OracleGP("gaussian", (h, w), X, y, s)
+    monkeypatch.setenv("GPX_POTRF_NB", nb)
+    res = {}
+    for label, env in (("resident", {}), ("resident_nofold", {"GPX_POTRF_FOLD_ROWS": "0"}), ("chain", {"GPX_POTRF_RES": "0"})):
+        for k in ("GPX_POTRF_FOLD_ROWS", "GPX_POTRF_RES"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        g = gp.GP(gp.GaussianKernel(h, w), X, y, s=s, dtype=dtype)
+        res[label] = (float(g.log_lh), np.array(g.Lxx, dtype=np.float64))
+    if dtype == "float64":
+        for label, (llh, L) in res.items():
+            np.testing.assert_allclose(llh, o.log_lh, rtol=1e-10, err_msg=label)
+            np.testing.assert_allclose(np.tril(L), o.Lxx, rtol=1e-9, atol=1e-12, err_msg=label)
+        np.testing.assert_allclose(np.tril(res["resident"][1]), np.tril(res["chain"][1]), rtol=1e-11, atol=1e-13)
+    else:
+        for label, (llh, L) in res.items():
+            np.testing.assert_allclose(llh, o.log_lh, rtol=1e-4, err_msg=label)
+            np.testing.assert_allclose(np.tril(L), o.Lxx, rtol=2e-3, atol=2e-4, err_msg=label)
+
+
+def test_resident_panel_reports_first_failing_minor():
+    """A pivot <= 0 inside the resident kernel (diagonal workgroup 0, 1, 2 or 3 of a panel; first or later panel):
+    info = LAPACK's first failing leading minor, nobody is left spinning, LinAlgError as the reference raises."""
+    N = 1104                                               # (gpx_d_potrf wants lda % 16 == 0)
+    rng = np.random.RandomState(3)
+    B = rng.randn(N, N)
+    A0 = B @ B.T + N * np.eye(N)
+    lib = _lib.load()
+    for bad in (0, 70, 130, 200, 255, 256, 300, 700, 1103):
+        A = A0.copy()
+        A[bad, bad] = -1.0                                 # minor bad + 1 is the first that is not positive definite
+        dA = DeviceBuffer.from_host(A)
+        info = DeviceBuffer((4,), np.int32).zero()
+        _lib.check(lib.gpx_d_potrf(_lib.F64, dA.ptr, N, N, info.ptr, None))
+        sync()
+        assert int(info.to_host()[0]) == bad + 1, (bad, int(info.to_host()[0]))
+        dA.free(); info.free()
+    # and the same matrix without the defect still factors afterwards (flags / scratch left consistent)
+    dA = DeviceBuffer.from_host(A0)
+    info = DeviceBuffer((4,), np.int32).zero()
+    _lib.check(lib.gpx_d_potrf(_lib.F64, dA.ptr, N, N, info.ptr, None))
+    L = np.tril(dA.to_host())
+    assert int(info.to_host()[0]) == 0
+    np.testing.assert_allclose(L, scipy.linalg.cholesky(A0, lower=True), rtol=1e-10, atol=1e-12)
+
+
+def test_resident_panel_interleaved_dtypes_and_batches(monkeypatch):
+    """The published blocks live in a per-thread scratch whose layout must not depend on the call: fp64, fp32,
+    a batch of 3, fp64 again, a batch of 2 in fp32 -- every result equal to the oracle's."""
+    from gaussian_processes_amd import mlii
+    N, d = 1350, 2
+    X, y, _ = orc.synth_inputs(N, d, 4)
+    thetas = np.array([[1.0, 0.9, 1.0], [0.7, 1.4, 0.8], [1.3, 0.6, 1.2]])
+    ref = [orc.OracleGP("gaussian", th[:2], X, y, th[2]).log_lh for th in thetas]
+    def single(dtype, i):
+        g = gp.GP(gp.GaussianKernel(*thetas[i, :2]), X, y, s=thetas[i, 2], dtype=dtype)
+        return float(g.log_lh)
+    np.testing.assert_allclose(single("float64", 0), ref[0], rtol=1e-10)
+    np.testing.assert_allclose(single("float32", 1), ref[1], rtol=1e-4)
+    np.testing.assert_allclose(mlii.log_lh_batch(X, y, thetas, dtype="float64"), ref, rtol=1e-10)
+    np.testing.assert_allclose(single("float64", 2), ref[2], rtol=1e-10)
+    np.testing.assert_allclose(mlii.log_lh_batch(X, y, thetas[:2], dtype="float32"), ref[:2], rtol=1e-4)
+    np.testing.assert_allclose(single("float32", 0), ref[0], rtol=1e-4)
+    np.testing.assert_allclose(mlii.log_lh_batch(X, y, thetas, dtype="float64"), ref, rtol=1e-10)
