@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void panel_res_kernel(T *__restrict__ A, in
                     a[r][c] = (own_a && col <= row) ? sA[row][col] : (T)0;
                     x[r][c] = (row == col) ? (T)1 : (T)0;
                 }
-            factor64_pipe<T, true>(a, x, IB, c0 + (int64_t)IB * j, info, ro);
+            factor64_pipe<T, true>(a, x, IB, r0 + (int64_t)IB * j, info, ro);      // (r0 = the global index of the panel's first pivot)
             T *W = pub + (int64_t)j * (IB * IB);
             if (own_x) {                                         // (tiles above the diagonal: zero since the buffer was cleared)
 #pragma unroll

@@ -782,7 +782,8 @@ static int potrf_panel_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, i
 {
     const int nbatch = bt ? bt->count : 1;
     const int64_t sM = bt ? bt->sA : 0;              // stride between the matrices of a batch
-    if (!inv_slots && kb % IB == 0 && kb <= panel_res_max() && r0 == c0)
+    // (c0 is a LOCAL column for a rank of the multi-GPU schedule: r0 != c0 there)
+    if (!inv_slots && kb % IB == 0 && kb <= panel_res_max())
         return potrf_panel_res(dtype, A, lda, n, r0, c0, kb, info_dev, st, bt, kpre);
     if (kpre != 0) { set_error("potrf_panel: a folded update needs the resident panel route"); return GPX_ERR_ARG; }
     if (!inv_slots && tall_route(n - (r0 + kb), kb, lda, sizeof(T), A + r0 * lda + c0, bt))
@@ -852,7 +853,7 @@ static int potrf_panel_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, i
     GPX_TRY(potrf_panel_t<T>(A, lda, n, r0, c0, h, info_dev, st, dtype, bt, inv_slots, pc0));
     T *R = A + (r0 + h) * lda + c0;                       // rows below the left half's diagonal block
     // the right half takes the left half's update itself when it is one resident-kernel launch over few rows
-    if (!inv_slots && r0 == c0 && panel_res_fold(n - (r0 + h), h, kb - h, sizeof(T), lda, A))
+    if (!inv_slots && panel_res_fold(n - (r0 + h), h, kb - h, sizeof(T), lda, A))
         return potrf_panel_t<T>(A, lda, n, r0 + h, c0 + h, kb - h, info_dev, st, dtype, bt, inv_slots, pc0, h);
     GPX_TRY(gemm_nt(dtype, n - (r0 + h), kb - h, h, R, lda, R, lda, R + h, lda, -1.0, GPX_LOWER, 0, 0, st, 0, 0, bt));
     return potrf_panel_t<T>(A, lda, n, r0 + h, c0 + h, kb - h, info_dev, st, dtype, bt, inv_slots, pc0);
