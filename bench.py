@@ -298,7 +298,8 @@ def measure_single(args, lib, _lib, N, d, m, dtid, npdt, steps, warmup, local_ra
         # the figure is the committed rocprofv3 --pmc measurement of THIS command and workload (two separate
         # passes, FETCH_SIZE with the gfx950 x2 correction + WRITE_SIZE; tools/profile_round.sh).  It is only
         # reported when it was taken with the GEMM source that is running now (sha256 of gpx_gemm.hip recorded
-        # beside the counters); otherwise traffic is null and the stale figure is labelled as such.
+        # beside the counters) and the same number of launches per step; otherwise traffic is null and the stale
+        # figure is labelled as such.
         if N == 65536 and d == 32 and dtype_name == "f64":
             try:
                 import hashlib
@@ -309,13 +310,14 @@ def measure_single(args, lib, _lib, N, d, m, dtid, npdt, steps, warmup, local_ra
                     sha = hashlib.sha256(f.read()).hexdigest()
                 label = "bytes per launch (fetch corrected %.3e + write %.3e)" % (
                     pmc["fetch_bytes_per_launch_corrected"], pmc["write_bytes_per_launch"])
-                if pmc.get("gemm_source_sha256") == sha:
+                same_schedule = abs(pmc.get("launches_per_step", 0) - roofline["launches_per_step"]) < 0.5
+                if pmc.get("gemm_source_sha256") == sha and same_schedule:
                     roofline["traffic"] = round(pmc["traffic_bytes_per_launch"])
                     roofline["traffic_unit"] = label
                     roofline["traffic_over_algorithmic"] = round(pmc["traffic_over_algorithmic"], 2)
                 else:
                     roofline["traffic_stale"] = {"value": round(pmc["traffic_bytes_per_launch"]), "unit": label,
-                                                 "note": "measured with an earlier build of gpx_gemm.hip"}
+                                                 "note": "measured with an earlier build (gpx_gemm.hip or the launch schedule changed)"}
                 roofline["traffic_source"] = "profiles/r02_pmc/traffic_n65536.json (rocprofv3 --pmc, offline)"
             except (OSError, KeyError, ValueError):
                 pass

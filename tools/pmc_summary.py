@@ -11,33 +11,56 @@ res = {}
 for cname in ("FETCH_SIZE", "WRITE_SIZE"):
     files = glob.glob(os.path.join(out, "pmc_" + cname, "**", "*counter_collection.csv"), recursive=True)
     tot, cnt = defaultdict(float), defaultdict(int)
+    summary = os.path.join(out, "bench_%s_by_kernel.csv" % cname)
+    if not files and os.path.exists(summary):            # raw per-dispatch CSVs already dropped: re-read the sums
+        for r in csv.DictReader(open(summary)):
+            tot[r["Kernel_Name"]] = float(r["Sum_KB"]); cnt[r["Kernel_Name"]] = int(r["Dispatches"])
+        res[cname] = (tot, cnt)
+        continue
     for f in files:
         for r in csv.DictReader(open(f)):
             if r.get("Counter_Name") != cname:
                 continue
             tot[r["Kernel_Name"]] += float(r["Counter_Value"]); cnt[r["Kernel_Name"]] += 1
-    with open(os.path.join(out, "bench_%s_by_kernel.csv" % cname), "w") as g:
+    with open(summary, "w") as g:
         g.write("Kernel_Name,Dispatches,Counter_Name,Sum_KB,Per_Dispatch_KB\n")
         for k in sorted(tot, key=lambda k: -tot[k]):
             g.write('"%s",%d,%s,%.1f,%.1f\n' % (k, cnt[k], cname, tot[k], tot[k] / cnt[k]))
     res[cname] = (tot, cnt)
+
+
+def schedule(N):
+    """(k0, width) of every panel: gpx_potrf.hip outer_block() re-evaluated with the rows left (256 / 512 / 1024 for
+    <= 8192 / <= 12288 / more)."""
+    out, k0 = [], 0
+    while k0 < N:
+        left = N - k0
+        w = 256 if left <= 8192 else 512 if left <= 12288 else 1024
+        w = min(w, left)
+        out.append((k0, w)); k0 += w
+    return out
+
+
 key = [k for k in res["FETCH_SIZE"][0] if "gemm_nt_fast_kernel<double, 128, 1, 128>" in k]
 if key:
     k = key[0]
     n = res["FETCH_SIZE"][1][k]
     fetch = res["FETCH_SIZE"][0][k] / n * 1024.0 * 2.0
     write = res["WRITE_SIZE"][0][k] / res["WRITE_SIZE"][1][k] * 1024.0
-    N, nb = 65536, 1024
-    steps = n / 125.0
-    # algorithmic bytes per average launch: the lower-triangle C update (one atomic add per element) + the panel once
-    c_bytes = sum(8.0 * (N - (j + 1) * nb) * ((N - (j + 1) * nb) + 1) / 2 for j in range(N // nb - 1)) / 125.0
-    p_bytes = sum(8.0 * (N - (j + 1) * nb) * nb for j in range(N // nb - 1)) / 125.0
+    N, fits = 65536, 2                                  # the profiled command runs one warm-up and one timed fit
+    per_fit = n / float(fits)
+    # algorithmic bytes of one fit's trailing updates: every element of the lower triangle to the right of a panel is
+    # read and written once per panel (8 B each way is counted once: WRITE_SIZE sees the atomic add's write), and the
+    # panel itself is read once; divided by the launches of that kernel per fit
+    c_tot = sum(8.0 * (N - (k0 + w)) * ((N - (k0 + w)) + 1) / 2 for k0, w in schedule(N))
+    p_tot = sum(8.0 * (N - (k0 + w)) * w for k0, w in schedule(N))
+    c_bytes, p_bytes = c_tot / per_fit, p_tot / per_fit
     src = open(os.path.join(root, "gaussian_processes_amd", "csrc", "gpx_gemm.hip"), "rb").read()
     json.dump({
         "command": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE> --output-format csv -- python3 bench.py --steps 1 "
                    "--warmup 1 --no-cpu-baseline --no-secondary --no-prof  (two separate passes)",
         "workload": "N=65536 d=32 f64, 1 GPU", "kernel": "gpx::gemm_nt_fast_kernel<double, 128, 1, 128>",
-        "dispatches_profiled": n, "launches_per_step": 125.0,
+        "dispatches_profiled": n, "launches_per_step": per_fit,
         "fetch_bytes_per_launch_corrected": fetch, "write_bytes_per_launch": write,
         "traffic_bytes_per_launch": fetch + write,
         "correction": "FETCH_SIZE doubled (gfx950 wide-read correction, MI355X_MICROARCH.md HBM section); WRITE_SIZE as read; unit KB",
