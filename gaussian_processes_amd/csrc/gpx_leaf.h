@@ -337,4 +337,179 @@ __device__ __forceinline__ void load_frag32(const T *__restrict__ p, T (&f)[PM<T
     memcpy(&f[PM<T>::SUB / 2], &b, 16);
 }
 
+
+// ---- the 64 x 64 leaf on the MFMA pipe (fp64) ------------------------------------------------------------------
+// The sweeps above hold the block as 4 x 4 thread tiles and do every rank-4 update on the VALU: a 4-column step costs
+// ~2700 cycles, almost all of it instruction issue and LDS round trips (tools/lat_probe.hip: the dependent arithmetic
+// of the four pivots is ~250).  v_mfma_f64_16x16x4 has exactly the step's depth K = 4, so here the block STAYS in
+// MFMA accumulator layout -- wave w rows 16w.., tiles a[jj] = columns 16jj.. (lane (li, lq): column li, rows lq + 4r)
+// -- which is also how the resident panel kernel already holds it, and a step is
+//   S1  the step's column strip (64 x 4) goes to LDS;                                            [barrier]
+//   S2  ONE lane factors the 4 x 4 diagonal tile and inverts it (the only VALU chain left);      [barrier]
+//   S3  every wave: new strip = strip . inv(L_dd)^T, one MFMA (A = strip rows, B = the 4 x 4 inverse, zero padded);
+//   S4  the new strip goes to LDS (the diagonal rows take L_dd itself); the wave that owns the diagonal rows forms the
+//       step's four rows of X = inv(L): X_d <- inv(L_dd) X_d, four MFMAs whose B operand is ALREADY in place in its
+//       accumulator registers (lane (li, lq), register q holds X[c0 + lq][col li]) and whose result lands back in the
+//       same registers; X_d goes to LDS;                                                         [barrier]
+//   S5  every wave: the strip's final values into its tile, then rank-4 updates  a[jj] -= L_s L_s^T  (tiles right of
+//       the step) and  x[jj] -= L_s X_d  (tiles left of it): 5 MFMAs.
+// Masks instead of branches: operand rows / columns at or above the step contribute zeros.  Three barriers and ~6
+// MFMAs a step.  Measured (tools/panel_stamps.py, stamps of step 9): 2200 cycles a step -- the pivot lane 1220 (one lane,
+// ~60 dependent fp64 operations, 8 LDS reads, 12 writes), strip solve + LDS 460, updates 510, barriers -- = 14.7 us a
+// leaf against 21.5 us for the pivot-wave VALU sweep (factor64_pipe), and no layout conversion on the way in or out.  Only the lower triangle of the block is read (the upper part of a diagonal block is stale in a
+// lower-only factorisation) and only it is meaningful on return; x must hold the identity on entry.
+__device__ __forceinline__ void factor64_mfma(PM<double>::v4 (&a)[4], PM<double>::v4 (&x)[4], int64_t j0, int *__restrict__ info,
+                                              int wave, int lane, unsigned long long *stamps = nullptr)
+{
+    typedef PM<double> M;
+    typedef M::v4 v4;
+    __shared__ __attribute__((aligned(16))) double sS[IB][4];   // the step's column strip as it is (S1) -- rows of the block
+    __shared__ double sLn[IB][4];         // the step's finished strip of L
+    __shared__ __attribute__((aligned(16))) double sWi[2][4][4];   // inv(L_dd) of the step (by parity), zero above the diagonal
+    __shared__ __attribute__((aligned(16))) double sDd[4][4];      // L_dd, zero above the diagonal
+    __shared__ double sXd[4][IB];         // four rows of X (of the step before: the X side runs one step behind)
+    const int li = lane & 15, lq = lane >> 4;
+    const v4 zero = {0.0, 0.0, 0.0, 0.0};
+    if (threadIdx.x < 16) {
+        sWi[0][threadIdx.x >> 2][threadIdx.x & 3] = 0.0; sWi[1][threadIdx.x >> 2][threadIdx.x & 3] = 0.0;
+        sDd[threadIdx.x >> 2][threadIdx.x & 3] = 0.0;
+    }
+    // (the parts above the diagonal stay zero: the pivot lane only ever writes the lower ones; the first barrier of
+    //  step 0 orders this against the first reads)
+    double al_prev = 0.0;                 // the previous step's strip as (negated, masked) A operand: its X update is applied one step late
+    // The X side (the step's four rows X_d <- inv(L_dd) X_d by the wave that owns them, then x -= L_s X_d) is not on the
+    // path to the next pivot.  It runs ONE STEP BEHIND: X_d of step jt - 1 is formed while the pivot lane -- in another
+    // wave -- factors the diagonal tile of step jt, and its rank-4 update joins the accumulator updates of step jt.
+    // fully unrolled: the tile (jj0) and register (q) the step touches must be compile-time constants, or the
+    // accumulator arrays go to scratch memory (first version: 544 bytes of scratch a lane, 48 us a leaf)
+#pragma unroll
+    for (int jt = 0; jt < IB / 4; ++jt) {
+        const int c0 = 4 * jt, jj0 = jt >> 2, q = jt & 3;
+        const int jjp = (jt - 1) >> 2, qp = (jt - 1) & 3;        // the step before (jt > 0)
+        const int pw = (jj0 + 1) & 3;                              // the pivot lane's wave: never the wave busy with X_d
+        // ---- S1 ----
+        if ((li >> 2) == q) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sS[16 * wave + lq + 4 * r][li & 3] = a[jj0][r];
+        }
+        __syncthreads();
+        if (stamps && jt == 9 && threadIdx.x == 0) stamps[0] = __builtin_amdgcn_s_memtime();
+        // ---- S2 ----
+        if (wave == pw && lane == 0) {
+            double d[4][4], wi[4][4], rk[4];
+            int bad = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                double row[4];
+                load_frag32<double>(&sS[c0 + i][0], row);       // two 16-byte LDS reads a row
+#pragma unroll
+                for (int k = 0; k < 4; ++k) d[i][k] = (k <= i) ? row[k] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double piv = d[k][k];
+                if (bad == 0 && !(piv > 0.0)) bad = c0 + k + 1;                      // also catches NaN; reported after the chain
+                const double rinv = fast_rsqrt(piv);
+                rk[k] = rinv;
+                d[k][k] = piv * rinv;
+#pragma unroll
+                for (int r = k + 1; r < 4; ++r) d[r][k] *= rinv;
+#pragma unroll
+                for (int c = k + 1; c < 4; ++c)
+#pragma unroll
+                    for (int r = c; r < 4; ++r) d[r][c] = fma(-d[r][k], d[c][k], d[r][c]);
+            }
+            // inv(L_dd): column by column, wi[i][k] = -rk[i] * sum_{m = k}^{i - 1} l[i][m] wi[m][k]
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (i < k) { wi[i][k] = 0.0; continue; }
+                    if (i == k) { wi[i][k] = rk[i]; continue; }
+                    double s = 0.0;
+#pragma unroll
+                    for (int m = k; m < i; ++m) s = fma(d[i][m], wi[m][k], s);
+                    wi[i][k] = -rk[i] * s;
+                }
+            }
+            // lower parts only, in 16-byte pieces where a row has a pair
+            struct alignas(16) D2 { double v[2]; };
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int k = 0; k + 1 <= i; k += 2) {
+                    *reinterpret_cast<D2 *>(&sWi[jt & 1][i][k]) = D2{{wi[i][k], wi[i][k + 1]}};
+                    *reinterpret_cast<D2 *>(&sDd[i][k]) = D2{{d[i][k], (k + 1 <= i) ? d[i][k + 1] : 0.0}};
+                }
+                if ((i & 1) == 0) { sWi[jt & 1][i][i] = wi[i][i]; sDd[i][i] = d[i][i]; }
+            }
+            if (bad != 0) atomicCAS(info, 0, (int)(j0 + bad));                         // first failure wins
+        }
+        if (jt > 0 && wave == jjp) {
+            // X_d of the step before (its inverse tile is still in the other half of sWi): B operand in place in the registers
+            const double wprev = (li < 4) ? sWi[(jt - 1) & 1][li][lq] : 0.0;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                if (jj > jjp) continue;                         // X is lower triangular: nothing to the right of the step
+                const v4 u = M::mfma(wprev, x[jj][qp], zero);
+                x[jj][qp] = u[0];
+                sXd[lq][16 * jj + li] = u[0];
+            }
+        }
+        if (stamps && jt == 9 && wave == pw && lane == 0) stamps[1] = __builtin_amdgcn_s_memtime();
+        __syncthreads();
+        if (stamps && jt == 9 && threadIdx.x == 0) stamps[2] = __builtin_amdgcn_s_memtime();
+        // ---- S3: new strip = strip . inv(L_dd)^T ----
+        const double winv = (li < 4) ? sWi[jt & 1][li][lq] : 0.0;   // B operand: B[k][n] = Winv[n][k]
+        const v4 t = M::mfma(sS[16 * wave + li][lq], winv, zero);
+        // ---- S4 ----
+        if (li < 4) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * wave + lq + 4 * r;
+                sLn[row][li] = (row >= c0 && row < c0 + 4) ? sDd[row - c0][li] : t[r];
+            }
+        }
+        if (stamps && jt == 9 && threadIdx.x == 0) stamps[3] = __builtin_amdgcn_s_memtime();
+        __syncthreads();
+        if (stamps && jt == 9 && threadIdx.x == 0) stamps[4] = __builtin_amdgcn_s_memtime();
+        // ---- S5 ----
+        if ((li >> 2) == q) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[jj0][r] = sLn[16 * wave + lq + 4 * r][li & 3];
+        }
+        const int arow = 16 * wave + li;
+        const double al = (arow > c0 + 3) ? -sLn[arow][lq] : 0.0;   // rows at or above the step: no update
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            // the tile that holds the NEXT step's strip first
+            const int tj = (jj + ((jt + 1) >> 2)) & 3;
+            if (tj >= jj0) {
+                const int bcol = 16 * tj + li;
+                const double bl = (bcol > c0 + 3) ? sLn[bcol][lq] : 0.0;          // columns up to the step are final
+                a[tj] = M::mfma(al, bl, a[tj]);
+            }
+        }
+        if (jt > 0) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                if (jj <= jjp) x[jj] = M::mfma(al_prev, sXd[lq][16 * jj + li], x[jj]);
+        }
+        al_prev = al;
+        if (stamps && jt == 9 && threadIdx.x == 0) stamps[5] = __builtin_amdgcn_s_memtime();
+        if (stamps && jt == 10 && threadIdx.x == 0) stamps[6] = __builtin_amdgcn_s_memtime();
+        // (no barrier: the next S1 writes sS, last read in S3 -- before the barrier after S4; sLn / sXd / sDd and the
+        //  parity half of sWi are rewritten only after the next step's first barrier, when every wave is past S5)
+    }
+    // the last step's X rows (its rank-4 update has no rows below it)
+    if (wave == 3) {
+        const double wprev = (li < 4) ? sWi[1][li][lq] : 0.0;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const v4 u = M::mfma(wprev, x[jj][3], zero);
+            x[jj][3] = u[0];
+        }
+    }
+}
+
 }  // namespace gpx

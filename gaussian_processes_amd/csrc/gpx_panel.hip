@@ -268,9 +268,11 @@ __global__ __launch_bounds__(256, 2) void panel_res_kernel(T *__restrict__ A, in
         }
     }
     stamp(1);
+    v4 dg[4];                                                   // fp64: the diagonal block of this workgroup when its step comes
+    int dg_step = -1;
 #pragma unroll
     for (int j = 0; j < RES_MAXSTEPS; ++j) {
-        if (j >= nsteps) break;
+        if (j >= nsteps || dg_step >= 0) continue;              // (no break: one loop exit, so the unrolled body keeps its static indices)
         if (j > 0) stamp(1 + j);
         __syncthreads();                                        // sA / sB of the previous step are consumed
         // column block j of my rows -> LDS by rows (operand of the substitution, or the leaf's input)
@@ -278,6 +280,14 @@ __global__ __launch_bounds__(256, 2) void panel_res_kernel(T *__restrict__ A, in
         for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
             for (int r = 0; r < 4; ++r) sA[16 * wave + M::row(lane, r)][16 * jj + li] = acc[j][jj][r];
+        if constexpr (sizeof(T) == 8) {
+            if (w == j) {                                       // fp64: the MFMA leaf, after the loop (ONE copy of its code)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) dg[jj] = acc[j][jj];
+                dg_step = j;
+                continue;
+            }
+        }
         if (w == j) {
             // ---- the diagonal block: leaf ----
             __syncthreads();
@@ -390,6 +400,34 @@ __global__ __launch_bounds__(256, 2) void panel_res_kernel(T *__restrict__ A, in
             res_stage<T, PT>(pub + (int64_t)res_xslot(c, j) * (IB * IB), sB);
             __syncthreads();
             res_prod<T, PT, true>(sA, sB, acc[c], wave, li, lq);
+        }
+    }
+    if constexpr (sizeof(T) == 8) {
+        if (dg_step >= 0) {
+            // ---- the diagonal block: the leaf on the MFMA pipe (gpx_leaf.h), in place in the accumulator tiles ----
+            const int j = dg_step;
+            v4 xw[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xw[jj][r] = (16 * wave + M::row(lane, r) == 16 * jj + li) ? (T)1 : (T)0;
+            factor64_mfma(dg, xw, r0 + (int64_t)IB * j, info, wave, lane, (stamps && w == 0 && blockIdx.y == 0) ? stamps + 2040 * 16 : nullptr);
+            T *W = pub + (int64_t)j * (IB * IB);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * wave + M::row(lane, r), col = 16 * jj + li;
+                    if (jj <= wave) pub_store(W + row * IB + col, (col <= row) ? xw[jj][r] : (T)0);   // (tiles above: zero since the clear)
+                }
+            res_raise(flags + j, serial);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * wave + M::row(lane, r), col = 16 * jj + li;
+                    if (col <= row) A[(r0 + (int64_t)IB * j + row) * lda + c0 + IB * j + col] = dg[jj][r];
+                }
         }
     }
     stamp(6);

@@ -21,7 +21,7 @@ sync()
 lib.gpx_debug_panel_stamps(None, -1)
 s = st.to_host().reshape(-1, 16).astype(np.int64)
 live = np.nonzero(s[:, 0])[0]
-t0 = s[live, 0].min()
+live = live[live < 2000]; t0 = s[live, 0].min()
 print("launch %d of the fit: %d workgroups; times in us after the first workgroup's start" % (at, len(live)))
 print("  wg   start  preupd   step0   step1   step2   step3     end   xcc/cu")
 for w in live:
@@ -33,5 +33,9 @@ print("chain hand-offs (workgroup j+1 at step j): flag seen, W staged, X done (+
 for w in live[:4]:
     r = s[w]
     if r[8]: print("  wg %d: %s" % (w, "  ".join("%7.1f" % ((r[k] - t0) / 100.0) for k in range(8, 13))))
+ls = st.to_host().reshape(-1, 16).astype(np.int64)[2040]
+if ls[0]:
+    print("MFMA leaf, step 9 of workgroup 0 (s_memtime cycles): S2 pivot %d, wait %d, S3+S4 %d, wait %d, S5 %d; whole step %d"
+          % (ls[1] - ls[0], ls[2] - ls[1], ls[3] - ls[2], ls[4] - ls[3], ls[5] - ls[4], ls[6] - ls[5]))
 ends = (s[live, 6] - t0) / 100.0; starts = (s[live, 0] - t0) / 100.0
 print("last start %.1f us, last end %.1f us (workgroup %d)" % (starts.max(), ends.max(), live[ends.argmax()]))
