@@ -106,7 +106,8 @@ int syrk_bc(int dtype, int64_t n, int64_t row_begin, void *Cloc, int64_t ldc, in
 // factor rows [r0, n) x columns [c0, c0 + kb) of A whose diagonal block sits at (r0, c0)
 int potrf_panel(int dtype, void *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int64_t kb,
                 int *info_dev, hipStream_t st, const Batch *bt = nullptr, int64_t kpre = 0);   // kpre: see potrf_panel_res
-int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t st, const Batch *bt = nullptr);
+int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t st, const Batch *bt = nullptr,
+          int64_t xrows = 0);      // xrows: extra rows below the matrix that ride along (A has n + xrows rows)
 // the same panel in ONE launch (gpx_panel.hip): kb a multiple of 64, at most panel_res_max()
 int potrf_panel_res(int dtype, void *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int64_t kb, int *info_dev,
                     hipStream_t st, const Batch *bt = nullptr, int64_t kpre = 0);

@@ -129,7 +129,7 @@ int gpx_gp_create(gpx_gp_t **out, int dtype, int kernel, int64_t n, int d)
     }
     GP_ALLOC(x, (size_t)n * d * es);
     GP_ALLOC(y, (size_t)n * es);
-    GP_ALLOC(A, (size_t)n * g->lda * es);
+    GP_ALLOC(A, (size_t)(n + 1) * g->lda * es);          // (+ one row: the right-hand side rides along in the factorisation)
     GP_ALLOC(alpha, (size_t)n * es);
     GP_ALLOC(t0, (size_t)n * es);
     GP_ALLOC(t1, (size_t)n * es);
@@ -235,13 +235,24 @@ int gpx_gp_fit(gpx_gp_t *g, int *info)
     g->have_K = false;   // the factor overwrites it
     GPX_HIP(hipEventRecord(g->ev[1], st));
     // Lxx (gp/gp.py:294), in place
-    GPX_TRY(potrf(g->dtype, g->A, g->n, g->lda, info_dev, st));
+    // Small and mid sizes: y rides along as row n of the matrix -- every panel substitutes it, every update reduces it,
+    // exactly what the forward solve L t = y would do afterwards -- so only the backward solve is left (n = 8192: the
+    // two solves were 1.0 ms of an 8 ms fit).  At large n the extra row of tiles in every update costs what it saves.
+    const int64_t ride_max = getenv("GPX_FIT_RIDE_MAX") ? atoll(getenv("GPX_FIT_RIDE_MAX")) : 16384;   // (read per call: tests switch it)
+    const bool ride = g->n <= ride_max;
+    char *row_n = (char *)g->A + (size_t)g->n * g->lda * es;
+    if (ride) GPX_HIP(hipMemcpyAsync(row_n, g->y, (size_t)g->n * es, hipMemcpyDeviceToDevice, st));
+    GPX_TRY(potrf(g->dtype, g->A, g->n, g->lda, info_dev, st, nullptr, ride ? 1 : 0));
     GPX_HIP(hipEventRecord(g->ev[2], st));
     // inv_Kxx_y = cho_solve((L, True), y) (gp/gp.py:332-334)
-    GPX_HIP(hipMemcpyAsync(g->t0, g->y, (size_t)g->n * es, hipMemcpyDeviceToDevice, st));
     g->ops.valid = false;                                 // a new factor: its block operators are rebuilt once
-    GPX_TRY(trsv_lower(g->dtype, g->A, g->n, g->lda, g->t0, g->t1, 0, st, nullptr, &g->ops));
-    GPX_TRY(trsv_lower(g->dtype, g->A, g->n, g->lda, g->t1, g->alpha, 1, st, nullptr, &g->ops));
+    if (ride) {
+        GPX_TRY(trsv_lower(g->dtype, g->A, g->n, g->lda, row_n, g->alpha, 1, st, nullptr, &g->ops));
+    } else {
+        GPX_HIP(hipMemcpyAsync(g->t0, g->y, (size_t)g->n * es, hipMemcpyDeviceToDevice, st));
+        GPX_TRY(trsv_lower(g->dtype, g->A, g->n, g->lda, g->t0, g->t1, 0, st, nullptr, &g->ops));
+        GPX_TRY(trsv_lower(g->dtype, g->A, g->n, g->lda, g->t1, g->alpha, 1, st, nullptr, &g->ops));
+    }
     GPX_HIP(hipEventRecord(g->ev[3], st));
     // logdet (replaces slogdet(K), gp_c.pyx:21) and y^T alpha (gp_c.pyx:26)
     GPX_TRY(logdet_chol(g->dtype, g->A, g->n, g->lda, g->scal + 0, st));
@@ -487,7 +498,9 @@ int gpx_gp_fit_batch(gpx_gp_t *g, const double *thetas, int64_t B, double *log_l
     const int64_t n = g->n, lda = g->lda;
     const size_t es = esize(g->dtype);
     const int np = g->nparams;
-    const size_t per = (size_t)n * lda * es;
+    const int64_t ride_max = getenv("GPX_FIT_RIDE_MAX") ? atoll(getenv("GPX_FIT_RIDE_MAX")) : 16384;   // (read per call: tests switch it)
+    const bool ride = n <= ride_max;                      // y rides along as row n of every matrix (see gpx_gp_fit)
+    const size_t per = (size_t)(n + (ride ? 1 : 0)) * lda * es;
     size_t freeb = 0, totalb = 0;
     GPX_HIP(hipMemGetInfo(&freeb, &totalb));
     int64_t Bc = (int64_t)((double)freeb * 0.85 / (double)(per + 4 * (size_t)n * es + 64));
@@ -516,7 +529,7 @@ int gpx_gp_fit_batch(gpx_gp_t *g, const double *thetas, int64_t B, double *log_l
     }
     const int64_t sV = (int64_t)(vec / es);               // element stride between the vectors of a chunk
     hipStream_t st = g->st;
-    const int64_t sM = n * lda;
+    const int64_t sM = (n + (ride ? 1 : 0)) * lda;
     std::vector<double> hs((size_t)Bc * 2);
     std::vector<int> hi((size_t)Bc), valid((size_t)Bc);
     const double eps = 2.220446049250313e-16;            // gp/kernels/gaussian.py:62-69: parameter < EPS is invalid
@@ -532,12 +545,17 @@ int gpx_gp_fit_batch(gpx_gp_t *g, const double *thetas, int64_t B, double *log_l
             const double s = ok ? th[np] : 1.0;
             GPX_TRY(kmat(g->dtype, g->kernel, GPX_K, g->x, n, g->x, n, g->d, prm, s * s, GPX_LOWER,
                          (char *)Ab.p + (size_t)i * per, lda, st));
-            GPX_HIP(hipMemcpyAsync((char *)t0.p + (size_t)i * vec, g->y, (size_t)n * es, hipMemcpyDeviceToDevice, st));
+            char *rhs = ride ? (char *)Ab.p + (size_t)i * per + (size_t)n * lda * es : (char *)t0.p + (size_t)i * vec;
+            GPX_HIP(hipMemcpyAsync(rhs, g->y, (size_t)n * es, hipMemcpyDeviceToDevice, st));
         }
         Batch bm; bm.count = cnt; bm.sA = bm.sB = bm.sC = sM;
-        GPX_TRY(potrf(g->dtype, Ab.p, n, lda, (int *)inf.p, st, cnt > 1 ? &bm : nullptr));
+        GPX_TRY(potrf(g->dtype, Ab.p, n, lda, (int *)inf.p, st, cnt > 1 ? &bm : nullptr, ride ? 1 : 0));
         Batch bs; bs.count = cnt; bs.sA = sM; bs.sB = sV; bs.sC = 0;
-        GPX_TRY(trsv_lower(g->dtype, Ab.p, n, lda, t0.p, t1.p, 0, st, &bs));
+        if (ride)      // rows n of the matrices (= L^-1 y) side by side as the backward solves' right-hand sides
+            GPX_HIP(hipMemcpy2DAsync(t1.p, vec, (char *)Ab.p + (size_t)n * lda * es, per, (size_t)n * es, (size_t)cnt,
+                                     hipMemcpyDeviceToDevice, st));
+        else
+            GPX_TRY(trsv_lower(g->dtype, Ab.p, n, lda, t0.p, t1.p, 0, st, &bs));
         GPX_TRY(trsv_lower(g->dtype, Ab.p, n, lda, t1.p, al.p, 1, st, &bs));
         GPX_TRY(logdet_chol(g->dtype, Ab.p, n, lda, (double *)sc.p, st, cnt, sM, 2));
         GPX_TRY(dot(g->dtype, g->y, al.p, n, (double *)sc.p + 1, st, cnt, 0, sV, 2));

@@ -972,21 +972,24 @@ static int reserve_cus_batch(int64_t n, int count)
 // factors panel k + 1 (whose block column was updated first).
 // bt != null: bt->count matrices sA elements apart are factored in lock-step (every launch covers all of
 // them; info_dev then holds one word per matrix).
-int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t st, const Batch *bt)
+int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t st, const Batch *bt, int64_t xrows)
 {
+    // xrows extra rows below the n x n matrix take part in every panel and update as rows, never as columns: on
+    // return row n + i holds L^-1 applied to what was stored there (a right-hand side rides along: gpx_gp_fit)
+    const int64_t N = n + xrows;
     GPX_HIP(hipMemsetAsync(info_dev, 0, sizeof(int) * (bt ? bt->count : 1), st));
     const int64_t nb = outer_block(n, bt != nullptr);
     const int64_t nblk = cdiv(n, nb);
     const size_t es = esize(dtype);
     static const bool no_la = getenv("GPX_POTRF_NO_LOOKAHEAD") != nullptr;
     g_leaf_pipe = false;
-    if (nblk <= 1) return potrf_panel(dtype, A, lda, n, 0, 0, n, info_dev, st, bt);
+    if (nblk <= 1) return potrf_panel(dtype, A, lda, N, 0, 0, n, info_dev, st, bt);
     auto at = [&](int64_t r, int64_t c) { return (char *)A + (r * lda + c) * es; };
     if (no_la) {
         for (int64_t k0 = 0; k0 < n; k0 += nb) {
             const int64_t kb = std::min(nb, n - k0), r = k0 + kb;
-            GPX_TRY(potrf_panel(dtype, A, lda, n, k0, k0, kb, info_dev, st, bt));
-            if (r < n) GPX_TRY(syrk_bc(dtype, n, r, A, lda, r, n, at(k0, k0), lda, k0, kb, nb, 1, 0, st, info_dev, bt));
+            GPX_TRY(potrf_panel(dtype, A, lda, N, k0, k0, kb, info_dev, st, bt));
+            if (r < n) GPX_TRY(syrk_bc(dtype, N, r, A, lda, r, n, at(k0, k0), lda, k0, kb, nb, 1, 0, st, info_dev, bt));
         }
         return GPX_OK;
     }
@@ -1023,7 +1026,7 @@ int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t
     static const bool taper = !(getenv("GPX_POTRF_TAPER") && atoi(getenv("GPX_POTRF_TAPER")) == 0) && !getenv("GPX_POTRF_NB");
     auto nominal = [&](int64_t k0) -> int64_t { return (taper && !bt) ? std::min(nb, outer_block(n - k0)) : nb; };
     int64_t k0 = 0, kb = std::min(nominal(0), n);
-    GPX_TRY(potrf_panel(dtype, A, lda, n, 0, 0, kb, info_dev, q, bt));
+    GPX_TRY(potrf_panel(dtype, A, lda, N, 0, 0, kb, info_dev, q, bt));
     GPX_TRY(g_la.get(&ep));
     GPX_HIP(hipEventRecord(ep, q));
     hipEvent_t e_rest = nullptr;                                // fires when the trailing update of the step before is done
@@ -1035,21 +1038,21 @@ int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t
         const int64_t w1 = nominal(r), kb1 = std::min(w1, n - r);
         // block column k + 1 first, so that its panel can start ... (small n: the panel kernel applies panel k to its
         // own columns itself -- it then only waits for the trailing update of step k - 1, not for this stream's turn)
-        const bool fold = panel_res_fold(n - r, kb, kb1, es, lda, A);
+        const bool fold = panel_res_fold(N - r, kb, kb1, es, lda, A);
         if (!fold) {
-            GPX_TRY(syrk_bc(dtype, n, r, A, lda, r, r + kb1, at(k0, k0), lda, k0, kb, w1, 1, 0, st, info_dev, bt));
+            GPX_TRY(syrk_bc(dtype, N, r, A, lda, r, r + kb1, at(k0, k0), lda, k0, kb, w1, 1, 0, st, info_dev, bt));
             GPX_TRY(g_la.get(&e));
             GPX_HIP(hipEventRecord(e, st));
             GPX_HIP(hipStreamWaitEvent(q, e, 0));
         } else if (e_rest) {
             GPX_HIP(hipStreamWaitEvent(q, e_rest, 0));
         }
-        GPX_TRY(potrf_panel(dtype, A, lda, n, r, r, kb1, info_dev, q, bt, fold ? kb : 0));
+        GPX_TRY(potrf_panel(dtype, A, lda, N, r, r, kb1, info_dev, q, bt, fold ? kb : 0));
         GPX_TRY(g_la.get(&ep));
         GPX_HIP(hipEventRecord(ep, q));
         // ... while the rest of the trailing matrix is updated underneath it
         if (r + kb1 < n)
-            GPX_TRY(syrk_bc(dtype, n, r, A, lda, r + kb1, n, at(k0, k0), lda, k0, kb, w1, 1, 0, st, info_dev, bt));
+            GPX_TRY(syrk_bc(dtype, N, r, A, lda, r + kb1, n, at(k0, k0), lda, k0, kb, w1, 1, 0, st, info_dev, bt));
         GPX_TRY(g_la.get(&e_rest));
         GPX_HIP(hipEventRecord(e_rest, st));
         k0 = r; kb = kb1;

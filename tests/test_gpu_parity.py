@@ -1216,3 +1216,32 @@ def test_resident_panel_interleaved_dtypes_and_batches(monkeypatch):
     np.testing.assert_allclose(mlii.log_lh_batch(X, y, thetas[:2], dtype="float32"), ref[:2], rtol=1e-4)
     np.testing.assert_allclose(single("float32", 0), ref[0], rtol=1e-4)
     np.testing.assert_allclose(mlii.log_lh_batch(X, y, thetas, dtype="float64"), ref, rtol=1e-10)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("N", [257, 1990, 4171])
+def test_right_hand_side_riding_along_vs_two_solves(monkeypatch, dtype, N):
+    """gpx_gp_fit / gpx_gp_fit_batch up to n = 16384: y is stored as row n of the matrix and takes part in every panel
+    and update of the factorisation (potrf with one extra row), which leaves L^-1 y there -- the forward solve -- so
+    only the backward solve runs.  Against the two-solve route (GPX_FIT_RIDE_MAX=0) and the oracle: alpha, log_lh, mean."""
+    from gaussian_processes_amd import mlii
+    d = 3
+    X, y, Xo = orc.synth_inputs(N, d, 16)
+    h, w, s = 1.0, 0.5 * np.sqrt(d), 0.9
+    o = orc.OracleGP("gaussian", (h, w), X, y, s)
+    out = {}
+    for label, env in (("ride", None), ("two_solves", "0")):
+        if env is None:
+            monkeypatch.delenv("GPX_FIT_RIDE_MAX", raising=False)
+        else:
+            monkeypatch.setenv("GPX_FIT_RIDE_MAX", env)
+        g = gp.GP(gp.GaussianKernel(h, w), X, y, s=s, dtype=dtype)
+        out[label] = (float(g.log_lh), np.array(g.inv_Kxx_y, dtype=np.float64), np.array(g.mean(Xo), dtype=np.float64),
+                      mlii.log_lh_batch(X, y, np.array([[h, w, s], [0.8, 1.1, 1.2]]), dtype=dtype))
+    tol = dict(rtol=1e-9, atol=1e-11) if dtype == "float64" else dict(rtol=2e-3, atol=2e-4)
+    for label, (llh, alpha, mean, batch) in out.items():
+        np.testing.assert_allclose(llh, o.log_lh, rtol=1e-10 if dtype == "float64" else 1e-4, err_msg=label)
+        np.testing.assert_allclose(alpha, o.inv_Kxx_y, err_msg=label, **tol)
+        np.testing.assert_allclose(mean, o.mean(Xo), err_msg=label, **tol)
+        np.testing.assert_allclose(batch[0], o.log_lh, rtol=1e-10 if dtype == "float64" else 1e-4, err_msg=label)
+    np.testing.assert_allclose(out["ride"][1], out["two_solves"][1], **tol)
