@@ -437,36 +437,47 @@ static unsigned long long *g_res_stamps = nullptr;             // diagnostic: th
 static int g_res_stamp_at = -1;
 
 // per host thread and device: the published blocks and flag words of every matrix of a batch
-struct ResScratch { void *p = nullptr; size_t bytes = 0; int device = -1; int nbatch = 0; int serial = 0; };
-static thread_local ResScratch g_res;
+struct ResScratch { void *p = nullptr; size_t bytes = 0; int nbatch = 0; int serial = 0; };
+constexpr int RES_MAXDEV = 16;
+static thread_local ResScratch g_res_dev[RES_MAXDEV];       // one per device: a thread that alternates between GPUs keeps both
 #define RES_TRACE(...) do { if (getenv("GPX_TRACE")) { fprintf(stderr, "[gpx] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
-static int res_scratch(int nbatch, size_t es, void **pub, int **flags)
+static int res_scratch(int nbatch, size_t es, void **pub, int **flags, ResScratch **out)
 {
     int dev = 0;
     GPX_HIP(hipGetDevice(&dev));
-    if (g_res.device != dev || g_res.nbatch < nbatch) {
-        RES_TRACE("res_scratch: grow %d -> %d matrices (device %d, old %p)", g_res.nbatch, nbatch, dev, g_res.p);
-        if (g_res.p && g_res.device == dev) { GPX_HIP(hipDeviceSynchronize()); (void)hipFree(g_res.p); }
-        g_res.p = nullptr; g_res.bytes = 0; g_res.device = dev; g_res.nbatch = 0;
+    if (dev < 0 || dev >= RES_MAXDEV) { set_error("resident panel: device index %d out of range", dev); return GPX_ERR_ARG; }
+    ResScratch &g = g_res_dev[dev];
+    if (g.nbatch < nbatch) {
+        RES_TRACE("res_scratch: grow %d -> %d matrices (device %d, old %p)", g.nbatch, nbatch, dev, g.p);
+        if (g.p) { GPX_HIP(hipDeviceSynchronize()); (void)hipFree(g.p); }
+        g.p = nullptr; g.bytes = 0; g.nbatch = 0;
         const size_t fbytes = ((size_t)nbatch * RES_FLAGS * sizeof(int) + 255) / 256 * 256;
         const size_t region = (size_t)nbatch * RES_SLOTS * IB * IB * 8;
         const size_t need = fbytes + region + region / 2;
-        RES_TRACE("res_scratch: old block released");
-        GPX_HIP(hipMalloc(&g_res.p, need));
-        GPX_HIP(hipMemset(g_res.p, 0, need));
+        GPX_HIP(hipMalloc(&g.p, need));
+        GPX_HIP(hipMemset(g.p, 0, need));
         GPX_HIP(hipDeviceSynchronize());
-        RES_TRACE("res_scratch: new block %p, %zu bytes, cleared", g_res.p, need);
-        g_res.bytes = need;
-        g_res.nbatch = nbatch;
-        g_res.serial = 0;
+        RES_TRACE("res_scratch: new block %p, %zu bytes, cleared", g.p, need);
+        g.bytes = need;
+        g.nbatch = nbatch;
+        g.serial = 0;
     }
     // the layout follows the CAPACITY, not this call's batch: a slot keeps its address and its role for the life of
     // the buffer (fp64 blocks first, the fp32 ones behind them) -- the tiles above a W block's diagonal are zero from
     // the initial clear and never rewritten
-    const size_t fbytes = ((size_t)g_res.nbatch * RES_FLAGS * sizeof(int) + 255) / 256 * 256;
-    const size_t region = (size_t)g_res.nbatch * RES_SLOTS * IB * IB * 8;
-    *flags = (int *)g_res.p;
-    *pub = (char *)g_res.p + fbytes + (es == 8 ? 0 : region);
+    const size_t fbytes = ((size_t)g.nbatch * RES_FLAGS * sizeof(int) + 255) / 256 * 256;
+    const size_t region = (size_t)g.nbatch * RES_SLOTS * IB * IB * 8;
+    if (g.serial >= (1 << 30)) {
+        // the flags hold the serial of the launch that raised them; long before the counter could wrap, start over
+        // (everything that used the block has to be done first)
+        GPX_HIP(hipDeviceSynchronize());
+        GPX_HIP(hipMemset(g.p, 0, fbytes));
+        GPX_HIP(hipDeviceSynchronize());
+        g.serial = 0;
+    }
+    *flags = (int *)g.p;
+    *pub = (char *)g.p + fbytes + (es == 8 ? 0 : region);
+    *out = &g;
     return GPX_OK;
 }
 
@@ -482,15 +493,16 @@ static int panel_res_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int
 {
     const int nbatch = bt ? bt->count : 1;
     void *pub = nullptr; int *flags = nullptr;
-    GPX_TRY(res_scratch(nbatch, sizeof(T), &pub, &flags));
+    ResScratch *scr = nullptr;
+    GPX_TRY(res_scratch(nbatch, sizeof(T), &pub, &flags, &scr));
     const int64_t rows = n - r0;
     dim3 grid((unsigned)cdiv(rows, IB), (unsigned)nbatch);
     const double kd = (double)kb;
     RES_TRACE("panel_res: n %lld r0 %lld kb %lld kpre %lld batch %d grid %u serial %d", (long long)n, (long long)r0, (long long)kb,
-              (long long)kpre, nbatch, grid.x, g_res.serial + 1);
+              (long long)kpre, nbatch, grid.x, scr->serial + 1);
     ProfScope prof(PC_POTRF_DIAG, (kd * kd * kd / 3.0 + (double)(rows - kb) * kd * kd + 2.0 * (double)rows * kd * (double)kpre) * nbatch, st);
     hipLaunchKernelGGL((panel_res_kernel<T>), grid, dim3(256), 0, st, A, lda, n, r0, c0, (int)(kb / IB), info_dev, (T *)pub,
-                       flags, ++g_res.serial, bt ? bt->sA : (int64_t)0, (int)(kpre / IB),
+                       flags, ++scr->serial, bt ? bt->sA : (int64_t)0, (int)(kpre / IB),
                        (g_res_stamps && g_res_stamp_at-- == 0) ? g_res_stamps : (unsigned long long *)nullptr);
     GPX_LAUNCH_CHECK();
     return GPX_OK;
