@@ -570,6 +570,7 @@ def bench_distributed(args, X, y, Xo, params, s, dtype_id, residual_check=None):
     a torch.distributed gloo group (rendezvous, barriers, the ncclUniqueId, the max-over-ranks clock); data
     plane: libgpx's C schedule with RCCL collectives.  GPX_DIST_BACKEND=gloo swaps the data-plane
     collectives for host callbacks over the same gloo group (rehearsal with several ranks on one GPU)."""
+    import sys
     import torch
     import torch.distributed as dist
     rank = int(os.environ["RANK"])
@@ -582,6 +583,29 @@ def bench_distributed(args, X, y, Xo, params, s, dtype_id, residual_check=None):
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     lib = _lib.load()
     backend = "callbacks" if os.environ.get("GPX_DIST_BACKEND", "nccl") == "gloo" else "rccl"
+    fallback_note = None
+    if backend == "rccl":
+        # pre-flight, so that a rank without a usable RCCL does not leave the others waiting inside
+        # ncclCommInitRank: every rank checks locally that its GPU is there and that librccl loads (an
+        # ncclUniqueId can be made), the verdict is agreed on over the gloo group, and if any rank says no,
+        # ALL ranks take the host-callback data plane (slower, same schedule, same result)
+        ok, why = 1, ""
+        try:
+            _lib.check(lib.gpx_set_device(int(local_rank)))
+            probe = np.zeros(_lib.MG_ID_BYTES, dtype=np.uint8)
+            _lib.check(lib.gpx_mg_unique_id(probe.ctypes.data_as(ctypes.c_void_p)))
+        except Exception as exc:                          # noqa: BLE001 -- any failure means "not usable here"
+            ok, why = 0, "%s: %s" % (type(exc).__name__, exc)
+        verdict = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(verdict, op=dist.ReduceOp.MIN)
+        if int(verdict.item()) == 0:
+            reasons = [None] * world
+            dist.all_gather_object(reasons, why)
+            fallback_note = "RCCL data plane unavailable (%s): host callbacks over gloo instead" % "; ".join(
+                "rank %d: %s" % (i, r) for i, r in enumerate(reasons) if r)
+            if rank == 0:
+                sys.stderr.write("bench: " + fallback_note + "\n")
+            backend = "callbacks"
     N, d, m = args.n, args.d, args.m
     # RCCL prints a version banner on stdout when its communicator is created; keep stdout clean for the
     # single JSON line (stderr still shows everything)
@@ -647,6 +671,7 @@ def bench_distributed(args, X, y, Xo, params, s, dtype_id, residual_check=None):
                                       % (gp.nb, world, "RCCL" if backend == "rccl" else "host-callback (gloo)")},
             "log_lh": llh,
             "check": check,
+            "data_plane_fallback": fallback_note,
             "whole_step_tflops_n3_over_3": round(tfl, 3),
             "whole_step_frac_of_peak_all_gpus": round(tfl / (peak * world), 4),
             # where each rank's step went (ms per step, HIP events on its own streams): the stages, and inside
