@@ -575,6 +575,8 @@ static int64_t outer_block(int64_t n, bool batched = false)
     }
     // lock-step batches: the chain is shared by all matrices, so the deeper K = 512 tiles of the trailing update
     // win (64 x n = 8192: 0.238 -> 0.214 s; 8 x: 0.290 -> 0.272 s)
+    // (with the one-launch panels: 1024 for n >= 8192 -- 64 x n = 8192: 0.217 -> 0.213 s, 16 x: 0.253 -> 0.240 s)
+    if (batched && n >= 8192 && n <= 32768) return 1024;
     if (batched && n >= 4096 && n <= 32768) return 512;
     // measured per factorisation (v8): n = 8192: 128 / 256 / 512 -> 12.6 / 11.5 / 12.5 ms; n = 16384:
     // 256 / 512 -> 42.4 / 40.8; n = 24576: 256 / 512 / 1024 -> 106 / 98 / 102; n = 32768: 228 / 203 / 204;
