@@ -8,9 +8,12 @@
 //   workgroup w owns rows r0 + 64 w .. + 64 of the panel; wave v of it keeps its 16 rows x kb columns as MFMA
 //   accumulator tiles (kb = 256 fp64: 64 doubles a lane), loaded once and stored once.
 //   Step j (64 columns, right-looking inside the panel):
-//     workgroup j   (the diagonal block, fully updated by the steps before) passes the block through LDS into
-//                   the leaf's thread-tile layout, factors it and forms W = inv(L_jj) (factor64, gpx_leaf.h),
-//                   stores L_jj, publishes W and raises flag W_j; it is done.
+//     workgroup j   (the diagonal block, fully updated by the steps before) factors it and forms W = inv(L_jj)
+//                   -- fp64: in place in the accumulator tiles, on the MFMA pipe (factor64_mfma, gpx_leaf.h);
+//                   fp32: through LDS into the VALU leaf's thread-tile layout (factor64_pipe) --, stores L_jj,
+//                   publishes W and raises flag W_j; it is done.
+//     before step 0 the launch applies the kpre columns immediately to its left (left-looking pre-update): what
+//                   used to be one more dependent GEMM launch in front of every panel.
 //     workgroup w>j waits for W_j (one lane polls, bounded), stages W through LDS, X = P_j W^T on the MFMA pipe
 //                   (its rows of column block j: final, stored), keeps X in LDS as an operand and updates its
 //                   blocks c > j:  P_c -= X X_c^T, where X_c -- the same step's rows of the diagonal block c --
@@ -37,7 +40,7 @@ namespace gpx {
 constexpr int RES_MAXSTEPS = 4;                   // panels of up to 256 columns
 constexpr int RES_SLOTS = 10;                     // W_0..3, X_10, X_20, X_21, X_30, X_31, X_32
 constexpr int RES_FLAGS = 16;                     // flag words per matrix (10 used)
-constexpr int RES_SPIN = 1 << 22;                 // polls (~0.1 us each): gives up after ~0.5 s
+constexpr int RES_SPIN = 1 << 22;                 // polls (~1 us each with the sleep): gives up after a few seconds
 
 __device__ __forceinline__ int res_xslot(int c, int j) { return 4 + c * (c - 1) / 2 + j; }
 
