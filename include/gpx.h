@@ -323,9 +323,13 @@ int gpx_gp_load(gpx_gp_t **gp, const char *path);
 int gpx_gp_describe(gpx_gp_t *gp, int *dtype, int *kernel, int64_t *n, int *d, double *params3, double *s);
 int gpx_gp_get_xy(gpx_gp_t *gp, double *x, double *y);
 /* timing of the last fit, milliseconds per stage (HIP events on the handle's
- * stream): [0] kernel build [1] potrf [2] solve [3] logdet+dot [4] total */
+ * stream): [0] kernel build [1] potrf [2] solve [3] logdet+dot [4] total.
+ * Up to n = 16384 the forward substitution L t = y is done inside [1] (y is carried
+ * as one more row of the matrix through the factorisation) and [2] is the backward
+ * solve alone. */
 int gpx_gp_last_timing(gpx_gp_t *gp, float *ms5);
-/* raw device views for tests / multi-GPU drivers (do not free) */
+/* raw device views for tests / multi-GPU drivers (do not free); A has n + 1 rows of lda
+ * elements (row n is the handle's work row, see gpx_gp_last_timing) */
 int gpx_gp_device_ptrs(gpx_gp_t *gp, void **A, int64_t *lda, void **x, void **y,
                        void **alpha, void **stream);
 
