@@ -15,7 +15,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgpx.so")
 
 OK = 0
-ERR_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_NOMEM, ERR_UNSUPPORTED = -1, -2, -3, -4, -5
+ERR_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_NOMEM, ERR_UNSUPPORTED, ERR_INTERNAL = -1, -2, -3, -4, -5, -6
+(ROUTE_TRSV_OPS, ROUTE_TRSV_STEPS, ROUTE_PANEL_RES, ROUTE_PANEL_CHAIN, ROUTE_FIT_RIDE, ROUTE_FIT_TWO_SOLVES,
+ ROUTE_GEMM_FAST, ROUTE_GEMM_GENERIC, ROUTE_SYRK_EXACT, ROUTE_SYRK_PATCH, ROUTE_MG_BCAST_ONE, ROUTE_MG_BCAST_SAG) = range(12)
 F64, F32 = 0, 1
 KERNEL_GAUSSIAN, KERNEL_PERIODIC = 0, 1
 FULL, LOWER = 0, 1
@@ -118,6 +120,14 @@ _SIGNATURES = {
     "gpx_gp_last_timing": (c_int, [c_void_p, POINTER(c_float)]),
     "gpx_gp_device_ptrs": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int64), POINTER(c_void_p),
                                    POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p)]),
+    "gpx_debug_route_count": (c_int, [c_int, POINTER(c_int64)]),
+    "gpx_debug_route_reset": (c_int, []),
+    "gpx_debug_mg_inject_info": (c_int, [c_void_p, c_int]),
+    "gpx_mg_probe": (c_int, []),
+    "gpx_mg_create_local": (c_int, [POINTER(c_void_p), c_int, c_int, c_int64, c_int, c_int64, c_int, c_int]),
+    "gpx_mg_connect": (c_int, [c_void_p, c_void_p]),
+    "gpx_mg_comm_info": (c_int, [c_void_p, c_int_p, c_int_p, c_int_p, c_int_p]),
+    "gpx_mg_set_bcast": (c_int, [c_void_p, c_int]),
     "gpx_mg_unique_id": (c_int, [c_void_p]),
     "gpx_mg_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_int64, c_int, c_int64, c_int, c_int, c_void_p]),
     "gpx_mg_create_cb": (c_int, [POINTER(c_void_p), c_int, c_int, c_int64, c_int, c_int64, c_int, c_int,
@@ -218,7 +228,21 @@ def device_info(device=0):
             "hbm_bytes": mem.value}
 
 
+def route_count(route):
+    """How often host-side route `route` (ROUTE_*) was taken since the last `route_reset()`."""
+    v = c_int64(0)
+    check(load().gpx_debug_route_count(int(route), ctypes.byref(v)))
+    return v.value
+
+
+def route_reset():
+    check(load().gpx_debug_route_reset())
+
+
 def lapack_info_error(info):
-    """The LinAlgError scipy.linalg.cholesky raises for a LAPACK info > 0."""
+    """The LinAlgError scipy.linalg.cholesky raises for a LAPACK info > 0.  (A host-side info is never
+    negative: an internal failure of the factorisation arrives as the status GPX_ERR_INTERNAL -> GpxError.)"""
+    if info < 0:
+        raise GpxError("internal failure inside the factorisation (info = %d)" % info)
     return np.linalg.LinAlgError(
         "%d-th leading minor of the array is not positive definite" % info)

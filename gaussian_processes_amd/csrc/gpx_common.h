@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <math.h>
 
@@ -36,6 +37,28 @@ int  ensure_device();   // GPX_OK when a GPU is usable
         hipError_t e__ = hipGetLastError();                                  \
         if (e__ != hipSuccess) return gpx::hip_fail(e__, "kernel launch", __FILE__, __LINE__); \
     } while (0)
+
+// Environment switches: ONE convention -- every switch is read at the point of use, per call, so
+// that a test (or a tuning script) that sets a variable always gets the route it asked for.  A getenv is a scan of
+// the environment block (~0.1 us); the launch paths read a handful per kernel launch.
+static inline bool env_set(const char *name) { const char *e = getenv(name); return e != nullptr && *e != 0; }
+static inline int64_t env_i64(const char *name, int64_t dflt)
+{
+    const char *e = getenv(name);
+    return (e && *e) ? (int64_t)atoll(e) : dflt;
+}
+
+// Route counters (gpx_debug_route_count): which of the alternative routes a call took, counted on the host at the
+// point of decision.  Tests that force a route through an environment switch assert it here.
+enum Route { RT_TRSV_OPS = 0, RT_TRSV_STEPS = 1, RT_PANEL_RES = 2, RT_PANEL_CHAIN = 3, RT_FIT_RIDE = 4,
+             RT_FIT_TWO_SOLVES = 5, RT_GEMM_FAST = 6, RT_GEMM_GENERIC = 7, RT_SYRK_EXACT = 8, RT_SYRK_PATCH = 9,
+             RT_MG_BCAST_ONE = 10, RT_MG_BCAST_SAG = 11, RT_COUNT = 16 };
+void route_hit(int route);
+
+// LAPACK-style info of a factorisation as the host sees it: > 0 "not positive definite" (the caller's business),
+// < 0 an INTERNAL failure of the factorisation (a hand-off inside the resident panel kernel timed out: -7) --
+// never to be mistaken for a property of the matrix.  Returns GPX_ERR_INTERNAL for the latter.
+int check_internal_info(int info);
 
 static inline hipStream_t S(void *s) { return (hipStream_t)s; }
 static inline size_t esize(int dtype) { return dtype == GPX_F64 ? 8 : 4; }
@@ -112,6 +135,9 @@ int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t
 int potrf_panel_res(int dtype, void *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int64_t kb, int *info_dev,
                     hipStream_t st, const Batch *bt = nullptr, int64_t kpre = 0);
 int64_t panel_res_max();
+// this host thread's look-ahead stream of the blocked factorisation on the current device (nullptr before the first
+// one): it lives as long as the thread, so an event may be recorded on it at any time
+hipStream_t potrf_side_stream();
 bool panel_res_fold(int64_t rows, int64_t kpre, int64_t kb, size_t es, int64_t lda, const void *base);
 // Per-factor block operators of the single-right-hand-side solves (gpx_solve.hip, "operator form"): owned by
 // whoever owns the factor; `valid` must be cleared whenever the factor changes.  nullptr: built per call.

@@ -273,6 +273,8 @@ static int read_info(gpx_gp *g, int *info, double *logdet, double *yta)
     GPX_HIP(hipMemcpyAsync(h4, g->scal, sizeof(h4), hipMemcpyDeviceToHost, g->st));
     GPX_HIP(hipStreamSynchronize(g->st));
     memcpy(info, &h4[3], sizeof(int));
+    GPX_TRY(check_internal_info(*info));
+    if (!g->y_finite) { set_error("array must not contain infs or NaNs (y)"); return GPX_ERR_ARG; }   // gp/gp.py:332-334
     *logdet = h4[0]; *yta = h4[1];
     return GPX_OK;
 }

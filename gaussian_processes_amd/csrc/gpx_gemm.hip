@@ -839,7 +839,7 @@ static int launch_gemm_nt_fast(int64_t M, int64_t N, int64_t K, const void *A, i
     fm.ktri = (ktri == 1 && M == N && N == K) ? 1 : ((ktri == 2 && N == K) ? 2 : 0);
     int64_t dblocks = 0;
     {
-        static const bool no_split = getenv("GPX_GEMM_NO_DSPLIT") != nullptr;
+        const bool no_split = env_set("GPX_GEMM_NO_DSPLIT");
         if (!no_split && !fm.exact && BM == 128 && BN == 128 && tri == GPX_LOWER && fm.a == 1 && fm.csh == 3 && fm.pm1nb == 0 &&
             col0 - row0 == (int64_t)fm.b * 1024 && fm.np > 0) {
             const int64_t pbc = cdiv(N, 1024);
@@ -860,16 +860,14 @@ static int launch_gemm_nt_fast(int64_t M, int64_t N, int64_t K, const void *A, i
     if (BM == 128 && fm.exact) { if (fm.eT <= 0) return GPX_OK; }
     else if (np <= 0 && dblocks == 0) return GPX_OK;
     {
-        static const bool no_vec = getenv("GPX_GEMM_NO_VEC_C") != nullptr;
+        const bool no_vec = env_set("GPX_GEMM_NO_VEC_C");
         fm.vec_c = (!no_vec && ldc % 2 == 0 && N % 2 == 0 && N >= 2 && ((uintptr_t)C) % (2 * sizeof(T)) == 0) ? 1 : 0;
         // default on: measured epilogue 20 k -> 11.7 k cycles per tile, whole fit 1.59 -> 1.54 s
-        static const int atomic_c = getenv("GPX_GEMM_ATOMIC_C") ? atoi(getenv("GPX_GEMM_ATOMIC_C")) : 1;
-        fm.atomic_c = atomic_c;
+        fm.atomic_c = (int)env_i64("GPX_GEMM_ATOMIC_C", 1);
     }
     {
         fm.stamps = g_gemm_stamps;
-        static const int abl = getenv("GPX_GEMM_ABLATE") ? atoi(getenv("GPX_GEMM_ABLATE")) : 0;
-        fm.ablate = abl;
+        fm.ablate = (int)env_i64("GPX_GEMM_ABLATE", 0);      // timing-only ablations: wrong results on purpose
     }
     const int64_t ablocks = (cdiv(np, 8) * 8 * (1024 / BM)) << fm.csh;
     if (dblocks) fm.dbegin = (int)ablocks;
@@ -888,8 +886,7 @@ static int launch_gemm_nt_fast(int64_t M, int64_t N, int64_t K, const void *A, i
 // 1.466 -> 1.435 s; n = 32768 f32: 131 -> 128.5 ms; n = 8192: 19.2 -> 18.1 ms.
 static int fast_bm()
 {
-    static const int bm = getenv("GPX_GEMM_BM") ? atoi(getenv("GPX_GEMM_BM")) : 128;
-    return bm == 256 ? 256 : 128;
+    return env_i64("GPX_GEMM_BM", 128) == 256 ? 256 : 128;
 }
 
 int gemm_nt(int dtype, int64_t M, int64_t N, int64_t K, const void *A, int64_t lda, const void *B,
@@ -897,10 +894,11 @@ int gemm_nt(int dtype, int64_t M, int64_t N, int64_t K, const void *A, int64_t l
             hipStream_t st, int beta0, int ktri, const Batch *bt)
 {
     if (M <= 0 || N <= 0 || K <= 0) return GPX_OK;
-    static const bool no_fast = getenv("GPX_GEMM_NO_FAST") != nullptr;
+    const bool no_fast = env_set("GPX_GEMM_NO_FAST");
     const int64_t epk = 128 / (int64_t)esize(dtype), ch = 16 / (int64_t)esize(dtype);
     const bool fast = !no_fast && K % epk == 0 && lda % ch == 0 && ldb % ch == 0 &&
                       ((uintptr_t)A) % 16 == 0 && ((uintptr_t)B) % 16 == 0;
+    route_hit(fast ? RT_GEMM_FAST : RT_GEMM_GENERIC);
     if (fast) {
         if (N <= 64 && fast_bm() == 128) {
             if (dtype == GPX_F64)
@@ -967,7 +965,7 @@ int syrk_bc(int dtype, int64_t n, int64_t row_begin, void *Cloc, int64_t ldc, in
     }
     const double work = 2.0 * (double)kb * elems;
     const bool fast = kb % epk == 0 && ldp % ch == 0 && ((uintptr_t)Pb) % 16 == 0 && cl0 % 128 == 0 &&
-                      nb % 128 == 0 && (1024 % nb == 0) && getenv("GPX_GEMM_NO_FAST") == nullptr;
+                      nb % 128 == 0 && (1024 % nb == 0) && !env_set("GPX_GEMM_NO_FAST");
     char *C = (char *)Cloc + (row_begin * ldc + cl0) * es;
     const char *A = (const char *)Pb + (row_begin - k0) * ldp * es;
     if (fast) {
@@ -993,7 +991,7 @@ int syrk_bc(int dtype, int64_t n, int64_t row_begin, void *Cloc, int64_t ldc, in
         fm.exact = 0;
         {
             // single rank, triangle aligned to the 128 x 128 tiles: enumerate exactly the tiles that exist
-            static const int exact_env = getenv("GPX_GEMM_EXACT") ? atoi(getenv("GPX_GEMM_EXACT")) : 1;
+            const int64_t exact_env = env_i64("GPX_GEMM_EXACT", 1);
             const int64_t off = row_begin - G0;                       // row origin minus column origin (global)
             if (exact_env && fast_bm() == 128 && off % 128 == 0 && cdiv(M, 1024) <= 64 && cl0 % nb == 0) {
                 const int TR = (int)cdiv(M, 128), TC = (int)cdiv(Ncols, 128), D = (int)(off / 128);
@@ -1025,6 +1023,7 @@ int syrk_bc(int dtype, int64_t n, int64_t row_begin, void *Cloc, int64_t ldc, in
                 if (total <= 0) return GPX_OK;
             }
         }
+        route_hit(fm.exact ? RT_SYRK_EXACT : RT_SYRK_PATCH);
         if (fast_bm() == 128) {
             if (dtype == GPX_F64)
                 return launch_gemm_nt_fast<double, 128, 1, 128>(M, Ncols, kb, A, ldp, Pb, ldp, C, ldc, -1.0, GPX_LOWER,

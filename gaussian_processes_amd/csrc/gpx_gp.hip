@@ -98,6 +98,67 @@ int kmat(int dtype, int kernel, int member, const void *x1, int64_t n, const voi
 
 static int nparams_of(int kernel) { return kernel == GPX_KERNEL_PERIODIC ? 3 : 2; }
 
+int check_internal_info(int info)
+{
+    if (info >= 0) return GPX_OK;
+    set_error("internal failure inside the factorisation (info = %d: a hand-off between workgroups of the resident "
+              "panel kernel timed out); the factor is not valid -- this is NOT a statement about the matrix", info);
+    return GPX_ERR_INTERNAL;
+}
+
+// flag[0] |= 1 when v holds a NaN or an infinity (scipy's asarray_chkfinite on the device, O(n))
+template <typename T>
+__global__ void nonfinite_kernel(const T *__restrict__ v, int64_t n, int *__restrict__ flag)
+{
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        bad = bad || !isfinite(v[i]);
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+// x_finite / y_finite of the handle from its device arrays (synchronous)
+int gp_scan_finite(gpx_gp *g)
+{
+    int *flags = (int *)(g->scal + 2);                    // two spare words of the scalar block
+    GPX_HIP(hipMemsetAsync(flags, 0, 2 * sizeof(int), g->st));
+    const int64_t nx = g->n * g->d, ny = g->n;
+    const unsigned bx = (unsigned)std::min<int64_t>(cdiv(nx, 256), 1024), by = (unsigned)std::min<int64_t>(cdiv(ny, 256), 1024);
+    if (g->dtype == GPX_F64) {
+        hipLaunchKernelGGL((nonfinite_kernel<double>), dim3(bx), dim3(256), 0, g->st, (const double *)g->x, nx, flags);
+        hipLaunchKernelGGL((nonfinite_kernel<double>), dim3(by), dim3(256), 0, g->st, (const double *)g->y, ny, flags + 1);
+    } else {
+        hipLaunchKernelGGL((nonfinite_kernel<float>), dim3(bx), dim3(256), 0, g->st, (const float *)g->x, nx, flags);
+        hipLaunchKernelGGL((nonfinite_kernel<float>), dim3(by), dim3(256), 0, g->st, (const float *)g->y, ny, flags + 1);
+    }
+    GPX_LAUNCH_CHECK();
+    int h[2] = {0, 0};
+    GPX_HIP(hipMemcpyAsync(h, flags, sizeof(h), hipMemcpyDeviceToHost, g->st));
+    GPX_HIP(hipStreamSynchronize(g->st));
+    g->x_finite = h[0] == 0; g->y_finite = h[1] == 0;
+    return GPX_OK;
+}
+
+// Would K(x, x) + s^2 I hold only finite numbers for finite x?  The kernel's value at r = 0 and at r = 1 in the
+// host's double arithmetic: a NaN or infinite parameter (the reference's setters let both through:
+// gp/kernels/gaussian.py:62-69 only reject values < EPS, gp/gp.py:192-193 only s < 0) shows up there.
+static bool kernel_values_finite(int kernel, const double *p, double s)
+{
+    double k0, k1;
+    if (kernel == GPX_KERNEL_GAUSSIAN) {
+        const double c1 = -0.5 / (p[1] * p[1]), c2 = 0.5 * sqrt(2.0 / M_PI) * p[0] * p[0] / p[1];   // gaussian_c.pyx:27-28
+        k0 = c2; k1 = c2 * exp(c1);
+    } else {
+        const double sn = sin(0.5 / p[2]);                                                            // periodic_c.pyx:27-29
+        k0 = p[0] * p[0]; k1 = p[0] * p[0] * exp(-2.0 * sn * sn / (p[1] * p[1]));
+    }
+    return std::isfinite(k0 + s * s) && std::isfinite(k1);
+}
+
+static const char *NONFINITE_MSG = "array must not contain infs or NaNs";      // scipy's text (gp/gp.py:294, 332-334)
+
+#define GP_NEED_FINITE_Y(g)                                                    \
+    do { if (!(g)->y_finite) { set_error("%s (y)", NONFINITE_MSG); return GPX_ERR_ARG; } } while (0)
+
 }  // namespace gpx
 
 using namespace gpx;
@@ -168,7 +229,7 @@ int gpx_gp_set_data(gpx_gp_t *g, const double *x, const double *y)
     GPX_TRY(upload_f64(g->dtype, g->x, x, g->n * g->d, g->st));
     GPX_TRY(upload_f64(g->dtype, g->y, y, g->n, g->st));
     g->have_data = true; g->fitted = false;
-    return GPX_OK;
+    return gp_scan_finite(g);
 }
 
 int gpx_gp_set_data_device(gpx_gp_t *g, const void *x_dev, const void *y_dev)
@@ -180,14 +241,14 @@ int gpx_gp_set_data_device(gpx_gp_t *g, const void *x_dev, const void *y_dev)
     GPX_HIP(hipMemcpyAsync(g->y, y_dev, (size_t)g->n * es, hipMemcpyDeviceToDevice, g->st));
     GPX_HIP(hipStreamSynchronize(g->st));      // the caller may free or overwrite the sources on return
     g->have_data = true; g->fitted = false;
-    return GPX_OK;
+    return gp_scan_finite(g);
 }
 
 int gpx_gp_set_params(gpx_gp_t *g, const double *params, double s)
 {
     GP_ENTER(g);
     GPX_ARG(g && params, "NULL argument");
-    GPX_ARG(s >= 0, "invalid value for s");                    // gp/gp.py:192-193
+    GPX_ARG(!(s < 0), "invalid value for s");                  // gp/gp.py:192-193 (`val < 0`: a NaN passes, as in the reference; gpx_gp_fit then rejects it as non-finite)
     for (int i = 0; i < g->nparams; ++i) g->params[i] = params[i];
     g->s = s;
     g->have_params = true; g->fitted = false; g->have_K = false;
@@ -224,6 +285,12 @@ int gpx_gp_fit(gpx_gp_t *g, int *info)
     GPX_ARG(g, "gp is NULL");
     GPX_ARG(g->have_data && (g->have_params || g->have_K),
             "set_data and set_params (or set_K) must be called before fit");
+    // scipy.linalg.cholesky(Kxx, check_finite=True), gp/gp.py:294: a kernel matrix with NaN / inf entries is a
+    // ValueError, not "not positive definite".  K is finite iff x, the kernel's constants and s^2 are.
+    if (!g->have_K && (!g->x_finite || !kernel_values_finite(g->kernel, g->params, g->s))) {
+        set_error("%s (%s)", NONFINITE_MSG, g->x_finite ? "kernel parameters or s" : "x");
+        return GPX_ERR_ARG;
+    }
     const size_t es = esize(g->dtype);
     int *info_dev = (int *)(g->scal + 3);
     hipStream_t st = g->st;
@@ -238,8 +305,9 @@ int gpx_gp_fit(gpx_gp_t *g, int *info)
     // Small and mid sizes: y rides along as row n of the matrix -- every panel substitutes it, every update reduces it,
     // exactly what the forward solve L t = y would do afterwards -- so only the backward solve is left (n = 8192: the
     // two solves were 1.0 ms of an 8 ms fit).  At large n the extra row of tiles in every update costs what it saves.
-    const int64_t ride_max = getenv("GPX_FIT_RIDE_MAX") ? atoll(getenv("GPX_FIT_RIDE_MAX")) : 16384;   // (read per call: tests switch it)
+    const int64_t ride_max = env_i64("GPX_FIT_RIDE_MAX", 16384);
     const bool ride = g->n <= ride_max;
+    route_hit(ride ? RT_FIT_RIDE : RT_FIT_TWO_SOLVES);
     char *row_n = (char *)g->A + (size_t)g->n * g->lda * es;
     if (ride) GPX_HIP(hipMemcpyAsync(row_n, g->y, (size_t)g->n * es, hipMemcpyDeviceToDevice, st));
     GPX_TRY(potrf(g->dtype, g->A, g->n, g->lda, info_dev, st, nullptr, ride ? 1 : 0));
@@ -262,6 +330,7 @@ int gpx_gp_fit(gpx_gp_t *g, int *info)
     if (info) {
         GPX_HIP(hipMemcpyAsync(info, info_dev, sizeof(int), hipMemcpyDeviceToHost, st));
         GPX_HIP(hipStreamSynchronize(st));
+        GPX_TRY(check_internal_info(*info));
     }
     return GPX_OK;
 }
@@ -273,15 +342,20 @@ static int gp_scalars(gpx_gp_t *g, double *logdet, double *yta, int *info)
     double h[4];
     GPX_HIP(hipMemcpyAsync(h, g->scal, sizeof(h), hipMemcpyDeviceToHost, g->st));
     GPX_HIP(hipStreamSynchronize(g->st));
+    int inf;
+    memcpy(&inf, &h[3], sizeof(int));
+    GPX_TRY(check_internal_info(inf));
     if (logdet) *logdet = h[0];
     if (yta) *yta = h[1];
-    if (info) memcpy(info, &h[3], sizeof(int));
+    if (info) *info = inf;
     return GPX_OK;
 }
 
 int gpx_gp_log_lh(gpx_gp_t *g, double *log_lh)
 {
     GPX_ARG(log_lh, "log_lh is NULL");
+    GPX_ARG(g, "gp is NULL");
+    GP_NEED_FINITE_Y(g);                                  // cho_solve(..., check_finite=True), gp/gp.py:332-334
     double logdet, yta; int info;
     GPX_TRY(gp_scalars(g, &logdet, &yta, &info));
     // gp/gp.py:362-365 (LinAlgError -> -inf) and gp_c.pyx:22-29 (sign / MIN clamp)
@@ -309,6 +383,7 @@ int gpx_gp_mean(gpx_gp_t *g, const double *xo, int64_t m, double *out)
 {
     GP_ENTER(g);
     GPX_ARG(g && g->fitted, "gp is not fitted");
+    GP_NEED_FINITE_Y(g);
     GPX_ARG(m >= 0 && (m == 0 || (xo && out)), "bad arguments");
     if (m == 0) return GPX_OK;
     const size_t es = esize(g->dtype);
@@ -348,6 +423,7 @@ int gpx_gp_mean_from_K(gpx_gp_t *g, const double *Kxox, int64_t m, double *out)
 {
     GP_ENTER(g);
     GPX_ARG(g && g->fitted, "gp is not fitted");
+    GP_NEED_FINITE_Y(g);
     GPX_ARG(m >= 0 && (m == 0 || (Kxox && out)), "bad arguments");
     if (m == 0) return GPX_OK;
     const size_t es = esize(g->dtype);
@@ -417,6 +493,7 @@ int gpx_gp_get_alpha(gpx_gp_t *g, double *out)
 {
     GP_ENTER(g);
     GPX_ARG(g && g->fitted && out, "bad arguments");
+    GP_NEED_FINITE_Y(g);                                  // cho_solve(..., check_finite=True), gp/gp.py:332-334
     return download_f64(g->dtype, out, 1, g->alpha, 1, g->n, 1, 0, g->st);
 }
 
@@ -448,6 +525,7 @@ int gpx_gp_dloglh_dtheta(gpx_gp_t *g, double *out)
 {
     GP_ENTER(g);
     GPX_ARG(g && g->fitted && out, "bad arguments");
+    GP_NEED_FINITE_Y(g);
     const size_t es = esize(g->dtype);
     const int64_t n = g->n, lda = g->lda;
     double h4[4];
@@ -455,6 +533,7 @@ int gpx_gp_dloglh_dtheta(gpx_gp_t *g, double *out)
     GPX_HIP(hipStreamSynchronize(g->st));
     int info;
     memcpy(&info, &h4[3], sizeof(int));
+    GPX_TRY(check_internal_info(info));
     if (info != 0) {                                   // gp/gp.py:424-428: NaN when K is not PD
         for (int i = 0; i <= g->nparams; ++i) out[i] = NAN;
         return GPX_OK;
@@ -495,16 +574,17 @@ int gpx_gp_fit_batch(gpx_gp_t *g, const double *thetas, int64_t B, double *log_l
     GPX_ARG(g->have_data, "set_data must be called before fit_batch");
     GPX_ARG(B >= 0 && (B == 0 || (thetas && log_lh)), "bad arguments");
     if (B == 0) return GPX_OK;
+    if (!g->x_finite || !g->y_finite) { set_error("%s (%s)", NONFINITE_MSG, g->x_finite ? "y" : "x"); return GPX_ERR_ARG; }
     const int64_t n = g->n, lda = g->lda;
     const size_t es = esize(g->dtype);
     const int np = g->nparams;
-    const int64_t ride_max = getenv("GPX_FIT_RIDE_MAX") ? atoll(getenv("GPX_FIT_RIDE_MAX")) : 16384;   // (read per call: tests switch it)
+    const int64_t ride_max = env_i64("GPX_FIT_RIDE_MAX", 16384);
     const bool ride = n <= ride_max;                      // y rides along as row n of every matrix (see gpx_gp_fit)
     const size_t per = (size_t)(n + (ride ? 1 : 0)) * lda * es;
     size_t freeb = 0, totalb = 0;
     GPX_HIP(hipMemGetInfo(&freeb, &totalb));
     int64_t Bc = (int64_t)((double)freeb * 0.85 / (double)(per + 4 * (size_t)n * es + 64));
-    if (const char *env = getenv("GPX_BATCH_MAX")) Bc = std::min<int64_t>(Bc, std::max<int64_t>(1, atoll(env)));
+    if (env_set("GPX_BATCH_MAX")) Bc = std::min<int64_t>(Bc, std::max<int64_t>(1, env_i64("GPX_BATCH_MAX", 1)));
     Bc = std::max<int64_t>(1, std::min<int64_t>(Bc, B));
     if (!g->bw && (double)per > (double)freeb * 0.85) { set_error("fit_batch: not even one more n x n matrix fits in HBM"); return GPX_ERR_NOMEM; }
     // one block, kept in the handle between calls (an ML-II loop calls this once per sweep; a fresh
@@ -561,9 +641,8 @@ int gpx_gp_fit_batch(gpx_gp_t *g, const double *thetas, int64_t B, double *log_l
         GPX_TRY(dot(g->dtype, g->y, al.p, n, (double *)sc.p + 1, st, cnt, 0, sV, 2));
         GPX_HIP(hipMemcpyAsync(hs.data(), sc.p, (size_t)cnt * 2 * sizeof(double), hipMemcpyDeviceToHost, st));
         GPX_HIP(hipMemcpyAsync(hi.data(), inf.p, (size_t)cnt * sizeof(int), hipMemcpyDeviceToHost, st));
-        if (getenv("GPX_TRACE")) { fprintf(stderr, "[gpx] fit_batch: chunk of %d enqueued, waiting\n", cnt); fflush(stderr); }
         GPX_HIP(hipStreamSynchronize(st));
-        if (getenv("GPX_TRACE")) { fprintf(stderr, "[gpx] fit_batch: chunk done\n"); fflush(stderr); }
+        for (int i = 0; i < cnt; ++i) GPX_TRY(check_internal_info(hi[i]));
         for (int i = 0; i < cnt; ++i) {
             const double logdet = hs[2 * i], yta = hs[2 * i + 1];
             double v;
@@ -691,6 +770,7 @@ int gpx_cholesky(double *L, const double *A, int64_t n, int *info)
     GPX_TRY(potrf(GPX_F64, a.p, n, lda, (int *)inf.p, nullptr));
     GPX_TRY(tril(GPX_F64, a.p, n, lda, nullptr));
     GPX_HIP(hipMemcpy(info, inf.p, sizeof(int), hipMemcpyDeviceToHost));
+    GPX_TRY(check_internal_info(*info));
     GPX_HIP(hipMemcpy2D(L, (size_t)n * 8, a.p, (size_t)lda * 8, (size_t)n * 8, (size_t)n, hipMemcpyDeviceToHost));
     return GPX_OK;
 }

@@ -13,6 +13,7 @@ struct gpx_gp {
     double params[3];
     double s;
     bool have_data, have_params, fitted, have_K;
+    bool x_finite, y_finite;   // scipy's check_finite=True (gp/gp.py:294, 332-334): one O(n d) device reduction per set_data
     float ms[5];
     // fit_batch workspace (grow-only, freed with the handle): the matrices of one chunk + their vectors
     void *bw; size_t bw_bytes; int64_t bw_cap;
@@ -34,6 +35,11 @@ struct DevBuf {
 };
 
 }  // namespace gpx
+
+namespace gpx {
+// x_finite / y_finite of the handle from its device arrays (one O(n d) reduction; synchronous)
+int gp_scan_finite(gpx_gp *g);
+}
 
 // every gpx_gp_* entry: the handle's device becomes current for the duration of the call
 #define GP_ENTER(g)                                                          \

@@ -12,6 +12,10 @@
 //     is produced with two panels of device memory.
 #include "gpx_gp_internal.h"
 #include <stdio.h>
+#include <string>
+#include <unistd.h>
+#include <sys/stat.h>
+#include <cmath>
 #include <vector>
 
 extern "C" int gpx_gp_create(gpx_gp_t **out, int dtype, int kernel, int64_t n, int d);
@@ -42,10 +46,34 @@ struct File {
     ~File() { if (f) fclose(f); }
 };
 
+// two events for the double-buffered staging, released on every way out
+struct EventPair {
+    hipEvent_t e[2] = {nullptr, nullptr};
+    ~EventPair() { for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); }
+    int create()
+    {
+        GPX_HIP(hipEventCreateWithFlags(&e[0], hipEventDisableTiming));
+        GPX_HIP(hipEventCreateWithFlags(&e[1], hipEventDisableTiming));
+        return GPX_OK;
+    }
+};
+
+// bytes of a checkpoint with this header: header, x, y, alpha as float64, then the lower trapezoid in row blocks
+static bool expected_file_bytes(const FactorHeader &hd, size_t es, unsigned long long *out)
+{
+    const unsigned long long n = (unsigned long long)hd.n, d = (unsigned long long)hd.d, R = (unsigned long long)hd.block_rows;
+    unsigned long long total = sizeof(FactorHeader) + 8ull * (n * d + 2 * n);
+    for (unsigned long long r0 = 0; r0 < n; r0 += R) {
+        const unsigned long long r1 = std::min(n, r0 + R);
+        total += (r1 - r0) * r1 * es;
+    }
+    *out = total;
+    return true;
+}
+
 static int64_t io_block_rows(int64_t n, size_t es)
 {
-    const char *env = getenv("GPX_IO_BLOCK_BYTES");
-    const size_t target = env ? (size_t)atoll(env) : ((size_t)64 << 20);
+    const size_t target = (size_t)std::max<int64_t>(1, env_i64("GPX_IO_BLOCK_BYTES", (int64_t)64 << 20));
     int64_t r = (int64_t)(target / ((size_t)std::max<int64_t>(n, 1) * es));
     return std::max<int64_t>(1, std::min<int64_t>(r, n));
 }
@@ -114,9 +142,13 @@ int gpx_gp_save(gpx_gp_t *g, const char *path)
     hd.n = n; hd.block_rows = io_block_rows(n, es);
     for (int i = 0; i < 3; ++i) hd.params[i] = g->have_params ? g->params[i] : 0.0;
     hd.s = g->s; hd.logdet = h4[0]; hd.yta = h4[1];
+    // written under a temporary name and renamed when complete: a failure never leaves a truncated checkpoint
+    // under the final name
+    const std::string tmp_path = std::string(path) + ".tmp";
+    struct Unlink { const std::string &p; bool armed = true; ~Unlink() { if (armed) (void)unlink(p.c_str()); } } cleanup{tmp_path};
     File fp;
-    fp.f = fopen(path, "wb");
-    if (!fp.f) { set_error("gpx_gp_save: cannot open %s for writing", path); return GPX_ERR_ARG; }
+    fp.f = fopen(tmp_path.c_str(), "wb");
+    if (!fp.f) { set_error("gpx_gp_save: cannot open %s for writing", tmp_path.c_str()); cleanup.armed = false; return GPX_ERR_ARG; }
     bool ok = fwrite(&hd, sizeof(hd), 1, fp.f) == 1;
     std::vector<double> v;
     GPX_TRY(vec_d2h_f64(g, g->x, n * g->d, v)); ok = ok && fwrite(v.data(), 8, v.size(), fp.f) == v.size();
@@ -125,11 +157,11 @@ int gpx_gp_save(gpx_gp_t *g, const char *path)
     // the lower trapezoid of L, row block [r0, r1): columns [0, r1), packed row-major, two staging buffers
     const int64_t R = hd.block_rows;
     Pinned stage[2];
-    hipEvent_t ev[2] = {nullptr, nullptr};
+    EventPair evp;
     GPX_TRY(stage[0].alloc((size_t)R * n * es));
     GPX_TRY(stage[1].alloc((size_t)R * n * es));
-    GPX_HIP(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
-    GPX_HIP(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+    GPX_TRY(evp.create());
+    hipEvent_t *ev = evp.e;
     const int64_t nblk = cdiv(n, R);
     auto issue = [&](int64_t b) -> int {
         const int64_t r0 = b * R, r1 = std::min(n, r0 + R);
@@ -149,9 +181,11 @@ int gpx_gp_save(gpx_gp_t *g, const char *path)
         ok = fwrite(buf, es, (size_t)(r1 - r0) * r1, fp.f) == (size_t)(r1 - r0) * r1;
     }
     (void)hipStreamSynchronize(g->st);
-    (void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]);
     if (rc != GPX_OK) return rc;
-    if (!ok || fflush(fp.f) != 0) { set_error("gpx_gp_save: short write to %s", path); return GPX_ERR_ARG; }
+    if (!ok || fflush(fp.f) != 0 || fsync(fileno(fp.f)) != 0) { set_error("gpx_gp_save: short write to %s", tmp_path.c_str()); return GPX_ERR_ARG; }
+    fclose(fp.f); fp.f = nullptr;
+    if (rename(tmp_path.c_str(), path) != 0) { set_error("gpx_gp_save: cannot rename %s to %s", tmp_path.c_str(), path); return GPX_ERR_ARG; }
+    cleanup.armed = false;
     return GPX_OK;
 }
 
@@ -168,6 +202,25 @@ int gpx_gp_load(gpx_gp_t **out, const char *path)
         set_error("gpx_gp_load: %s is not a gpx factor checkpoint", path);
         return GPX_ERR_ARG;
     }
+    // the header is not trusted: every field is checked, and the sizes it implies against the size of the file,
+    // before anything is allocated from it
+    const bool dtype_ok = hd.dtype == GPX_F64 || hd.dtype == GPX_F32;
+    const bool kernel_ok = hd.kernel == GPX_KERNEL_GAUSSIAN || hd.kernel == GPX_KERNEL_PERIODIC;
+    const int np_expected = hd.kernel == GPX_KERNEL_PERIODIC ? 3 : 2;
+    bool fields_ok = dtype_ok && kernel_ok && hd.n >= 1 && hd.n <= ((int64_t)1 << 24) && hd.d >= 1 && hd.d <= 65536 &&
+                     hd.block_rows >= 1 && hd.block_rows <= hd.n && (hd.nparams == 0 || hd.nparams == np_expected) &&
+                     hd.info >= 0 && std::isfinite(hd.s) && hd.s >= 0;
+    for (int i = 0; i < hd.nparams && fields_ok; ++i) fields_ok = std::isfinite(hd.params[i]);
+    if (!fields_ok) { set_error("gpx_gp_load: %s has a corrupt header", path); return GPX_ERR_ARG; }
+    {
+        struct stat sb;
+        unsigned long long want = 0;
+        expected_file_bytes(hd, hd.dtype == GPX_F64 ? 8 : 4, &want);
+        if (fstat(fileno(fp.f), &sb) != 0 || (unsigned long long)sb.st_size != want) {
+            set_error("gpx_gp_load: %s is truncated or its header is corrupt (%llu bytes expected)", path, want);
+            return GPX_ERR_ARG;
+        }
+    }
     gpx_gp_t *g = nullptr;
     GPX_TRY(gpx_gp_create(&g, hd.dtype, hd.kernel, hd.n, hd.d));
     struct Guard { gpx_gp_t *g; ~Guard() { if (g) gpx_gp_destroy(g); } } guard{g};
@@ -183,13 +236,12 @@ int gpx_gp_load(gpx_gp_t **out, const char *path)
     GPX_TRY(rd(g->y, n));
     GPX_TRY(rd(g->alpha, n));
     const int64_t R = hd.block_rows;
-    GPX_ARG(R >= 1 && R <= n, "corrupt header (block_rows)");
     Pinned stage[2];
-    hipEvent_t ev[2] = {nullptr, nullptr};
+    EventPair evp;
     GPX_TRY(stage[0].alloc((size_t)R * n * es));
     GPX_TRY(stage[1].alloc((size_t)R * n * es));
-    GPX_HIP(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
-    GPX_HIP(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+    GPX_TRY(evp.create());
+    hipEvent_t *ev = evp.e;
     const int64_t nblk = cdiv(n, R);
     int rc = GPX_OK;
     bool used[2] = {false, false};
@@ -207,8 +259,8 @@ int gpx_gp_load(gpx_gp_t **out, const char *path)
         used[b & 1] = true;
     }
     (void)hipStreamSynchronize(g->st);
-    (void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]);
     if (rc != GPX_OK) return rc;
+    GPX_TRY(gp_scan_finite(g));
     double h4[4] = {hd.logdet, hd.yta, 0.0, 0.0};
     memcpy(&h4[3], &hd.info, sizeof(int));
     GPX_HIP(hipMemcpy(g->scal, h4, sizeof(h4), hipMemcpyHostToDevice));
@@ -253,8 +305,7 @@ int gpx_kmat_host(int kernel, int member, double *out, const double *x1, int64_t
     GPX_ARG(out && x1 && x2 && params, "NULL pointer");
     const int64_t ld = round_up(m, 16);
     // panel height: GPX_KMAT_PANEL_BYTES of device memory per panel (default 256 MiB), a multiple of 64 rows
-    const char *env = getenv("GPX_KMAT_PANEL_BYTES");
-    const size_t target = env ? (size_t)atoll(env) : ((size_t)256 << 20);
+    const size_t target = (size_t)std::max<int64_t>(1, env_i64("GPX_KMAT_PANEL_BYTES", (int64_t)256 << 20));
     int64_t R = (int64_t)(target / ((size_t)ld * 8));
     R = std::max<int64_t>(64, R / 64 * 64);
     R = std::min<int64_t>(R, round_up(n, 64));

@@ -22,9 +22,23 @@
 // ONE GPU over gloo, which RCCL cannot do.
 #include "gpx_common.h"
 #include <dlfcn.h>
-#include <rccl/rccl.h>
+#include <climits>
 #include <cmath>
 #include <vector>
+
+// The handful of RCCL declarations this file needs, restated from the public nccl.h ABI (stable since NCCL 2.x):
+// libgpx.so builds on a ROCm install without the RCCL headers, as it already runs without the library.
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef int ncclResult_t;                 // ncclSuccess = 0
+typedef int ncclDataType_t;               // ncclInt32 = 2, ncclFloat32 = 7, ncclFloat64 = 8
+typedef int ncclRedOp_t;                  // ncclSum = 0, ncclMax = 2
+}
+static constexpr ncclResult_t ncclSuccess = 0;
+static constexpr ncclDataType_t ncclInt32 = 2, ncclFloat32 = 7, ncclFloat64 = 8;
+static constexpr ncclRedOp_t ncclSum = 0, ncclMax = 2;
+static_assert(sizeof(ncclUniqueId) == GPX_MG_ID_BYTES, "ncclUniqueId is 128 bytes");
 
 extern "C" int gpx_d_mean(int dtype, int kernel, const void *xo, int64_t m, const void *x, int64_t n, int d,
                           const double *params, const void *alpha, void *out, void *stream);
@@ -47,6 +61,9 @@ struct Rccl {
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommCuDevice)(const ncclComm_t, int *) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 static Rccl g_rccl;
@@ -74,6 +91,9 @@ static int rccl_load()
     GPX_SYM(Recv, "ncclRecv");
     GPX_SYM(GroupStart, "ncclGroupStart");
     GPX_SYM(GroupEnd, "ncclGroupEnd");
+    GPX_SYM(CommCount, "ncclCommCount");
+    GPX_SYM(CommUserRank, "ncclCommUserRank");
+    GPX_SYM(CommCuDevice, "ncclCommCuDevice");
     GPX_SYM(GetErrorString, "ncclGetErrorString");
 #undef GPX_SYM
     g_rccl.lib = h;
@@ -117,8 +137,9 @@ __global__ void axpy_slot_kernel(double *__restrict__ acc, const double *__restr
 
 __global__ void info_key_kernel(const int *__restrict__ info, int *__restrict__ key)
 {
-    // LAPACK info over all ranks = the SMALLEST positive one: max-reduce of (BIG - info) for info > 0
-    if (threadIdx.x == 0 && blockIdx.x == 0) key[0] = info[0] > 0 ? (1 << 30) - info[0] : 0;
+    // LAPACK info over all ranks = the SMALLEST positive one: max-reduce of (BIG - info) for info > 0.  A negative
+    // info (an internal failure of a resident panel launch on some rank) outranks everything: INT_MAX.
+    if (threadIdx.x == 0 && blockIdx.x == 0) key[0] = info[0] < 0 ? INT_MAX : (info[0] > 0 ? (1 << 30) - info[0] : 0);
 }
 
 }  // namespace gpx
@@ -139,12 +160,15 @@ struct gpx_mg {
     gpx_mg_allreduce_fn cb_allreduce = nullptr;
     void *cb_user = nullptr;
     int bcast_chunks = 4;
+    int bcast_sag = 0;                            // panel broadcast as scatter + all-gather (GPX_MG_BCAST=sag / gpx_mg_set_bcast)
+    void *sag_tmp = nullptr; size_t sag_tmp_bytes = 0;   // callback back-end only: where a rank drops pieces that are not its own
+    int debug_info = 0;                           // gpx_debug_mg_inject_info: written into the device info word after the factorisation
     // device state
     void *A = nullptr, *pbuf[2] = {nullptr, nullptr}, *x = nullptr, *y = nullptr, *w = nullptr, *z = nullptr,
          *alpha = nullptr, *tmp = nullptr;
     double *work = nullptr, *scal = nullptr;      // scal: [0] logdet block [1] y^T alpha [2] logdet acc [3] spare
     int *info = nullptr;                          // [0] info [1] reduction key
-    hipStream_t S = nullptr, Q = nullptr;
+    hipStream_t S = nullptr, Q = nullptr, B = nullptr;   // main (updates, solves) / panel (factor, pack) / panel broadcasts
     std::vector<hipEvent_t> ev;                   // sync events (no timing), reused round-robin per fit
     size_t ev_next = 0;
     std::vector<hipEvent_t> tev;                  // timing events (pairs)
@@ -222,7 +246,7 @@ static int mg_bcast(gpx_mg *g, void *dev_ptr, size_t count, int root, hipStream_
         if (rc != 0) { set_error("broadcast callback failed (%d)", rc); return GPX_ERR_HIP; }
         return GPX_OK;
     }
-    if (g->world == 1 && !getenv("GPX_FORCE_COLLECTIVES")) return GPX_OK;
+    if (g->world == 1 && !env_set("GPX_FORCE_COLLECTIVES")) return GPX_OK;
     GPX_NCCL(g_rccl.Broadcast(dev_ptr, dev_ptr, count, nccl_type(g->dtype), root, g->comm, st));
     return GPX_OK;
 }
@@ -237,9 +261,66 @@ static int mg_allreduce(gpx_mg *g, void *dev_ptr, size_t count, int dtype, int o
         if (rc != 0) { set_error("all-reduce callback failed (%d)", rc); return GPX_ERR_HIP; }
         return GPX_OK;
     }
-    if (g->world == 1 && !getenv("GPX_FORCE_COLLECTIVES")) return GPX_OK;
+    if (g->world == 1 && !env_set("GPX_FORCE_COLLECTIVES")) return GPX_OK;
     const ncclDataType_t t = dtype == GPX_F64 ? ncclFloat64 : (dtype == GPX_F32 ? ncclFloat32 : ncclInt32);
     GPX_NCCL(g_rccl.AllReduce(dev_ptr, dev_ptr, count, t, op == 0 ? ncclSum : ncclMax, g->comm, st));
+    return GPX_OK;
+}
+
+// Panel broadcast.  Default: one collective (ncclBroadcast; RCCL picks its rings).  "sag" (GPX_MG_BCAST=sag or
+// gpx_mg_set_bcast): two point-to-point phases -- the root scatters piece i to rank i, then every rank sends its
+// piece straight to every other rank -- so that each of the root's xGMI links carries 1 / P of the payload per phase
+// instead of one ring pushing all of it through link after link (xGMI is point to point, 7 links per GPU).
+// The callback back-end (tests: several ranks on one GPU) emulates the two phases with the broadcast callback: in
+// phase 1 piece i is received into its place only by rank i (the others drop it into a scratch block), in phase 2
+// piece i is re-broadcast by rank i, so a wrong piece map or a missing piece shows in the result.
+static int mg_bcast_panel(gpx_mg *g, void *dev_ptr, size_t count, int root, hipStream_t st)
+{
+    const int P = g->world, me = g->rank;
+    const size_t piece = count / (size_t)P / 32 * 32;             // 32-element (128- / 256-byte) aligned pieces; the last one takes the rest
+    const bool sag = g->bcast_sag && P > 2 && piece >= 1024 && (g->cb_bcast || g->comm);
+    if (!sag) { route_hit(RT_MG_BCAST_ONE); return mg_bcast(g, dev_ptr, count, root, st); }
+    route_hit(RT_MG_BCAST_SAG);
+    auto off = [&](int i) { return (size_t)i * piece; };
+    auto len = [&](int i) { return i + 1 == P ? count - off(i) : piece; };
+    auto at = [&](int i) { return (char *)dev_ptr + off(i) * g->es; };
+    if (g->cb_bcast) {
+        const size_t need = (count - off(P - 1)) * g->es;
+        if (g->sag_tmp_bytes < need) {
+            GPX_HIP(hipStreamSynchronize(st));
+            if (g->sag_tmp) (void)hipFree(g->sag_tmp);
+            g->sag_tmp = nullptr; g->sag_tmp_bytes = 0;
+            GPX_HIP(hipMalloc(&g->sag_tmp, need));
+            g->sag_tmp_bytes = need;
+        }
+        for (int i = 0; i < P; ++i) {                             // phase 1: root -> rank i
+            if (i == root) continue;
+            void *dst = (me == root || me == i) ? (void *)at(i) : g->sag_tmp;
+            const int rc = g->cb_bcast(g->cb_user, dst, len(i) * g->es, root, (void *)st);
+            if (rc != 0) { set_error("broadcast callback failed (%d)", rc); return GPX_ERR_HIP; }
+        }
+        for (int i = 0; i < P; ++i) {                             // phase 2: rank i -> everybody
+            const int rc = g->cb_bcast(g->cb_user, at(i), len(i) * g->es, i, (void *)st);
+            if (rc != 0) { set_error("broadcast callback failed (%d)", rc); return GPX_ERR_HIP; }
+        }
+        return GPX_OK;
+    }
+    const ncclDataType_t t = nccl_type(g->dtype);
+    GPX_NCCL(g_rccl.GroupStart());
+    if (me == root) {
+        for (int i = 0; i < P; ++i)
+            if (i != root) GPX_NCCL(g_rccl.Send(at(i), len(i), t, i, g->comm, st));
+    } else {
+        GPX_NCCL(g_rccl.Recv(at(me), len(me), t, root, g->comm, st));
+    }
+    GPX_NCCL(g_rccl.GroupEnd());
+    GPX_NCCL(g_rccl.GroupStart());
+    for (int j = 0; j < P; ++j) {
+        if (j == me) continue;
+        if (j != root) GPX_NCCL(g_rccl.Send(at(me), len(me), t, j, g->comm, st));      // (the root already holds every piece)
+        if (me != root) GPX_NCCL(g_rccl.Recv(at(j), len(j), t, j, g->comm, st));
+    }
+    GPX_NCCL(g_rccl.GroupEnd());
     return GPX_OK;
 }
 
@@ -256,35 +337,42 @@ static int mg_pack(gpx_mg *g, int64_t r0, int64_t cl, int64_t rows, int64_t kb, 
     return GPX_OK;
 }
 
-// Factor (owner), pack (owner) and broadcast block column j into buf, on Q.  chunk_ev: when non-null the
-// broadcast goes out in row chunks and an event is recorded after each (chunk_rows[c] = first row AFTER chunk c,
+// Factor (owner, stream Q), pack (owner, Q) and broadcast (everybody, stream B) block column j into buf.  The
+// broadcasts have a stream of their own: all ranks issue them in panel order on B, and Q -- the panel chain -- never
+// queues a factorisation behind a transfer it does not depend on.  buf_free: the last update that read `buf`
+// (pack and receive wait for it; the factorisation itself, in place in A, does not).  chunk_ev: when non-null the
+// broadcast goes out in row chunks and an event is recorded after each (chunk_end[c] = first row AFTER chunk c,
 // relative to the panel's first row).
-static int mg_factor_and_bcast(gpx_mg *g, int64_t j, void *buf, std::vector<hipEvent_t> *chunk_ev,
+static int mg_factor_and_bcast(gpx_mg *g, int64_t j, void *buf, hipEvent_t buf_free, std::vector<hipEvent_t> *chunk_ev,
                                std::vector<int64_t> *chunk_end)
 {
     const int64_t r0 = g->k0(j), kb = g->kb(j), rows = g->n - r0;
-    hipStream_t Q = g->Q;
+    hipStream_t Q = g->Q, B = g->B;
     if (g->owner(j) == g->rank) {
         const int64_t cl = g->local_col(j);
         { MgTimer t(g, T_PANEL, Q); GPX_TRY(potrf_panel(g->dtype, g->A, g->ld, g->n, r0, cl, kb, g->info, Q)); }
+        if (buf_free) GPX_HIP(hipStreamWaitEvent(Q, buf_free, 0));
         { MgTimer t(g, T_PACK, Q); GPX_TRY(mg_pack(g, r0, cl, rows, kb, buf, Q)); }
+        GPX_TRY(mg_order(g, Q, B));
+    } else if (buf_free) {
+        GPX_HIP(hipStreamWaitEvent(B, buf_free, 0));
     }
     // row chunks: the first one covers at least the next block column's diagonal rows (its B-operand rows)
     int nch = (chunk_ev && g->world > 1) ? g->bcast_chunks : 1;
     const int64_t min_rows = std::min(rows, std::max<int64_t>(2 * g->nb, 1024));
     if (rows < 4 * min_rows) nch = 1;
-    MgTimer t(g, T_BCAST, Q);
+    MgTimer t(g, T_BCAST, B);
     int64_t done = 0;
     for (int c = 0; c < nch; ++c) {
         int64_t end = (c + 1 == nch) ? rows : std::max(min_rows, (rows * (c + 1) / nch) / 128 * 128);
         end = std::min(end, rows);
         if (end <= done) continue;
-        GPX_TRY(mg_bcast(g, (char *)buf + (size_t)done * g->nb * g->es, (size_t)(end - done) * g->nb, (int)g->owner(j), Q));
+        GPX_TRY(mg_bcast_panel(g, (char *)buf + (size_t)done * g->nb * g->es, (size_t)(end - done) * g->nb, (int)g->owner(j), B));
         done = end;
         if (chunk_ev) {
             hipEvent_t e;
             GPX_TRY(mg_event(g, &e));
-            GPX_HIP(hipEventRecord(e, Q));
+            GPX_HIP(hipEventRecord(e, B));
             chunk_ev->push_back(e);
             chunk_end->push_back(end);
         }
@@ -311,7 +399,7 @@ static int mg_factor(gpx_mg *g)
     MgTimer tf(g, T_FACTOR, S);
     GPX_TRY(mg_order(g, S, Q));                                   // the kernel build is done
     std::vector<hipEvent_t> cev; std::vector<int64_t> cend;
-    GPX_TRY(mg_factor_and_bcast(g, 0, g->pbuf[0], &cev, &cend));
+    GPX_TRY(mg_factor_and_bcast(g, 0, g->pbuf[0], nullptr, &cev, &cend));
     hipEvent_t readers_done[2] = {nullptr, nullptr};              // last update that read pbuf[i]
     for (int64_t k = 0; k < g->nblk; ++k) {
         const int64_t k0 = g->k0(k), kb = g->kb(k), r = k0 + kb;
@@ -341,9 +429,8 @@ static int mg_factor(gpx_mg *g)
         } else {
             GPX_HIP(hipStreamWaitEvent(S, cev.back(), 0));        // the whole panel k is here
         }
-        if (readers_done[nxt % 2]) GPX_HIP(hipStreamWaitEvent(Q, readers_done[nxt % 2], 0));   // update k-1 has let go of that buffer
         std::vector<hipEvent_t> nev; std::vector<int64_t> nend;
-        GPX_TRY(mg_factor_and_bcast(g, nxt, g->pbuf[nxt % 2], &nev, &nend));
+        GPX_TRY(mg_factor_and_bcast(g, nxt, g->pbuf[nxt % 2], readers_done[nxt % 2], &nev, &nend));   // (update k-1 has to let go of that buffer)
         if (jl_first >= 0) {
             MgTimer t(g, T_UPDATE, S);
             GPX_TRY(syrk_bc(g->dtype, g->n, r, g->A, g->ld, jl_first * g->nb, g->ncols_local, Pk, g->nb, k0, kb, g->nb,
@@ -356,6 +443,12 @@ static int mg_factor(gpx_mg *g)
         cev.swap(nev); cend.swap(nend);
     }
     GPX_TRY(mg_order(g, Q, S));
+    GPX_TRY(mg_order(g, g->B, S));
+    if (g->debug_info != 0) {                                     // test hook: as if a resident panel launch had failed
+        GPX_HIP(hipMemcpyAsync(g->info, &g->debug_info, sizeof(int), hipMemcpyHostToDevice, S));
+        GPX_HIP(hipStreamSynchronize(S));
+        g->debug_info = 0;
+    }
     return GPX_OK;
 }
 
@@ -410,8 +503,9 @@ static int mg_reduce(gpx_mg *g)
     GPX_HIP(hipMemcpyAsync(hi, g->info, sizeof(hi), hipMemcpyDeviceToHost, S));
     GPX_HIP(hipStreamSynchronize(S));
     GPX_HIP(hipStreamSynchronize(g->Q));
+    GPX_HIP(hipStreamSynchronize(g->B));
     g->logdet = h[2]; g->yta = h[1];
-    g->info_host = hi[1] == 0 ? 0 : (1 << 30) - hi[1];
+    g->info_host = hi[1] == 0 ? 0 : (hi[1] == INT_MAX ? -7 : (1 << 30) - hi[1]);
     return GPX_OK;
 }
 
@@ -437,7 +531,8 @@ static int mg_alloc(gpx_mg *g)
     GPX_HIP(hipStreamCreateWithFlags(&g->S, hipStreamNonBlocking));
     int least = 0, greatest = 0;
     GPX_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    GPX_HIP(hipStreamCreateWithPriority(&g->Q, hipStreamNonBlocking, greatest));   // panel + broadcast: critical path
+    GPX_HIP(hipStreamCreateWithPriority(&g->Q, hipStreamNonBlocking, greatest));   // the panel chain: critical path
+    GPX_HIP(hipStreamCreateWithPriority(&g->B, hipStreamNonBlocking, greatest));   // the panel broadcasts
     return GPX_OK;
 }
 
@@ -459,8 +554,9 @@ static int mg_new(gpx_mg **out, int dtype, int kernel, int64_t n, int d, int64_t
     for (int64_t j = rank; j < g->nblk; j += world) g->my_blocks.push_back(j);
     g->ncols_local = std::max<int64_t>(1, (int64_t)g->my_blocks.size()) * nb;
     g->ld = g->ncols_local;
-    if (const char *env = getenv("GPX_MG_BCAST_CHUNKS")) g->bcast_chunks = std::max(1, std::min(16, atoi(env)));
-    g->timing = getenv("GPX_MG_NO_TIMING") == nullptr;
+    g->bcast_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(16, env_i64("GPX_MG_BCAST_CHUNKS", 4)));
+    g->timing = !env_set("GPX_MG_NO_TIMING");
+    if (const char *e = getenv("GPX_MG_BCAST")) g->bcast_sag = strcmp(e, "sag") == 0;
     *out = g;
     return GPX_OK;
 }
@@ -491,14 +587,45 @@ int gpx_mg_destroy(gpx_mg_t *g)
     gpx::DeviceGuard guard__(g->device);
     if (g->S) (void)hipStreamSynchronize(g->S);
     if (g->Q) (void)hipStreamSynchronize(g->Q);
+    if (g->B) (void)hipStreamSynchronize(g->B);
     if (g->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(g->comm);
-    void *bufs[] = {g->A, g->pbuf[0], g->pbuf[1], g->x, g->y, g->w, g->z, g->alpha, g->tmp, g->work, g->scal, g->info};
+    void *bufs[] = {g->A, g->pbuf[0], g->pbuf[1], g->x, g->y, g->w, g->z, g->alpha, g->tmp, g->work, g->scal, g->info, g->sag_tmp};
     for (void *b : bufs) if (b) (void)hipFree(b);
     for (hipEvent_t e : g->ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : g->tev) (void)hipEventDestroy(e);
     if (g->S) (void)hipStreamDestroy(g->S);
     if (g->Q) (void)hipStreamDestroy(g->Q);
+    if (g->B) (void)hipStreamDestroy(g->B);
     delete g;
+    return GPX_OK;
+}
+
+int gpx_mg_probe(void)
+{
+    GPX_TRY(ensure_device());
+    return rccl_load();                                           // dlopen + dlsym only: no bootstrap thread, no socket
+}
+
+int gpx_mg_create_local(gpx_mg_t **out, int dtype, int kernel, int64_t n, int d, int64_t nb, int world, int rank)
+{
+    GPX_TRY(mg_new(out, dtype, kernel, n, d, nb, world, rank));
+    gpx_mg *g = *out;
+    int rc = rccl_load();
+    if (rc == GPX_OK) rc = mg_alloc(g);
+    if (rc != GPX_OK) { gpx_mg_destroy(g); *out = nullptr; }
+    return rc;
+}
+
+int gpx_mg_connect(gpx_mg_t *g, const void *id128)
+{
+    MG_ENTER(g);
+    GPX_ARG(id128, "the RCCL unique id is NULL");
+    GPX_ARG(!g->comm && !g->cb_bcast, "the handle already has a communicator");
+    GPX_TRY(rccl_load());
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    ncclResult_t r = g_rccl.CommInitRank(&g->comm, g->world, id, g->rank);
+    if (r != ncclSuccess) { g->comm = nullptr; set_error("ncclCommInitRank failed: %s", g_rccl.GetErrorString(r)); return GPX_ERR_HIP; }
     return GPX_OK;
 }
 
@@ -506,18 +633,41 @@ int gpx_mg_create(gpx_mg_t **out, int dtype, int kernel, int64_t n, int d, int64
                   const void *id128)
 {
     GPX_ARG(id128, "the RCCL unique id is NULL");
-    GPX_TRY(mg_new(out, dtype, kernel, n, d, nb, world, rank));
-    gpx_mg *g = *out;
-    int rc = rccl_load();
-    if (rc == GPX_OK) rc = mg_alloc(g);
-    if (rc == GPX_OK) {
-        ncclUniqueId id;
-        memcpy(&id, id128, sizeof(id));
-        ncclResult_t r = g_rccl.CommInitRank(&g->comm, world, id, rank);
-        if (r != ncclSuccess) { set_error("ncclCommInitRank failed: %s", g_rccl.GetErrorString(r)); rc = GPX_ERR_HIP; }
-    }
-    if (rc != GPX_OK) { gpx_mg_destroy(g); *out = nullptr; }
+    GPX_TRY(gpx_mg_create_local(out, dtype, kernel, n, d, nb, world, rank));
+    const int rc = gpx_mg_connect(*out, id128);
+    if (rc != GPX_OK) { gpx_mg_destroy(*out); *out = nullptr; }
     return rc;
+}
+
+int gpx_mg_comm_info(gpx_mg_t *g, int *nranks, int *rank, int *device, int *bcast_sag)
+{
+    MG_ENTER(g);
+    if (bcast_sag) *bcast_sag = g->bcast_sag;
+    if (g->comm) {                                                // what RCCL itself says about the communicator
+        int v = 0;
+        if (nranks) { GPX_NCCL(g_rccl.CommCount(g->comm, &v)); *nranks = v; }
+        if (rank) { GPX_NCCL(g_rccl.CommUserRank(g->comm, &v)); *rank = v; }
+        if (device) { GPX_NCCL(g_rccl.CommCuDevice(g->comm, &v)); *device = v; }
+        return GPX_OK;
+    }
+    if (nranks) *nranks = 0;                                      // no RCCL communicator (callback back-end)
+    if (rank) *rank = g->rank;
+    if (device) *device = g->device;
+    return GPX_OK;
+}
+
+int gpx_mg_set_bcast(gpx_mg_t *g, int sag)
+{
+    MG_ENTER(g);
+    g->bcast_sag = sag ? 1 : 0;                                   // collective: every rank sets the same mode before the next fit
+    return GPX_OK;
+}
+
+int gpx_debug_mg_inject_info(gpx_mg_t *g, int value)
+{
+    GPX_ARG(g != nullptr, "mg is NULL");
+    g->debug_info = value;
+    return GPX_OK;
 }
 
 int gpx_mg_create_cb(gpx_mg_t **out, int dtype, int kernel, int64_t n, int d, int64_t nb, int world, int rank,
@@ -557,13 +707,14 @@ int gpx_mg_fit(gpx_mg_t *g, const double *params, double s, double *log_lh, int 
 {
     MG_ENTER(g);
     GPX_ARG(g->have_data && params, "set_data must be called before fit");
-    GPX_ARG(s >= 0, "invalid value for s");
+    GPX_ARG(!(s < 0), "invalid value for s");
     g->ev_next = 0; g->tev_next = 0;
     GPX_HIP(hipMemsetAsync(g->info, 0, 4 * sizeof(int), g->S));
     GPX_TRY(mg_build(g, params, s));
     GPX_TRY(mg_factor(g));
     GPX_TRY(mg_solve(g));
     GPX_TRY(mg_reduce(g));
+    GPX_TRY(check_internal_info(g->info_host));                   // every rank sees the same reduced word: all fail together
     g->fitted = true;
     // stage and chain times of this rank (HIP events, all streams drained by mg_reduce)
     for (double &v : g->ms) v = 0;

@@ -440,10 +440,19 @@ static unsigned long long *g_res_stamps = nullptr;             // diagnostic: th
 static int g_res_stamp_at = -1;
 
 // per host thread and device: the published blocks and flag words of every matrix of a batch
-struct ResScratch { void *p = nullptr; size_t bytes = 0; int nbatch = 0; int serial = 0; };
+// The blocks and flag words are ONE set per host thread and device, told apart between launches only by the serial:
+// two resident launches of a thread must never be in flight at once.  Launches on one stream are ordered anyway (the
+// factorisation's panels all go to the thread's look-ahead stream); when the stream CHANGES (a single-panel matrix on
+// the caller's stream, gpx_d_potrf_panel on any stream, the multi-GPU schedule's panel stream, an asynchronous
+// gpx_gp_fit followed by another handle's) the new launch waits for the previous one through `ev`.
+struct ResScratch {
+    void *p = nullptr; size_t bytes = 0; int nbatch = 0; int serial = 0;
+    hipEvent_t ev = nullptr;        // after the last launch that was NOT on the look-ahead stream / recorded on demand on it
+    hipStream_t last = nullptr; bool have_last = false, last_on_side = false;
+};
 constexpr int RES_MAXDEV = 16;
 static thread_local ResScratch g_res_dev[RES_MAXDEV];       // one per device: a thread that alternates between GPUs keeps both
-#define RES_TRACE(...) do { if (getenv("GPX_TRACE")) { fprintf(stderr, "[gpx] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
+#define RES_TRACE(...) do { if (env_set("GPX_TRACE")) { fprintf(stderr, "[gpx] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
 static int res_scratch(int nbatch, size_t es, void **pub, int **flags, ResScratch **out)
 {
     int dev = 0;
@@ -486,7 +495,7 @@ static int res_scratch(int nbatch, size_t es, void **pub, int **flags, ResScratc
 
 int64_t panel_res_max()
 {
-    const int64_t v = getenv("GPX_POTRF_RES") ? atoll(getenv("GPX_POTRF_RES")) : (int64_t)RES_MAXSTEPS * IB;   // (read per call: tests switch it)
+    const int64_t v = env_i64("GPX_POTRF_RES", (int64_t)RES_MAXSTEPS * IB);
     return std::min<int64_t>(v, (int64_t)RES_MAXSTEPS * IB);
 }
 
@@ -504,10 +513,21 @@ static int panel_res_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int
     RES_TRACE("panel_res: n %lld r0 %lld kb %lld kpre %lld batch %d grid %u serial %d", (long long)n, (long long)r0, (long long)kb,
               (long long)kpre, nbatch, grid.x, scr->serial + 1);
     ProfScope prof(PC_POTRF_DIAG, (kd * kd * kd / 3.0 + (double)(rows - kb) * kd * kd + 2.0 * (double)rows * kd * (double)kpre) * nbatch, st);
+    const hipStream_t side = potrf_side_stream();
+    if (!scr->ev) GPX_HIP(hipEventCreateWithFlags(&scr->ev, hipEventDisableTiming));
+    if (scr->have_last && scr->last != st) {
+        if (scr->last_on_side) {
+            if (side == scr->last) GPX_HIP(hipEventRecord(scr->ev, side));     // everything queued there so far
+            else GPX_HIP(hipDeviceSynchronize());                               // (that stream went away with its device context)
+        }
+        GPX_HIP(hipStreamWaitEvent(st, scr->ev, 0));
+    }
     hipLaunchKernelGGL((panel_res_kernel<T>), grid, dim3(256), 0, st, A, lda, n, r0, c0, (int)(kb / IB), info_dev, (T *)pub,
                        flags, ++scr->serial, bt ? bt->sA : (int64_t)0, (int)(kpre / IB),
                        (g_res_stamps && g_res_stamp_at-- == 0) ? g_res_stamps : (unsigned long long *)nullptr);
     GPX_LAUNCH_CHECK();
+    scr->last = st; scr->have_last = true; scr->last_on_side = (side != nullptr && st == side);
+    if (!scr->last_on_side) GPX_HIP(hipEventRecord(scr->ev, st));               // (a caller's stream may not outlive this call)
     return GPX_OK;
 }
 
@@ -524,8 +544,8 @@ int potrf_panel_res(int dtype, void *A, int64_t lda, int64_t n, int64_t r0, int6
 // run in several rounds and the tuned GEMM does the same update faster than they do)
 bool panel_res_fold(int64_t rows, int64_t kpre, int64_t kb, size_t es, int64_t lda, const void *base)
 {
-    const int64_t rows_max = getenv("GPX_POTRF_FOLD_ROWS") ? atoll(getenv("GPX_POTRF_FOLD_ROWS")) : 16384;
-    const int64_t kpre_max = getenv("GPX_POTRF_FOLD_K") ? atoll(getenv("GPX_POTRF_FOLD_K")) : 256;
+    const int64_t rows_max = env_i64("GPX_POTRF_FOLD_ROWS", 16384);
+    const int64_t kpre_max = env_i64("GPX_POTRF_FOLD_K", 256);
     return kb % IB == 0 && kb <= panel_res_max() && kpre % IB == 0 && kpre > 0 && kpre <= kpre_max && rows <= rows_max &&
            lda % (16 / (int64_t)es) == 0 && ((uintptr_t)base) % 16 == 0;
 }

@@ -1,6 +1,7 @@
 // gpx_runtime.hip -- device / memory / stream / event plumbing of the C ABI.
 #include "gpx_common.h"
 #include <stdarg.h>
+#include <atomic>
 #include <mutex>
 #include <set>
 #include <utility>
@@ -88,6 +89,10 @@ static void prof_clear()
     g_prof.clear();
 }
 
+// ---- route counters ----------------------------------------------------------
+static std::atomic<long long> g_route[RT_COUNT];
+void route_hit(int route) { if (route >= 0 && route < RT_COUNT) g_route[route].fetch_add(1, std::memory_order_relaxed); }
+
 // ---- per-(kernel, device) launch attributes -------------------------------------
 static std::mutex g_attr_mu;
 static std::set<std::pair<const void *, int>> g_attr_done;
@@ -111,6 +116,19 @@ using namespace gpx;
 extern "C" {
 
 int gpx_version(void) { return GPX_VERSION; }
+
+int gpx_debug_route_count(int route, int64_t *count)
+{
+    GPX_ARG(route >= 0 && route < RT_COUNT && count, "bad route / NULL count");
+    *count = (int64_t)g_route[route].load(std::memory_order_relaxed);
+    return GPX_OK;
+}
+
+int gpx_debug_route_reset(void)
+{
+    for (int i = 0; i < RT_COUNT; ++i) g_route[i].store(0, std::memory_order_relaxed);
+    return GPX_OK;
+}
 
 const char *gpx_last_error(void) { return g_err; }
 

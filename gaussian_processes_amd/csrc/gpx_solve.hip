@@ -603,15 +603,13 @@ static int trsv_ops_prepare(const T *L, int64_t n, int64_t ldl, void *buf, hipSt
 
 static bool trsv_ops_enabled()
 {
-    static const bool on = !(getenv("GPX_TRSV_OPS") && atoi(getenv("GPX_TRSV_OPS")) == 0);
-    return on;
+    return env_i64("GPX_TRSV_OPS", 1) != 0;
 }
 // below this the ~0.7 ms of operator products (11 under-filled launches) costs what the shorter steps save
 // (n = 8192: 1.17 vs 1.10 ms for both sweeps; n = 16384: 1.78 vs 2.49; n = 65536: 9.7 vs 12.1)
 static int64_t trsv_ops_min_n()
 {
-    static const int64_t v = getenv("GPX_TRSV_OPS_MIN") ? std::max<int64_t>(2 * OB, atoll(getenv("GPX_TRSV_OPS_MIN"))) : 10240;
-    return v;
+    return std::max<int64_t>(2 * OB, env_i64("GPX_TRSV_OPS_MIN", 10240));
 }
 
 template <typename T>
@@ -632,13 +630,14 @@ static int trsv_t(const T *L, int64_t n, int64_t ldl, T *b, T *x, int transpose,
     GPX_TRY(scratch((size_t)nbt * sLinv * sizeof(T), &scr));
     T *Linv = (T *)scr;
     const int aligned = (((uintptr_t)L) % (2 * sizeof(T)) == 0) && (ldl % 2 == 0);
-    static const int ablate = getenv("GPX_TRSV_ABLATE") ? atoi(getenv("GPX_TRSV_ABLATE")) : 0;   // timing diagnostics only
+    const int ablate = (int)env_i64("GPX_TRSV_ABLATE", 0);   // timing diagnostics only
     const int64_t nb = cdiv(ncols, TB);
     auto width = [&](int64_t blk) { return (int)std::min<int64_t>(TB, ncols - blk * TB); };
     // operator form: square systems of at least two full blocks, aligned rows, one system
     if (trsv_ops_enabled() && !bt && ncols == n && n >= trsv_ops_min_n() && aligned && ldl % (16 / (int64_t)sizeof(T)) == 0 &&
         ((uintptr_t)L) % 16 == 0) {
         const int64_t nfull = n / OB, rag = n - nfull * OB, BS = (int64_t)OB * OB;
+        route_hit(RT_TRSV_OPS);
         void *buf = nullptr;
         bool fresh = true;
         if (ops) {                                                   // the caller's cache (one factor, many solves)
@@ -697,6 +696,7 @@ static int trsv_t(const T *L, int64_t n, int64_t ldl, T *b, T *x, int transpose,
     // Per block two launches: (N) the 512 x 512 tile that carries the previous block's
     // solution into this block's rows/columns, spread over 8-16 workgroups; (F) workgroup 0
     // solves the block while the other workgroups stream the previous block's far panel.
+    route_hit(RT_TRSV_STEPS);
     if (!transpose) {
         hipLaunchKernelGGL((inv64_kernel<T>), dim3((unsigned)nblk, nbt), dim3(256), 0, st, L, ldl, ncols, Linv, 1,
                            (T *)nullptr, (T *)nullptr, sL, sLinv);
@@ -818,7 +818,7 @@ int trsm_right_lt(int dtype, const void *L, int64_t n, int64_t ldl, void *X, int
 {
     if (n <= 0 || m <= 0) return GPX_OK;
     const size_t es = esize(dtype);
-    static const int64_t nb_env = getenv("GPX_TRSM_NB") ? atoll(getenv("GPX_TRSM_NB")) : 0;
+    const int64_t nb_env = env_i64("GPX_TRSM_NB", 0);
     const int64_t NB = nb_env > 0 ? nb_env : (n >= 8192 ? 512 : 256);
     auto Lp = [&](int64_t r, int64_t c) { return (const char *)L + (r * ldl + c) * es; };
     auto Xp = [&](int64_t c) { return (char *)X + c * es; };

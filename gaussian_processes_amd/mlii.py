@@ -82,7 +82,9 @@ def log_lh_batch(x, y, thetas, kernel="gaussian", dtype="float64", dist=None, de
     (kernel parameter < EPS or s < 0, the reference's ValueError conditions) and rows whose
     kernel matrix is not positive definite give ``-inf`` / ``nan`` as the reference would
     (-inf for non-PD, gp/gp.py:362-365; nan marks a row that would have raised ValueError).
-    `dist`: an initialised ``torch.distributed`` module (any backend) or None.
+    `dist`: an initialised ``torch.distributed`` module (any backend) or None: rows are dealt round-robin
+    to the ranks (rank r takes rows r, r + world, ...; each rank runs them on ITS GPU -- `device`), one
+    all-reduce of a (value, code) table over a CPU group assembles the result on every rank.
     `batched` (default): this process's rows go through one ``gpx_gp_fit_batch`` call (lock-step
     factorisation of all their matrices).  ``batched=False`` is the row-at-a-time route:
     `concurrency`: handles (= host threads, each with its own HIP streams) working on this
@@ -153,13 +155,27 @@ def log_lh_batch(x, y, thetas, kernel="gaussian", dtype="float64", dist=None, de
         # -inf / nan do not survive a SUM all-reduce of zero-padded tables: ship a finite code
         code = np.where(np.isnan(out), 2.0, np.where(np.isneginf(out), 1.0, 0.0))
         val = np.where(code > 0, 0.0, out)
+        # control-plane traffic (2 x rows doubles): a CPU group.  A process group whose default backend is RCCL gets
+        # a gloo side group here -- the product package never touches torch.cuda
+        group = _cpu_group(dist)
         t = torch.from_numpy(np.stack([val, code]))
-        if dist.get_backend() == "nccl":
-            t = t.cuda()
-        dist.all_reduce(t)
-        t = t.cpu().numpy()
+        dist.all_reduce(t, group=group)
+        t = t.numpy()
         out = np.where(t[1] == 2.0, np.nan, np.where(t[1] == 1.0, -np.inf, t[0]))
     return out
+
+
+_CPU_GROUPS = {}
+
+
+def _cpu_group(dist):
+    """None (the default group) when it is a CPU backend already, else one gloo group per process group."""
+    if dist.get_backend() != "nccl":
+        return None
+    key = id(dist)
+    if key not in _CPU_GROUPS:
+        _CPU_GROUPS[key] = dist.new_group(backend="gloo")          # collective: every rank gets here together
+    return _CPU_GROUPS[key]
 
 
 def best_restart(x, y, thetas, **kw):

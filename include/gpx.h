@@ -20,7 +20,16 @@
  *   - every function returns an int status: GPX_OK (0) or a negative GPX_ERR_*;
  *     gpx_last_error() gives the message (thread-local).  Factorisations report
  *     LAPACK-style `info` (> 0: that leading minor is not positive definite)
- *     through an out-parameter, not through the status.
+ *     through an out-parameter, not through the status.  A HOST-side info is
+ *     never negative: an internal failure of the factorisation is the status
+ *     GPX_ERR_INTERNAL.
+ *   - check_finite: the reference factors with scipy's check_finite=True
+ *     (gp/gp.py:294, 332-334) -- NaN / inf in the kernel matrix or in y raise
+ *     ValueError("array must not contain infs or NaNs").  The handle does the
+ *     same with one O(n d) device reduction over x and y per set_data and a host
+ *     check of the kernel constants: gpx_gp_fit returns GPX_ERR_ARG with that
+ *     text when x, a kernel parameter or s is not finite; every getter that
+ *     involves y (alpha, log_lh, mean, the derivative stack) when y is not.
  *   - "device" entry points (gpx_d_*) take DEVICE pointers and a hipStream_t
  *     passed as void* (NULL = the null stream); they enqueue work and return.
  *     Device matrices must have ld % 16 == 0 and 16-byte aligned bases.
@@ -60,6 +69,9 @@ extern "C" {
 #define GPX_ERR_NO_DEVICE  -3   /* no usable GPU                                  */
 #define GPX_ERR_NOMEM      -4   /* device allocation failed                       */
 #define GPX_ERR_UNSUPPORTED -5  /* combination not implemented                    */
+#define GPX_ERR_INTERNAL   -6   /* the factorisation itself failed (a hand-off between workgroups of the resident
+                                   panel kernel timed out: device info < 0).  Maps to RuntimeError -- it is never
+                                   reported as "not positive definite" (info > 0) nor as log_lh = -inf        */
 
 /* dtype */
 #define GPX_F64 0
@@ -139,6 +151,24 @@ int gpx_stream_wait_event(void *stream, void *event);
 #define GPX_PROF_GEMM_PANEL   9 /* gemm_nt_fast_kernel<T,128,0>: panel / covariance products; flops */
 int gpx_prof_enable(int on);    /* also clears the registry */
 int gpx_prof_read(int cls, double *launches, double *total_ms, double *total_work);
+
+/* Route counters: how often each of the alternative host-side routes was taken since the last reset (counted at
+ * the point of decision, always on).  Every behaviour switch of the library is an environment variable that is
+ * read PER CALL at its point of use; a test that forces a route asserts it here. */
+#define GPX_ROUTE_TRSV_OPS        0   /* single-rhs solve: operator form (one launch per 512-block step)      */
+#define GPX_ROUTE_TRSV_STEPS      1   /* single-rhs solve: two launches per 512-block                         */
+#define GPX_ROUTE_PANEL_RES       2   /* panel: the resident one-launch kernel                                */
+#define GPX_ROUTE_PANEL_CHAIN     3   /* panel: 64-wide leaf + row substitution launches                      */
+#define GPX_ROUTE_FIT_RIDE        4   /* fit: y rode along in the factorisation (forward solve folded in)     */
+#define GPX_ROUTE_FIT_TWO_SOLVES  5   /* fit: forward and backward solve after the factorisation              */
+#define GPX_ROUTE_GEMM_FAST       6   /* product on the LDS-DMA MFMA kernel                                   */
+#define GPX_ROUTE_GEMM_GENERIC    7   /* product on the generic (unaligned / K-tail) kernel                   */
+#define GPX_ROUTE_SYRK_EXACT      8   /* trailing update with the exact tile enumeration                      */
+#define GPX_ROUTE_SYRK_PATCH      9   /* trailing update on the 1024 x 1024 patch grid                        */
+#define GPX_ROUTE_MG_BCAST_ONE   10   /* multi-GPU panel broadcast: one collective per row chunk              */
+#define GPX_ROUTE_MG_BCAST_SAG   11   /* multi-GPU panel broadcast: scatter + all-gather (point to point)     */
+int gpx_debug_route_count(int route, int64_t *count);
+int gpx_debug_route_reset(void);
 
 /* ------------------------------------------------- device-level hot path -- */
 
@@ -350,9 +380,29 @@ typedef struct gpx_mg gpx_mg_t;
 typedef int (*gpx_mg_bcast_fn)(void *user, void *dev_ptr, size_t bytes, int root, void *stream);
 /* dtype: GPX_F64 / GPX_F32 / 2 (int32); op: 0 sum, 1 max; in place on dev_ptr; 0 = success */
 typedef int (*gpx_mg_allreduce_fn)(void *user, void *dev_ptr, size_t count, int dtype, int op, void *stream);
+/* can RCCL be used here at all?  dlopen + symbol lookup only (no bootstrap thread, no socket): the pre-flight a
+ * launcher runs on every rank before anybody enters ncclCommInitRank */
+int gpx_mg_probe(void);
 int gpx_mg_unique_id(void *id128);
+/* Two-step creation, so that a launcher can AGREE on the outcome of the local step (device memory: the local
+ * matrix and two panel buffers; streams) over its own control plane before any rank enters ncclCommInitRank -- a
+ * rank that fails to allocate would otherwise leave the others blocked in there for ever:
+ *   gpx_mg_create_local (no communicator yet)  ->  all ranks exchange ok / not ok  ->  gpx_mg_connect.
+ * gpx_mg_create does both in one call (single process / tests). */
+int gpx_mg_create_local(gpx_mg_t **mg, int dtype, int kernel, int64_t n, int d, int64_t nb, int world, int rank);
+int gpx_mg_connect(gpx_mg_t *mg, const void *id128);
 int gpx_mg_create(gpx_mg_t **mg, int dtype, int kernel, int64_t n, int d, int64_t nb, int world, int rank,
                   const void *id128);
+/* what the communicator itself reports (ncclCommCount / ncclCommUserRank / ncclCommCuDevice); nranks = 0 for
+ * the callback back-end.  bcast_sag: the panel-broadcast algorithm in force.  Any pointer may be NULL. */
+int gpx_mg_comm_info(gpx_mg_t *mg, int *nranks, int *rank, int *device, int *bcast_sag);
+/* panel broadcast algorithm: 0 one collective per row chunk (ncclBroadcast), 1 scatter + all-gather by grouped
+ * ncclSend / ncclRecv (every xGMI link of the root carries 1 / world of the payload per phase).  Also selected by
+ * the environment (GPX_MG_BCAST=sag).  Every rank must set the same mode before the next gpx_mg_fit. */
+int gpx_mg_set_bcast(gpx_mg_t *mg, int sag);
+/* test hook: the next gpx_mg_fit of this rank behaves as if its factorisation had left `value` in the device
+ * info word (value < 0: an internal failure, which every rank must then report as GPX_ERR_INTERNAL) */
+int gpx_debug_mg_inject_info(gpx_mg_t *mg, int value);
 int gpx_mg_create_cb(gpx_mg_t **mg, int dtype, int kernel, int64_t n, int d, int64_t nb, int world, int rank,
                      gpx_mg_bcast_fn bcast, gpx_mg_allreduce_fn allreduce, void *user);
 int gpx_mg_destroy(gpx_mg_t *mg);

@@ -4,7 +4,8 @@ panel broadcasts and the distributed solves against the oracle."""
 import numpy as np
 import pytest
 
-from gaussian_processes_amd.multi_gpu import BlockCyclic, DistributedGP, LocalComm
+from gaussian_processes_amd.multi_gpu import BlockCyclic
+from _py_schedule import DistributedGP, LocalComm
 from oracle import gp_oracle as orc
 from _dist_helpers import CpuOps, run_world
 
