@@ -122,17 +122,29 @@ def test_config5_full_size_lock_step_batch():
     with mlii.BatchEvaluator(X, y) as ev:
         llh = ev(thetas)
         llh_again = ev(thetas)                                     # the workspace is reused: same bits
-    assert llh.shape == (64,) and np.isfinite(llh).all()
+    # SURVEY 8(d)'s draws include small noise levels: with s < 1 the log-determinant of an 8192 x 8192 matrix drops
+    # below MIN = log(2^-1018) and the reference's clamp (gp_c.pyx:22-23) turns the row into -inf.  That
+    # is the reference's answer for those rows; most rows are finite.
+    assert llh.shape == (64,) and not np.isnan(llh).any()
+    finite = np.isfinite(llh)
+    assert finite.sum() >= 40 and (llh[~finite] == -np.inf).all(), llh
     np.testing.assert_array_equal(llh, llh_again)
     rowwise = mlii.log_lh_batch(X, y, thetas, batched=False)
-    np.testing.assert_allclose(llh, rowwise, rtol=1e-12)
-    for i in (0, 37):
+    np.testing.assert_allclose(llh, rowwise, rtol=1e-12)            # (equal infinities compare equal)
+    fin, clamped = np.flatnonzero(finite), np.flatnonzero(~finite)
+    for i in (fin[0], fin[len(fin) // 2]):
         o = orc.OracleGP("gaussian", thetas[i, :2], X, y, thetas[i, 2])
         np.testing.assert_allclose(llh[i], o.log_lh_chol, rtol=1e-10)
+    if clamped.size:
+        i = clamped[0]
+        o = orc.OracleGP("gaussian", thetas[i, :2], X, y, thetas[i, 2])
+        assert o.log_lh_chol == -np.inf                            # the oracle clamps the same row
+        g = gp.GP(gp.GaussianKernel(*thetas[i, :2]), X, y, s=thetas[i, 2])
+        assert g.log_lh == -np.inf and 2 * np.log(_device_diag(g)).sum() < gp.gp.MIN
     # eight at a time (what one GPU of an 8-GPU run of this config gets), with the reference's conventions mixed in
     odd = np.vstack([thetas[:6], [1.0, 200.0, 0.0], [1.0, -1.0, 1.0]])      # rank-deficient (w huge, s = 0); invalid w
     got = mlii.log_lh_batch(X, y, odd)
-    np.testing.assert_array_equal(got[:6], llh[:6])
+    np.testing.assert_allclose(got[:6], llh[:6], rtol=1e-12)       # (8 matrices in lock-step take narrower outer blocks than 64)
     assert got[6] == -np.inf and np.isnan(got[7])
     i, th, best = mlii.best_restart(X, y, thetas)
     assert i == int(np.argmax(llh)) and best == llh[i]
@@ -167,9 +179,11 @@ def test_config5_rows_dealt_over_two_ranks_sharing_the_gpu(tmp_path):
     X, y, _ = orc.synth_inputs(N, d, 4)
     thetas = np.vstack([_config5_thetas(d, 9), [1.0, 200.0, 0.0], [1.0, -1.0, 1.0]])
     single = mlii.log_lh_batch(X, y, thetas)
-    assert np.isfinite(single[:9]).all() and single[9] == -np.inf and np.isnan(single[10])
-    o = orc.OracleGP("gaussian", thetas[4, :2], X, y, thetas[4, 2])
-    np.testing.assert_allclose(single[4], o.log_lh, rtol=1e-10)
+    assert not np.isnan(single[:9]).any() and np.isfinite(single[:9]).sum() >= 5, single
+    assert single[9] == -np.inf and np.isnan(single[10])
+    k = int(np.flatnonzero(np.isfinite(single[:9]))[1])
+    o = orc.OracleGP("gaussian", thetas[k, :2], X, y, thetas[k, 2])
+    np.testing.assert_allclose(single[k], o.log_lh, rtol=1e-10)
     for r in range(2):
         got = np.load(os.path.join(str(tmp_path), "llh_rank%d.npy" % r))
         np.testing.assert_allclose(got[:9], single[:9], rtol=1e-12)      # (rows run in batches of 5 / 4 here, 11 there)
