@@ -45,9 +45,11 @@ def parse_args():
     ap.add_argument("--problem-m", dest="m", type=int, default=1000)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--cpu-sample-n", type=int, default=12288)    # 15-20 s of host work on the GPU box
+    ap.add_argument("--cpu-sample-n2", type=int, default=18432)   # second sample (~45 s): the N^3 exponent is fitted
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip per-launch HIP-event profiling")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the N=8192 (configs[1]) side measurement")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the side measurements (configs[1], [2], [4] and the gp.GP API path)")
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous only (gloo, no GPU work): proves that `bench.py --gpus P` starts P ranks")
     return ap.parse_args()
@@ -86,15 +88,8 @@ def sampled_row_residual(X, y, alpha, h, w, s, nrows=16):
     return res / max(1e-300, float(np.abs(y).max())), int(rows.size)
 
 
-def cpu_baseline(N, d, m, sample_n):
-    """Oracle stage sequence on the host cores, on a bounded sample; scaled to N."""
-    from oracle import gp_oracle as orc
-    try:
-        from threadpoolctl import threadpool_info
-        blas_threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-    except Exception:
-        blas_threads = os.cpu_count()
-    ns = min(sample_n, N)
+def _cpu_sample(orc, ns, d, m):
+    """Oracle stage sequence at N = ns: seconds per stage (and the log_lh it produced)."""
     X, y, Xo = orc.synth_inputs(ns, d, m)
     h, w, s = 1.0, 0.5 * np.sqrt(d), 1.0
     o = orc.OracleGP("gaussian", (h, w), X, y, s)
@@ -104,23 +99,64 @@ def cpu_baseline(N, d, m, sample_n):
     t0 = time.perf_counter(); o.inv_Kxx_y; t["solve"] = time.perf_counter() - t0
     t0 = time.perf_counter(); llh = o.log_lh; t["slogdet_lu"] = time.perf_counter() - t0
     t0 = time.perf_counter(); o.mean(Xo); t["mean"] = time.perf_counter() - t0
-    r = N / float(ns)
-    scaled = {"kmat": t["kmat"] * r ** 2, "potrf": t["potrf"] * r ** 3, "solve": t["solve"] * r ** 2,
-              "slogdet_lu": t["slogdet_lu"] * r ** 3, "mean": t["mean"] * r}
+    return t, float(llh)
+
+
+def cpu_baseline(N, d, m, sample_n, sample_n2=0):
+    """Oracle stage sequence (the reference's own: C kernel loop, scipy cholesky / cho_solve, numpy slogdet LU, dot)
+    on the host cores, on bounded samples; scaled stage by stage to N.  With two samples the exponent of the
+    O(N^3) stages is FITTED from them (log t2/t1 / log n2/n1) instead of assumed."""
+    from oracle import gp_oracle as orc
+    try:
+        from threadpoolctl import threadpool_info
+        blas_threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        blas_threads = os.cpu_count()
+    ns = min(sample_n, N)
+    _cpu_sample(orc, min(768, N), d, 8)                     # untimed: library loading / thread-pool start-up
+    t, llh = _cpu_sample(orc, ns, d, m)
+    powers = {"kmat": 2.0, "potrf": 3.0, "solve": 2.0, "slogdet_lu": 3.0, "mean": 1.0}
+    fitted = None
+    t2 = None
+    ns2 = min(sample_n2, N) if sample_n2 else 0
+    if ns2 > ns:
+        t2, _ = _cpu_sample(orc, ns2, d, m)
+        fitted = {k: float(np.log(max(t2[k], 1e-9) / max(t[k], 1e-9)) / np.log(ns2 / float(ns))) for k in ("potrf", "slogdet_lu", "kmat")}
+    base_n, base_t = (ns2, t2) if t2 is not None else (ns, t)
+    r = N / float(base_n)
+    scaled = {k: base_t[k] * r ** powers[k] for k in powers}                 # nominal exponents from the larger sample
     faithful = sum(scaled.values())
     fair = faithful - scaled["slogdet_lu"]
-    return {
+    out = {
         "value": round(faithful, 3), "unit": "s", "cores": int(blas_threads), "kind": "port",
-        "sample": ("oracle stage sequence (C kernel loop 1 thread; scipy cholesky/cho_solve, "
-                   "numpy slogdet LU on %d BLAS threads) measured at N=%d d=%d m=%d: %s; scaled per "
-                   "stage (N^2, N^3, N^2, N^3, N) to N=%d -- EXTRAPOLATED, the N=%d run needs >128 GiB; "
-                   "without the reference's redundant LU (logdet from diag L): %.1f s"
-                   % (blas_threads, ns, d, m,
-                      ", ".join("%s %.2fs" % kv for kv in t.items()), N, N, fair)),
-        "sample_seconds": round(sum(t.values()), 3),
+        "sample_seconds": round(sum(t.values()) + (sum(t2.values()) if t2 else 0.0), 3),
         "fair_value": round(fair, 3),
-        "log_lh_sample": float(llh),
+        "log_lh_sample": llh,
     }
+    # what stands between this host and running the workload itself: memory (K, L and the LU's copy as float64, plus
+    # LAPACK work space: ~3.2 N^2 x 8 bytes) and time (the extrapolation itself) -- measured, not asserted
+    need_gib = 3.2 * N * N * 8 / 2.0 ** 30
+    try:
+        host_gib = os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE") / 2.0 ** 30
+    except (ValueError, OSError, AttributeError):
+        host_gib = None
+    limits = "needs ~%.0f GiB of host memory (this host: %s) and ~%.0f s" % (
+        need_gib, ("%.0f GiB" % host_gib) if host_gib else "unknown", faithful)
+    out["full_size_run"] = {"host_mem_gib": None if host_gib is None else round(host_gib, 1),
+                            "needed_mem_gib": round(need_gib, 1), "estimated_seconds": round(faithful, 1),
+                            "binding_limit": ("memory" if (host_gib is not None and host_gib < need_gib) else "time")}
+    desc = ("oracle stage sequence (C kernel loop 1 thread; scipy cholesky/cho_solve, numpy slogdet LU on %d BLAS "
+            "threads) measured at N=%d d=%d m=%d: %s" % (blas_threads, ns, d, m, ", ".join("%s %.2fs" % kv for kv in t.items())))
+    if t2 is not None:
+        desc += "; and at N=%d: %s; fitted exponents %s" % (
+            ns2, ", ".join("%s %.2fs" % kv for kv in t2.items()), ", ".join("%s %.2f" % kv for kv in fitted.items()))
+        out["fitted_exponents"] = {k: round(v, 3) for k, v in fitted.items()}
+        out["samples"] = [{"N": ns, "seconds": {k: round(v, 3) for k, v in t.items()}},
+                          {"N": ns2, "seconds": {k: round(v, 3) for k, v in t2.items()}}]
+    desc += ("; scaled per stage (N^2, N^3, N^2, N^3, N) from N=%d to N=%d -- EXTRAPOLATED: the full-size run %s; "
+             "without the reference's redundant LU (logdet from diag L): %.1f s" % (base_n, N, limits, fair))
+    out["sample"] = desc
+    return out
 
 
 def self_launch(nproc):
@@ -207,15 +243,85 @@ def main():
     result = measure_single(args, lib, _lib, N, d, m, dtid, npdt, args.steps, args.warmup, local_rank,
                             prof_on=not args.no_prof)
     if not args.no_secondary and (N, d) != (8192, 8):
-        # BASELINE configs[1] (N=8192, d=8 fp64, 1024 test points), same run, for reference
-        sec = measure_single(args, lib, _lib, 8192, 8, 1024, _lib.F64, np.float64, 10, 2, local_rank,
-                             prof_on=False)
-        result["secondary"] = {"config": sec["config"]["workload"], "value": sec["value"], "unit": "s",
-                               "stages_ms": sec["stages_ms"], "potrf_tflops": sec["potrf_tflops"],
-                               "potrf_frac_of_peak": sec["potrf_frac_of_peak"], "log_lh": sec["log_lh"]}
+        result["secondary"] = secondary_measurements(args, lib, _lib, local_rank, result)
     if not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(N, d, m, args.cpu_sample_n)
+        result["cpu_baseline"] = cpu_baseline(N, d, m, args.cpu_sample_n, args.cpu_sample_n2)
     print(json.dumps(result))
+
+
+def secondary_measurements(args, lib, _lib, local_rank, headline):
+    """The other BASELINE.json configs and the drop-in API path on the driver's clock, same process, after the timed
+    headline region (a list; every entry names its config):
+      configs[1]  N=8192  d=8  fp64, m=1024          handle path
+      configs[2]  N=32768 d=16 fp32, m=1024          handle path, with the fp32 trailing kernel's roofline fraction
+      configs[4]  64 (and 8) restarts x N=8192 d=8   one lock-step gpx_gp_fit_batch call (mlii.BatchEvaluator)
+      headline workload once more through gp.GP(...).log_lh / .mean(xo) -- the reference's own API"""
+    out = []
+    sec = measure_single(args, lib, _lib, 8192, 8, 1024, _lib.F64, np.float64, 10, 2, local_rank, prof_on=False)
+    out.append({"name": "configs[1]", "config": sec["config"]["workload"], "value": sec["value"], "unit": "s",
+                "stages_ms": sec["stages_ms"], "potrf_tflops": sec["potrf_tflops"],
+                "potrf_frac_of_peak": sec["potrf_frac_of_peak"], "log_lh": sec["log_lh"], "check": sec["check"]})
+    sec = measure_single(args, lib, _lib, 32768, 16, 1024, _lib.F32, np.float32, 5, 2, local_rank, prof_on=True)
+    out.append({"name": "configs[2]", "config": sec["config"]["workload"], "value": sec["value"], "unit": "s",
+                "stages_ms": sec["stages_ms"], "potrf_tflops": sec["potrf_tflops"],
+                "potrf_frac_of_peak": sec["potrf_frac_of_peak"], "roofline": sec["roofline"], "log_lh": sec["log_lh"],
+                "check": sec["check"]})
+    out.append(measure_mlii(_lib))
+    if headline["config"]["N"] >= 4096:
+        out.append(measure_api(headline))
+    return out
+
+
+def measure_mlii(_lib, N=8192, d=8):
+    """BASELINE configs[4]: 64 (lengthscale, variance, noise) restarts x N = 8192, one GP per GPU across 8 GPUs.  One GPU's
+    share of that is 8 restarts; the whole table on one GPU is 64.  SURVEY 8(d) draws."""
+    from gaussian_processes_amd import mlii
+    X, y, _ = synth(N, d, 4, np.float64)
+    rs = np.random.RandomState(2)
+    w = rs.uniform(0.25, 2, 64) * np.sqrt(d)
+    h = rs.uniform(0.5, 2, 64)
+    sn = rs.uniform(0.5, 2, 64)
+    thetas = np.column_stack([h, w, sn])
+    res = {"name": "configs[4]", "config": "batched ML-II: restarts x N=%d d=%d fp64, lock-step gpx_gp_fit_batch" % (N, d),
+           "unit": "s"}
+    with mlii.BatchEvaluator(X, y) as ev:
+        for rows in (64, 8):
+            ev(thetas[:rows])                                      # warm: workspace allocation, first launches
+            reps = 3 if rows == 64 else 10
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                llh = ev(thetas[:rows])
+            sec = (time.perf_counter() - t0) / reps
+            tfl = rows * (N ** 3 / 3.0) / sec / 1e12
+            res["restarts_%d" % rows] = {"value": round(sec, 5), "ms_per_restart": round(sec / rows * 1e3, 3),
+                                         "tflops_n3_over_3": round(tfl, 2), "frac_of_peak": round(tfl / FP64_MFMA_PEAK_TFLOPS, 4),
+                                         "finite_rows": int(np.isfinite(llh).sum()),
+                                         "minus_inf_rows_logdet_below_MIN": int(np.isneginf(llh).sum())}
+    res["value"] = res["restarts_64"]["value"]
+    return res
+
+
+def measure_api(headline):
+    """The headline step through the drop-in class: gp.GP(GaussianKernel(h, w), x, y, s) -> set a parameter -> .log_lh,
+    .mean(xo) with host arrays in and out (gp/gp.py:216-223, 337-367, 574-597), against the handle path above."""
+    import gaussian_processes_amd as gp
+    N, d, m = headline["config"]["N"], headline["config"]["d"], headline["config"]["m"]
+    dtype = "float64" if headline["dtype"] == "f64" else "float32"
+    X, y, Xo = synth(N, d, m, np.float64)
+    h, w, s = 1.0, 0.5 * np.sqrt(d), 1.0
+    g = gp.GP(gp.GaussianKernel(h, w), X, y, s=s, dtype=dtype)
+    float(g.log_lh); g.mean(Xo)                                   # warm (allocation, uploads)
+    steps = 2
+    t0 = time.perf_counter()
+    for k in range(steps):
+        g.set_param("h", h * (1.0 + (k + 1) * 1e-13))             # invalidates the memo: the next read refits
+        llh = float(g.log_lh)
+        mean = g.mean(Xo)
+    sec = (time.perf_counter() - t0) / steps
+    assert np.isfinite(llh) and np.isfinite(mean).all()
+    return {"name": "api_path", "config": "headline workload through gp.GP(...).set_param / .log_lh / .mean(xo) (host arrays)",
+            "value": round(sec, 4), "unit": "s", "steps": steps, "handle_path_value": headline["value"],
+            "api_over_handle": round(sec / headline["value"], 4), "log_lh": llh}
 
 
 def measure_single(args, lib, _lib, N, d, m, dtid, npdt, steps, warmup, local_rank, prof_on):
@@ -304,7 +410,10 @@ def measure_single(args, lib, _lib, N, d, m, dtid, npdt, steps, warmup, local_ra
             try:
                 import hashlib
                 here = os.path.dirname(os.path.abspath(__file__))
-                with open(os.path.join(here, "profiles", "r02_pmc", "traffic_n65536.json")) as f:
+                pmc_rel = next(rel for rel in (os.path.join("profiles", "r03_pmc", "traffic_n65536.json"),
+                                               os.path.join("profiles", "r02_pmc", "traffic_n65536.json"))
+                               if os.path.exists(os.path.join(here, rel)))
+                with open(os.path.join(here, pmc_rel)) as f:
                     pmc = json.load(f)
                 with open(os.path.join(here, "gaussian_processes_amd", "csrc", "gpx_gemm.hip"), "rb") as f:
                     sha = hashlib.sha256(f.read()).hexdigest()
@@ -318,8 +427,8 @@ def measure_single(args, lib, _lib, N, d, m, dtid, npdt, steps, warmup, local_ra
                 else:
                     roofline["traffic_stale"] = {"value": round(pmc["traffic_bytes_per_launch"]), "unit": label,
                                                  "note": "measured with an earlier build (gpx_gemm.hip or the launch schedule changed)"}
-                roofline["traffic_source"] = "profiles/r02_pmc/traffic_n65536.json (rocprofv3 --pmc, offline)"
-            except (OSError, KeyError, ValueError):
+                roofline["traffic_source"] = pmc_rel + " (rocprofv3 --pmc, offline)"
+            except (OSError, KeyError, ValueError, StopIteration):
                 pass
     potrf_tflops = (N ** 3 / 3.0) / (stage_ms[1] * 1e-3) / 1e12 if stage_ms[1] > 0 else None
 

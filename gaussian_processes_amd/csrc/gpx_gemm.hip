@@ -1017,7 +1017,15 @@ int syrk_bc(int dtype, int64_t n, int64_t row_begin, void *Cloc, int64_t ldc, in
                 }
                 fm.epre[bands] = total;
                 fm.exact = 1; fm.eT = total; fm.eD = D; fm.eTR = TR; fm.eTC = TC; fm.ebands = bands;
-                int cl = 6;                                           // chunk of 64 tiles = one 8 x 8 patch per XCD turn
+                // Chunk of 2^cl consecutive tiles per XCD turn.  64 = one 8 x 8 patch (8 A- and 8 B-slices in that XCD's
+                // L2 at a time).  An XCD runs 64 tiles at a time (56 with CUs reserved for the panel stream), so the
+                // chunk is also the granule of the load balance BETWEEN the XCDs: with 64-tile chunks one XCD can hold a
+                // whole round of tiles more than its neighbours, and a short update (n <= 12288: 1 - 5 rounds in all)
+                // waits for it -- measured at n = 8192: steps with 1711 / 1275 / 820 tiles took 5 / 4 / 3 rounds of
+                // ~75 us where 4 / 3 / 2 would do (gpurun_out/r3_timeline8192.txt).  Up to GPX_GEMM_FINE_TILES tiles the
+                // chunk is one tile COLUMN of a band (8 tiles: the same 8 A-slices as its neighbours on that XCD, one
+                // B-slice), which keeps the slices per resident tile the same and evens the XCDs out to within 8 tiles.
+                int cl = total <= env_i64("GPX_GEMM_FINE_TILES", 8192) ? 3 : 6;
                 while (cl > 2 && ((int64_t)8 << cl) > total) --cl;   // few tiles: smaller chunks, every XCD still gets some
                 fm.ecl = cl;
                 if (total <= 0) return GPX_OK;

@@ -516,7 +516,8 @@ int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t
     }
     // ... once the step is bound by the panel chain: while the trailing update is the longer of the two (many
     // rows left) it keeps the whole chip
-    const int64_t reserve_below = env_i64("GPX_POTRF_RESERVE_BELOW", 8192);
+    // (round 3, with the XCD-balanced tile map: 8192 -> 4096: n = 8192 potrf 6.37 -> 6.27 ms, tools/r3_ab.sh)
+    const int64_t reserve_below = env_i64("GPX_POTRF_RESERVE_BELOW", 4096);
     auto switch_to = [&](hipStream_t want) -> int {
         if (want == st) return GPX_OK;
         hipEvent_t es;

@@ -303,6 +303,28 @@ def bench_distributed(args, X, y, Xo, params, s, dtype_id, residual_check=None):
 
         for _ in range(args.warmup):
             step()
+        # what the communicator itself says (ncclCommCount / ncclCommUserRank / ncclCommCuDevice), from every rank:
+        # evidence that the data plane really spans `world` GPUs (a silent fallback would show rccl_nranks = 0)
+        comm_infos = [None] * world
+        dist.all_gather_object(comm_infos, gp.comm_info())
+        # panel broadcast algorithm: measured, not guessed.  xGMI is point to point (7 links per GPU); whether RCCL's own
+        # broadcast or the scatter + all-gather form moves a panel faster depends on the node.  One untimed fit each
+        # (after the warm-up), the slower rank decides, every rank takes the same mode.
+        bcast_tune = None
+        if world > 2 and not os.environ.get("GPX_MG_BCAST") and not os.environ.get("GPX_BENCH_NO_BCAST_TUNE"):
+            times = {}
+            for mode in (0, 1):
+                gp.set_bcast(mode)
+                dist.barrier()
+                t0 = time.perf_counter()
+                gp.fit(params, s)
+                el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+                dist.all_reduce(el, op=dist.ReduceOp.MAX)
+                times[mode] = float(el.item())
+            best = 1 if times[1] < times[0] else 0
+            gp.set_bcast(best)
+            bcast_tune = {"one_collective_s": round(times[0], 4), "scatter_allgather_s": round(times[1], 4),
+                          "chosen": "scatter+allgather" if best else "one collective per chunk"}
         dist.barrier()
         _lib.check(lib.gpx_device_sync())
         if rank == 0 and not args.no_prof:
@@ -351,6 +373,10 @@ def bench_distributed(args, X, y, Xo, params, s, dtype_id, residual_check=None):
             "log_lh": llh,
             "check": check,
             "data_plane_fallback": fallback_note,
+            "rccl_nranks": comm_infos[0]["rccl_nranks"],
+            "comm_info_per_rank": comm_infos,
+            "panel_bcast_autotune": bcast_tune,
+            "panel_bcast": gp.comm_info()["panel_bcast"],
             "whole_step_tflops_n3_over_3": round(tfl, 3),
             "whole_step_frac_of_peak_all_gpus": round(tfl / (peak * world), 4),
             # where each rank's step went (ms per step, HIP events on its own streams): the stages, and inside
