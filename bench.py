@@ -127,8 +127,15 @@ def cpu_baseline(N, d, m, sample_n, sample_n2=0):
     scaled = {k: base_t[k] * r ** powers[k] for k in powers}                 # nominal exponents from the larger sample
     faithful = sum(scaled.values())
     fair = faithful - scaled["slogdet_lu"]
+    # with the FITTED exponents instead (the host BLAS is still gaining parallel efficiency at these sizes, so its
+    # measured exponent is below 3): a lower estimate; the truth lies between the two
+    fitted_total = None
+    if fitted is not None:
+        fp = dict(powers); fp.update({k: max(1.0, min(3.0, v)) for k, v in fitted.items()})
+        fitted_total = sum(base_t[k] * r ** fp[k] for k in powers)
     out = {
         "value": round(faithful, 3), "unit": "s", "cores": int(blas_threads), "kind": "port",
+        "value_with_fitted_exponents": None if fitted_total is None else round(fitted_total, 3),
         "sample_seconds": round(sum(t.values()) + (sum(t2.values()) if t2 else 0.0), 3),
         "fair_value": round(fair, 3),
         "log_lh_sample": llh,
