@@ -127,13 +127,15 @@ int syrk_bc(int dtype, int64_t n, int64_t row_begin, void *Cloc, int64_t ldc, in
             const void *Pb, int64_t ldp, int64_t k0, int64_t kb, int64_t nb, int P, int rank,
             hipStream_t st, const int *abort_flag = nullptr, const Batch *bt = nullptr);
 // factor rows [r0, n) x columns [c0, c0 + kb) of A whose diagonal block sits at (r0, c0)
+// done: an event recorded behind the panel's last launch
 int potrf_panel(int dtype, void *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int64_t kb,
-                int *info_dev, hipStream_t st, const Batch *bt = nullptr, int64_t kpre = 0);   // kpre: see potrf_panel_res
+                int *info_dev, hipStream_t st, const Batch *bt = nullptr, int64_t kpre = 0,   // kpre: see potrf_panel_res
+                hipEvent_t done = nullptr);
 int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t st, const Batch *bt = nullptr,
           int64_t xrows = 0);      // xrows: extra rows below the matrix that ride along (A has n + xrows rows)
 // the same panel in ONE launch (gpx_panel.hip): kb a multiple of 64, at most panel_res_max()
 int potrf_panel_res(int dtype, void *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int64_t kb, int *info_dev,
-                    hipStream_t st, const Batch *bt = nullptr, int64_t kpre = 0);
+                    hipStream_t st, const Batch *bt = nullptr, int64_t kpre = 0, hipEvent_t done = nullptr);
 int64_t panel_res_max();
 // this host thread's look-ahead stream of the blocked factorisation on the current device (nullptr before the first
 // one): it lives as long as the thread, so an event may be recorded on it at any time

@@ -199,7 +199,7 @@ template <typename T>
 __global__ __launch_bounds__(256, 2) void panel_res_kernel(T *__restrict__ A, int64_t lda, int64_t n, int64_t r0, int64_t c0,
                                                            int nsteps, int *__restrict__ info, T *__restrict__ pub,
                                                            int *__restrict__ flags, int serial, int64_t sM, int kpre,
-                                                           unsigned long long *__restrict__ stamps)
+                                                           unsigned long long *__restrict__ stamps, int w0)
 {
     typedef PM<T> M;
     typedef typename M::v4 v4;
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void panel_res_kernel(T *__restrict__ A, in
     flags += (int64_t)blockIdx.y * RES_FLAGS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
-    const int w = blockIdx.x;
+    const int w = blockIdx.x + w0;                            // (w0 > 0: the rows of a panel launched in two parts, see panel_res_t)
     const bool future_diag = w < nsteps;
     // diagnostic (gpx_debug_panel_stamps): 8 words per workgroup: start, pre-update done, steps 0..3 done, end, hardware id
     auto stamp = [&](int slot) {
@@ -501,7 +501,7 @@ int64_t panel_res_max()
 
 template <typename T>
 static int panel_res_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int64_t kb, int *info_dev, hipStream_t st,
-                       const Batch *bt, int64_t kpre)
+                       const Batch *bt, int64_t kpre, hipEvent_t done)
 {
     const int nbatch = bt ? bt->count : 1;
     void *pub = nullptr; int *flags = nullptr;
@@ -522,10 +522,33 @@ static int panel_res_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int
         }
         GPX_HIP(hipStreamWaitEvent(st, scr->ev, 0));
     }
-    hipLaunchKernelGGL((panel_res_kernel<T>), grid, dim3(256), 0, st, A, lda, n, r0, c0, (int)(kb / IB), info_dev, (T *)pub,
-                       flags, ++scr->serial, bt ? bt->sA : (int64_t)0, (int)(kpre / IB),
-                       (g_res_stamps && g_res_stamp_at-- == 0) ? g_res_stamps : (unsigned long long *)nullptr);
+    unsigned long long *stamps = (g_res_stamps && g_res_stamp_at-- == 0) ? g_res_stamps : (unsigned long long *)nullptr;
+    const int serial = ++scr->serial;
+    const int nsteps = (int)(kb / IB);
+    // TALL panels go out as TWO launches on the same stream: first the diagonal workgroups alone (the chain of leaves),
+    // then all the rows below.  In one launch the row workgroups sit on their CUs for the whole chain -- ~230 us at
+    // 32768 rows, of which they compute for ~30 -- and each of them keeps a trailing-update workgroup of the other
+    // stream off its CU meanwhile (254 VGPRs: two workgroups fill a CU).  Launched after the chain they find every
+    // flag raised, never wait, and hold their CUs for a tenth of the time.  The panel's own latency grows by the
+    // row pass (it no longer hides under the chain), which only matters where the panel chain is the critical path:
+    // short panels (rows <= GPX_POTRF_TWO_PART_ROWS) stay one launch.
+    // (measured: n = 32768 fp32 96.7 -> 95.5 ms with 16384; n = 65536 fp64 unchanged; n = 16384 28.8 -> 29.3 with 12288)
+    const int64_t two_part_rows = env_i64("GPX_POTRF_TWO_PART_ROWS", 16384);
+    // (`done` is recorded behind the launch.  Carrying it as the completion signal of the dispatch packet itself --
+    //  hipExtLaunchKernelGGL(..., stopEvent) -- saves ~2.5 us per panel (tools/sync_probe.hip) and was tried; one run of
+    //  the parity suite then produced a wrong log_lh at n = 1990 that never reproduced.  Not worth 1 %: dropped.)
+    hipEvent_t record_after = done;
+    if (rows > two_part_rows && (int64_t)grid.x > nsteps) {
+        hipLaunchKernelGGL((panel_res_kernel<T>), dim3((unsigned)nsteps, grid.y), dim3(256), 0, st, A, lda, n, r0, c0, nsteps, info_dev,
+                           (T *)pub, flags, serial, bt ? bt->sA : (int64_t)0, (int)(kpre / IB), stamps, 0);
+        hipLaunchKernelGGL((panel_res_kernel<T>), dim3(grid.x - (unsigned)nsteps, grid.y), dim3(256), 0, st, A, lda, n, r0, c0, nsteps,
+                           info_dev, (T *)pub, flags, serial, bt ? bt->sA : (int64_t)0, (int)(kpre / IB), stamps, nsteps);
+    } else {
+        hipLaunchKernelGGL((panel_res_kernel<T>), grid, dim3(256), 0, st, A, lda, n, r0, c0, nsteps, info_dev, (T *)pub,
+                           flags, serial, bt ? bt->sA : (int64_t)0, (int)(kpre / IB), stamps, 0);
+    }
     GPX_LAUNCH_CHECK();
+    if (record_after) GPX_HIP(hipEventRecord(record_after, st));
     scr->last = st; scr->have_last = true; scr->last_on_side = (side != nullptr && st == side);
     if (!scr->last_on_side) GPX_HIP(hipEventRecord(scr->ev, st));               // (a caller's stream may not outlive this call)
     return GPX_OK;
@@ -534,10 +557,10 @@ static int panel_res_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int
 // kpre (a multiple of 64, <= c0): that many columns immediately to the left of the panel, rows [r0, n), are applied to
 // it first (P -= R R_d^T); the caller then omits that update
 int potrf_panel_res(int dtype, void *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int64_t kb, int *info_dev,
-                    hipStream_t st, const Batch *bt, int64_t kpre)
+                    hipStream_t st, const Batch *bt, int64_t kpre, hipEvent_t done)
 {
-    if (dtype == GPX_F64) return panel_res_t<double>((double *)A, lda, n, r0, c0, kb, info_dev, st, bt, kpre);
-    return panel_res_t<float>((float *)A, lda, n, r0, c0, kb, info_dev, st, bt, kpre);
+    if (dtype == GPX_F64) return panel_res_t<double>((double *)A, lda, n, r0, c0, kb, info_dev, st, bt, kpre, done);
+    return panel_res_t<float>((float *)A, lda, n, r0, c0, kb, info_dev, st, bt, kpre, done);
 }
 
 // fold the update by the columns to the left into the panel kernel?  (short panels only: a tall panel's workgroups

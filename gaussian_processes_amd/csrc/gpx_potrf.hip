@@ -288,14 +288,14 @@ static int leaf_scratch(size_t bytes, void **out)
 // "fused" (one launch per 64 columns, left-looking) and "lean" (leaf + one row kernel per 64 columns).
 template <typename T>
 static int potrf_panel_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int64_t kb, int *info_dev,
-                         hipStream_t st, int dtype, const Batch *bt, int64_t kpre = 0)
+                         hipStream_t st, int dtype, const Batch *bt, int64_t kpre = 0, hipEvent_t done = nullptr)
 {
     const int nbatch = bt ? bt->count : 1;
     const int64_t sM = bt ? bt->sA : 0;              // stride between the matrices of a batch
     // (c0 is a LOCAL column for a rank of the multi-GPU schedule: r0 != c0 there)
     if (kb % IB == 0 && kb <= panel_res_max()) {
         route_hit(RT_PANEL_RES);
-        return potrf_panel_res(dtype, A, lda, n, r0, c0, kb, info_dev, st, bt, kpre);
+        return potrf_panel_res(dtype, A, lda, n, r0, c0, kb, info_dev, st, bt, kpre, done);
     }
     if (kpre != 0) { set_error("potrf_panel: a folded update needs the resident panel route"); return GPX_ERR_ARG; }
     if (kb <= IB) {
@@ -348,6 +348,7 @@ static int potrf_panel_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, i
             Batch br; br.count = nbatch; br.sA = sM; br.sB = sM; br.sC = 0;
             GPX_TRY(trsm_rows(dtype, A + (r0 + jb) * lda + c0, lda, below, D, lda, jb, st, bt ? &br : nullptr));
         }
+        if (done) GPX_HIP(hipEventRecord(done, st));
         return GPX_OK;
     }
     const int64_t h = ((kb / IB + 1) / 2) * IB;          // left half, a multiple of 64
@@ -355,17 +356,17 @@ static int potrf_panel_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, i
     T *R = A + (r0 + h) * lda + c0;                       // rows below the left half's diagonal block
     // the right half takes the left half's update itself when it is one resident-kernel launch over few rows
     if (panel_res_fold(n - (r0 + h), h, kb - h, sizeof(T), lda, A))
-        return potrf_panel_t<T>(A, lda, n, r0 + h, c0 + h, kb - h, info_dev, st, dtype, bt, h);
+        return potrf_panel_t<T>(A, lda, n, r0 + h, c0 + h, kb - h, info_dev, st, dtype, bt, h, done);
     GPX_TRY(gemm_nt(dtype, n - (r0 + h), kb - h, h, R, lda, R, lda, R + h, lda, -1.0, GPX_LOWER, 0, 0, st, 0, 0, bt));
-    return potrf_panel_t<T>(A, lda, n, r0 + h, c0 + h, kb - h, info_dev, st, dtype, bt);
+    return potrf_panel_t<T>(A, lda, n, r0 + h, c0 + h, kb - h, info_dev, st, dtype, bt, 0, done);
 }
 
 int potrf_panel(int dtype, void *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int64_t kb,
-                int *info_dev, hipStream_t st, const Batch *bt, int64_t kpre)
+                int *info_dev, hipStream_t st, const Batch *bt, int64_t kpre, hipEvent_t done)
 {
     if (dtype == GPX_F64)
-        return potrf_panel_t<double>((double *)A, lda, n, r0, c0, kb, info_dev, st, dtype, bt, kpre);
-    return potrf_panel_t<float>((float *)A, lda, n, r0, c0, kb, info_dev, st, dtype, bt, kpre);
+        return potrf_panel_t<double>((double *)A, lda, n, r0, c0, kb, info_dev, st, dtype, bt, kpre, done);
+    return potrf_panel_t<float>((float *)A, lda, n, r0, c0, kb, info_dev, st, dtype, bt, kpre, done);
 }
 
 // side stream + event pool for the look-ahead (one set per host thread and device)
@@ -535,10 +536,10 @@ int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t
     const bool taper = env_i64("GPX_POTRF_TAPER", 1) != 0 && !env_set("GPX_POTRF_NB");
     auto nominal = [&](int64_t k0) -> int64_t { return (taper && !bt) ? std::min(nb, outer_block(n - k0)) : nb; };
     int64_t k0 = 0, kb = std::min(nominal(0), n);
-    GPX_TRY(potrf_panel(dtype, A, lda, N, 0, 0, kb, info_dev, q, bt));
     GPX_TRY(g_la.get(&ep));
-    GPX_HIP(hipEventRecord(ep, q));
+    GPX_TRY(potrf_panel(dtype, A, lda, N, 0, 0, kb, info_dev, q, bt, 0, ep));
     hipEvent_t e_rest = nullptr;                                // fires when the trailing update of the step before is done
+    const bool host_paced = !bt && n <= env_i64("GPX_POTRF_HOST_PACED", 12288);
     while (true) {
         const int64_t r = k0 + kb;
         if (masked && n - r <= reserve_below) GPX_TRY(switch_to(masked));
@@ -554,11 +555,18 @@ int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t
             GPX_HIP(hipEventRecord(e, st));
             GPX_HIP(hipStreamWaitEvent(q, e, 0));
         } else if (e_rest) {
+            // Host-paced panels (single matrices, n <= 12288: the sizes whose factorisation is a chain of panels).  A wait on an
+            // event of another stream that is still pending at ENQUEUE time becomes a barrier packet in front of the panel;
+            // the command processor takes ~6 us over it even when the event has long fired by then (tools/sync_probe.hip:
+            // 1.5 us between two kernels of a stream, 6.7 with a record, 15 - 18 with a cross-stream wait).  The update of
+            // step k - 1 is done well before panel k ends, so the HOST waits for it here -- the stream wait below then costs
+            // nothing and panel k + 1 queues directly behind panel k.  n = 8192: potrf 6.33 -> 6.09 ms, n = 4096: 2.19 ->
+            // 2.09, n = 2048: 0.99 -> 0.96 (tools/r3_ab.sh).  The call is then no longer a pure enqueue (include/gpx.h).
+            if (host_paced) GPX_HIP(hipEventSynchronize(e_rest));
             GPX_HIP(hipStreamWaitEvent(q, e_rest, 0));
         }
-        GPX_TRY(potrf_panel(dtype, A, lda, N, r, r, kb1, info_dev, q, bt, fold ? kb : 0));
         GPX_TRY(g_la.get(&ep));
-        GPX_HIP(hipEventRecord(ep, q));
+        GPX_TRY(potrf_panel(dtype, A, lda, N, r, r, kb1, info_dev, q, bt, fold ? kb : 0, ep));
         // ... while the rest of the trailing matrix is updated underneath it
         if (r + kb1 < n)
             GPX_TRY(syrk_bc(dtype, N, r, A, lda, r + kb1, n, at(k0, k0), lda, k0, kb, w1, 1, 0, st, info_dev, bt));

@@ -288,8 +288,9 @@ int gpx_gp_set_params(gpx_gp_t *gp, const double *params, double s);
  * full (n, n) HOST float64 matrix over; gpx_gp_fit then skips the kernel build. */
 int gpx_gp_set_K(gpx_gp_t *gp, const double *Kxx, int64_t ld);
 /* kernel build (lower) -> potrf -> alpha -> logdet, y^T alpha.  info != NULL: *info (HOST)
- * is filled and the call returns after the fit has completed.  info == NULL: the fit is only
- * ENQUEUED on the handle's stream (asynchronous); the next gpx_gp_* getter synchronises. */
+ * is filled and the call returns after the fit has completed.  info == NULL: the call returns without waiting for
+ * the end of the fit (the next gpx_gp_* getter synchronises); for n <= 12288 it paces its panel launches on the
+ * device's progress, so it returns when most of the factorisation has run, not at once. */
 int gpx_gp_fit(gpx_gp_t *gp, int *info);
 /* log marginal likelihood with the reference's conventions (gp/gp.py:360-367,
  * gp_c.pyx:17-31): -inf when the factorisation failed or logdet < MIN. */
