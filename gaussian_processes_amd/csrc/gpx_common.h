@@ -144,6 +144,9 @@ bool panel_res_fold(int64_t rows, int64_t kpre, int64_t kb, size_t es, int64_t l
 // Per-factor block operators of the single-right-hand-side solves (gpx_solve.hip, "operator form"): owned by
 // whoever owns the factor; `valid` must be cleared whenever the factor changes.  nullptr: built per call.
 struct TrsvOps { void *buf = nullptr; size_t bytes = 0; bool valid = false; };
+// Build the operators of an n x n factor (n a multiple of 512) ahead of time on `st`; a later trsv_lower with these ops
+// takes the operator route whatever n is (the distributed solve prepares each diagonal block right after its panel).
+int trsv_ops_build(int dtype, const void *L, int64_t n, int64_t ldl, TrsvOps *ops, hipStream_t st);
 int trsv_lower(int dtype, const void *L, int64_t n, int64_t ldl, void *b, void *x, int transpose,
                hipStream_t st, const Batch *bt = nullptr,   // bt: sA = stride of L, sB = stride of b / x
                TrsvOps *ops = nullptr);

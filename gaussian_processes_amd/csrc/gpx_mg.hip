@@ -3,17 +3,19 @@
 // collectives over xGMI (the reference has nothing distributed).
 //
 // Layout: 1-D block-cyclic block columns of width nb -- global block column j lives on rank j % P as local
-// block j / P (row-major local matrix: n rows x ceil(nblk / P) * nb columns).
+// block j / P (row-major local matrix: (n + 1) rows x ceil(nblk / P) * nb columns; row n carries y, see below).
 // Per panel k (right-looking, one-panel look-ahead, two panel buffers):
-//   owner(k)    factors its block column below the diagonal (potrf_panel) on the side stream Q,
-//               packs it into a contiguous (n - k0) x nb buffer (pack kernel),
-//   all ranks   receive it by a broadcast rooted at the owner, issued in ROW CHUNKS on Q: the owner of
+//   owner(k)    factors its block column below the diagonal (potrf_panel) on the panel stream Q,
+//               packs it into a contiguous (n + 1 - k0) x nb buffer (pack kernel),
+//   all ranks   receive it by a broadcast rooted at the owner, issued in ROW CHUNKS on the broadcast stream B
+//               (one collective per chunk, or scatter + all-gather by grouped send / recv): the owner of
 //               panel k+1 applies chunk c to its block column k+1 (main stream S) as soon as chunk c has
 //               landed, so that its column update hides under the tail of the transfer,
 //   all ranks   update their remaining block columns with the whole panel (one launch, syrk_bc) on S
-//               while Q already factors / broadcasts panel k+1.
-// Solves walk the block columns (one small all-reduce / broadcast per block), logdet and the posterior
-// mean are local sums plus one all-reduce.
+//               while Q already factors and B broadcasts panel k+1.
+// Solve: y rides along as row n of every block column (forward substitution happens inside the factorisation);
+// the backward substitution is right-looking over the block columns, one nb-vector broadcast per block.
+// logdet and the posterior mean are local sums plus one all-reduce.
 //
 // Communicator back-ends: (1) RCCL, loaded with dlopen at first use -- libgpx.so itself has no link-time
 // dependency on it, single-GPU users never load it; ranks are joined through an ncclUniqueId that the
@@ -42,11 +44,6 @@ static_assert(sizeof(ncclUniqueId) == GPX_MG_ID_BYTES, "ncclUniqueId is 128 byte
 
 extern "C" int gpx_d_mean(int dtype, int kernel, const void *xo, int64_t m, const void *x, int64_t n, int d,
                           const double *params, const void *alpha, void *out, void *stream);
-extern "C" int gpx_d_trsv_lower_cols(int dtype, const void *L, int64_t n, int64_t ldl, int64_t ncols, void *b,
-                                     void *x, void *stream);
-extern "C" int gpx_d_panel_gemv_t(int dtype, const void *Lp, int64_t ldl, int64_t rows, int64_t ncols,
-                                  const void *x, void *y, void *work, void *stream);
-
 namespace gpx {
 
 // ---- RCCL through dlopen ---------------------------------------------------------------------------
@@ -129,6 +126,38 @@ __global__ __launch_bounds__(256) void pack_panel_kernel(const T *__restrict__ A
     }
 }
 
+// y[c] -= sum_{r < rows} A[r, c] * x[r]  for c < ncols: a block of `rows` (<= 1024) rows of this rank's local matrix
+// against one finished block of alpha -- the right-looking step of the distributed back substitution.  64 columns per
+// workgroup (one per lane: coalesced rows), the rows split over the four waves, partial sums combined in a fixed order.
+template <typename T>
+__global__ __launch_bounds__(256) void rowblock_gemv_t_kernel(const T *__restrict__ A, int64_t ld, int rows, int64_t ncols,
+                                                              const T *__restrict__ x, T *__restrict__ y)
+{
+    __shared__ T sx[1024];
+    __shared__ double part[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < rows; i += 256) sx[i] = x[i];
+    __syncthreads();
+    const int64_t c = (int64_t)blockIdx.x * 64 + lane;
+    const int per = (rows + 3) / 4, ra = wave * per, rb = min(rows, ra + per);
+    double acc = 0.0;
+    if (c < ncols) {
+        const T *col = A + c;
+        int r = ra;
+        for (; r + 8 <= rb; r += 8) {
+            T v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = col[(int64_t)(r + u) * ld];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = fma((double)v[u], (double)sx[r + u], acc);
+        }
+        for (; r < rb; ++r) acc = fma((double)col[(int64_t)r * ld], (double)sx[r], acc);
+    }
+    part[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && c < ncols) y[c] = (T)((double)y[c] - (((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane]));
+}
+
 template <typename T>
 __global__ void axpy_slot_kernel(double *__restrict__ acc, const double *__restrict__ v)
 {
@@ -151,9 +180,10 @@ typedef int (*gpx_mg_allreduce_fn)(void *user, void *dev_ptr, size_t count, int 
 
 struct gpx_mg {
     int device, dtype, kernel, d, world, rank;
-    int64_t n, nb, nblk, ncols_local, ld;
+    int64_t n, nr, nb, nblk, ncols_local, ld;    // nr = n + 1: y rides along as row n of the local matrix (the forward solve)
     size_t es;
     std::vector<int64_t> my_blocks;
+    std::vector<gpx::TrsvOps> ops;                // per owned block column: inverse of its diagonal block (backward solve)
     // communicator
     ncclComm_t comm = nullptr;
     gpx_mg_bcast_fn cb_bcast = nullptr;
@@ -164,9 +194,8 @@ struct gpx_mg {
     void *sag_tmp = nullptr; size_t sag_tmp_bytes = 0;   // callback back-end only: where a rank drops pieces that are not its own
     int debug_info = 0;                           // gpx_debug_mg_inject_info: written into the device info word after the factorisation
     // device state
-    void *A = nullptr, *pbuf[2] = {nullptr, nullptr}, *x = nullptr, *y = nullptr, *w = nullptr, *z = nullptr,
-         *alpha = nullptr, *tmp = nullptr;
-    double *work = nullptr, *scal = nullptr;      // scal: [0] logdet block [1] y^T alpha [2] logdet acc [3] spare
+    void *A = nullptr, *pbuf[2] = {nullptr, nullptr}, *x = nullptr, *y = nullptr, *alpha = nullptr, *tmp = nullptr;
+    double *scal = nullptr;                       // scal: [0] logdet block [1] y^T alpha [2] logdet acc [3] spare
     int *info = nullptr;                          // [0] info [1] reduction key
     hipStream_t S = nullptr, Q = nullptr, B = nullptr;   // main (updates, solves) / panel (factor, pack) / panel broadcasts
     std::vector<hipEvent_t> ev;                   // sync events (no timing), reused round-robin per fit
@@ -346,14 +375,17 @@ static int mg_pack(gpx_mg *g, int64_t r0, int64_t cl, int64_t rows, int64_t kb, 
 static int mg_factor_and_bcast(gpx_mg *g, int64_t j, void *buf, hipEvent_t buf_free, std::vector<hipEvent_t> *chunk_ev,
                                std::vector<int64_t> *chunk_end)
 {
-    const int64_t r0 = g->k0(j), kb = g->kb(j), rows = g->n - r0;
+    const int64_t r0 = g->k0(j), kb = g->kb(j), rows = g->nr - r0;   // (the rider row n travels with every panel)
     hipStream_t Q = g->Q, B = g->B;
     if (g->owner(j) == g->rank) {
         const int64_t cl = g->local_col(j);
-        { MgTimer t(g, T_PANEL, Q); GPX_TRY(potrf_panel(g->dtype, g->A, g->ld, g->n, r0, cl, kb, g->info, Q)); }
+        { MgTimer t(g, T_PANEL, Q); GPX_TRY(potrf_panel(g->dtype, g->A, g->ld, g->nr, r0, cl, kb, g->info, Q)); }
         if (buf_free) GPX_HIP(hipStreamWaitEvent(Q, buf_free, 0));
         { MgTimer t(g, T_PACK, Q); GPX_TRY(mg_pack(g, r0, cl, rows, kb, buf, Q)); }
         GPX_TRY(mg_order(g, Q, B));
+        // the inverse of this diagonal block for the backward solve, built here, off everybody's critical path (the
+        // broadcast is already ordered behind the pack; this rank's next panel is `world` steps away)
+        GPX_TRY(trsv_ops_build(g->dtype, g->Aat(r0, cl), kb, g->ld, &g->ops[(size_t)(j / g->world)], Q));
     } else if (buf_free) {
         GPX_HIP(hipStreamWaitEvent(B, buf_free, 0));
     }
@@ -389,6 +421,11 @@ static int mg_build(gpx_mg *g, const double *params, double s)
         GPX_TRY(kmat(g->dtype, g->kernel, GPX_K, (const char *)g->x + (size_t)r0 * g->d * g->es, g->n - r0,
                      (const char *)g->x + (size_t)r0 * g->d * g->es, kb, g->d, params, s * s, GPX_LOWER, g->Aat(r0, cl),
                      g->ld, g->S));
+        // row n of the block column: y of its columns.  It takes part in every panel and update as one more ROW, which
+        // is forward substitution block by block: when the factor is done row n holds L^-1 y (gpx_gp_fit does the same
+        // on one GPU up to n = 16384; here it replaces a chain of nblk all-reduces)
+        GPX_HIP(hipMemcpyAsync(g->Aat(g->n, cl), (const char *)g->y + (size_t)r0 * g->es, (size_t)kb * g->es,
+                               hipMemcpyDeviceToDevice, g->S));
     }
     return GPX_OK;
 }
@@ -403,7 +440,7 @@ static int mg_factor(gpx_mg *g)
     hipEvent_t readers_done[2] = {nullptr, nullptr};              // last update that read pbuf[i]
     for (int64_t k = 0; k < g->nblk; ++k) {
         const int64_t k0 = g->k0(k), kb = g->kb(k), r = k0 + kb;
-        if (r >= g->n) {                                          // last panel: S must see it before the solves
+        if (r >= g->n) {                                          // last panel: S must see it before the solve
             GPX_HIP(hipStreamWaitEvent(S, cev.back(), 0));
             break;
         }
@@ -421,7 +458,7 @@ static int mg_factor(gpx_mg *g)
                 GPX_HIP(hipStreamWaitEvent(S, cev[c], 0));
                 if (hi > lo)
                     GPX_TRY(syrk_bc(g->dtype, hi, lo, g->A, g->ld, cl, cl + g->nb, Pk, g->nb, k0, kb, g->nb, g->world,
-                                    g->rank, S));
+                                    g->rank, S));       // (hi reaches nr with the last chunk: the rider row is its last row)
                 lo = std::max(lo, hi);
             }
             GPX_TRY(mg_order(g, S, Q));
@@ -433,7 +470,7 @@ static int mg_factor(gpx_mg *g)
         GPX_TRY(mg_factor_and_bcast(g, nxt, g->pbuf[nxt % 2], readers_done[nxt % 2], &nev, &nend));   // (update k-1 has to let go of that buffer)
         if (jl_first >= 0) {
             MgTimer t(g, T_UPDATE, S);
-            GPX_TRY(syrk_bc(g->dtype, g->n, r, g->A, g->ld, jl_first * g->nb, g->ncols_local, Pk, g->nb, k0, kb, g->nb,
+            GPX_TRY(syrk_bc(g->dtype, g->nr, r, g->A, g->ld, jl_first * g->nb, g->ncols_local, Pk, g->nb, k0, kb, g->nb,
                             g->world, g->rank, S));
         }
         hipEvent_t e;
@@ -452,31 +489,41 @@ static int mg_factor(gpx_mg *g)
     return GPX_OK;
 }
 
+// alpha = K^-1 y.  The forward substitution L t = y rode along in the factorisation (row n of the local matrices holds
+// this rank's blocks of t).  Backward, L^T alpha = t, right-looking over the block columns from the last: the owner of
+// block j finishes alpha_j from its block of the running right-hand side -- one launch with the inverse of the diagonal
+// block prepared after the panel (nb a multiple of 512; the step route otherwise) --, broadcasts it (nb numbers), and
+// every rank subtracts  L[rows of block j, its columns left of block j]^T alpha_j  from its part of the right-hand side
+// in one launch.  Per block: two small launches and one broadcast on the chain; round 2 walked the blocks twice with an
+// all-reduce, a broadcast and five launches each (25 ms at N = 65536 with one rank; measured now: DESIGN section 5).
 static int mg_solve(gpx_mg *g)
 {
     hipStream_t S = g->S;
     MgTimer t(g, T_SOLVE, S);
     const int64_t n = g->n;
-    if (g->rank == 0) GPX_HIP(hipMemcpyAsync(g->w, g->y, (size_t)n * g->es, hipMemcpyDeviceToDevice, S));
-    else GPX_HIP(hipMemsetAsync(g->w, 0, (size_t)n * g->es, S));
-    for (int64_t j = 0; j < g->nblk; ++j) {                        // forward: L z = y
-        const int64_t r0 = g->k0(j), kb = g->kb(j);
-        GPX_TRY(mg_allreduce(g, (char *)g->w + (size_t)r0 * g->es, (size_t)kb, g->dtype, 0, S));
-        if (g->owner(j) == g->rank)
-            GPX_TRY(gpx_d_trsv_lower_cols(g->dtype, g->Aat(r0, g->local_col(j)), n - r0, g->ld, kb,
-                                          (char *)g->w + (size_t)r0 * g->es, (char *)g->z + (size_t)r0 * g->es, (void *)S));
-    }
-    for (int64_t j = g->nblk - 1; j >= 0; --j) {                   // backward: L^T alpha = z
+    char *rhs = g->Aat(n, 0);                                      // row n: this rank's blocks of L^-1 y, then of the running rhs
+    for (int64_t j = g->nblk - 1; j >= 0; --j) {
         const int64_t r0 = g->k0(j), kb = g->kb(j);
         if (g->owner(j) == g->rank) {
-            const int64_t cl = g->local_col(j), below = n - r0 - kb;
-            GPX_HIP(hipMemcpyAsync(g->tmp, (char *)g->z + (size_t)r0 * g->es, (size_t)kb * g->es, hipMemcpyDeviceToDevice, S));
-            if (below > 0)
-                GPX_TRY(gpx_d_panel_gemv_t(g->dtype, g->Aat(r0 + kb, cl), g->ld, below, kb,
-                                           (char *)g->alpha + (size_t)(r0 + kb) * g->es, g->tmp, g->work, (void *)S));
-            GPX_TRY(trsv_lower(g->dtype, g->Aat(r0, cl), kb, g->ld, g->tmp, (char *)g->alpha + (size_t)r0 * g->es, 1, S));
+            const int64_t cl = g->local_col(j);
+            GPX_HIP(hipMemcpyAsync(g->tmp, rhs + (size_t)cl * g->es, (size_t)kb * g->es, hipMemcpyDeviceToDevice, S));
+            GPX_TRY(trsv_lower(g->dtype, g->Aat(r0, cl), kb, g->ld, g->tmp, (char *)g->alpha + (size_t)r0 * g->es, 1, S, nullptr,
+                               &g->ops[(size_t)(j / g->world)]));
         }
         GPX_TRY(mg_bcast(g, (char *)g->alpha + (size_t)r0 * g->es, (size_t)kb, (int)g->owner(j), S));
+        int64_t before = 0;                                          // this rank's block columns left of block j
+        for (int64_t b : g->my_blocks) if (b < j) ++before;
+        const int64_t ncols = before * g->nb;
+        if (ncols > 0) {
+            const unsigned blocks = (unsigned)cdiv(ncols, 64);
+            if (g->dtype == GPX_F64)
+                hipLaunchKernelGGL((rowblock_gemv_t_kernel<double>), dim3(blocks), dim3(256), 0, S, (const double *)g->Aat(r0, 0), g->ld,
+                                   (int)kb, ncols, (const double *)g->alpha + r0, (double *)rhs);
+            else
+                hipLaunchKernelGGL((rowblock_gemv_t_kernel<float>), dim3(blocks), dim3(256), 0, S, (const float *)g->Aat(r0, 0), g->ld,
+                                   (int)kb, ncols, (const float *)g->alpha + r0, (float *)rhs);
+            GPX_LAUNCH_CHECK();
+        }
     }
     return GPX_OK;
 }
@@ -514,16 +561,13 @@ static int mg_alloc(gpx_mg *g)
     const size_t es = g->es;
     const int64_t n = g->n;
 #define MG_ALLOC(field, bytes) GPX_HIP(hipMalloc((void **)&g->field, (bytes) ? (bytes) : 16))
-    MG_ALLOC(A, (size_t)n * g->ld * es);
-    MG_ALLOC(pbuf[0], (size_t)n * g->nb * es);
-    MG_ALLOC(pbuf[1], (size_t)n * g->nb * es);
+    MG_ALLOC(A, (size_t)g->nr * g->ld * es);
+    MG_ALLOC(pbuf[0], (size_t)g->nr * g->nb * es);
+    MG_ALLOC(pbuf[1], (size_t)g->nr * g->nb * es);
     MG_ALLOC(x, (size_t)n * g->d * es);
     MG_ALLOC(y, (size_t)n * es);
-    MG_ALLOC(w, (size_t)n * es);
-    MG_ALLOC(z, (size_t)n * es);
     MG_ALLOC(alpha, (size_t)n * es);
     MG_ALLOC(tmp, (size_t)g->nb * es);
-    MG_ALLOC(work, (size_t)std::max<int64_t>(1, cdiv(n, 256)) * g->nb * sizeof(double));
     MG_ALLOC(scal, 4 * sizeof(double));
     MG_ALLOC(info, 4 * sizeof(int));
 #undef MG_ALLOC
@@ -554,6 +598,8 @@ static int mg_new(gpx_mg **out, int dtype, int kernel, int64_t n, int d, int64_t
     for (int64_t j = rank; j < g->nblk; j += world) g->my_blocks.push_back(j);
     g->ncols_local = std::max<int64_t>(1, (int64_t)g->my_blocks.size()) * nb;
     g->ld = g->ncols_local;
+    g->nr = n + 1;
+    g->ops.resize(std::max<size_t>(1, g->my_blocks.size()));
     g->bcast_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(16, env_i64("GPX_MG_BCAST_CHUNKS", 4)));
     g->timing = !env_set("GPX_MG_NO_TIMING");
     if (const char *e = getenv("GPX_MG_BCAST")) g->bcast_sag = strcmp(e, "sag") == 0;
@@ -589,8 +635,9 @@ int gpx_mg_destroy(gpx_mg_t *g)
     if (g->Q) (void)hipStreamSynchronize(g->Q);
     if (g->B) (void)hipStreamSynchronize(g->B);
     if (g->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(g->comm);
-    void *bufs[] = {g->A, g->pbuf[0], g->pbuf[1], g->x, g->y, g->w, g->z, g->alpha, g->tmp, g->work, g->scal, g->info, g->sag_tmp};
+    void *bufs[] = {g->A, g->pbuf[0], g->pbuf[1], g->x, g->y, g->alpha, g->tmp, g->scal, g->info, g->sag_tmp};
     for (void *b : bufs) if (b) (void)hipFree(b);
+    for (gpx::TrsvOps &o : g->ops) if (o.buf) (void)hipFree(o.buf);
     for (hipEvent_t e : g->ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : g->tev) (void)hipEventDestroy(e);
     if (g->S) (void)hipStreamDestroy(g->S);

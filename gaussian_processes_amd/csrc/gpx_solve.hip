@@ -634,8 +634,9 @@ static int trsv_t(const T *L, int64_t n, int64_t ldl, T *b, T *x, int transpose,
     const int64_t nb = cdiv(ncols, TB);
     auto width = [&](int64_t blk) { return (int)std::min<int64_t>(TB, ncols - blk * TB); };
     // operator form: square systems of at least two full blocks, aligned rows, one system
-    if (trsv_ops_enabled() && !bt && ncols == n && n >= trsv_ops_min_n() && aligned && ldl % (16 / (int64_t)sizeof(T)) == 0 &&
-        ((uintptr_t)L) % 16 == 0) {
+    const bool prebuilt = ops && ops->valid && ops->buf && n % OB == 0 && ops->bytes >= trsv_ops_bytes(dtype, n);
+    if (trsv_ops_enabled() && !bt && ncols == n && (n >= trsv_ops_min_n() || prebuilt) && aligned &&
+        ldl % (16 / (int64_t)sizeof(T)) == 0 && ((uintptr_t)L) % 16 == 0) {
         const int64_t nfull = n / OB, rag = n - nfull * OB, BS = (int64_t)OB * OB;
         route_hit(RT_TRSV_OPS);
         void *buf = nullptr;
@@ -739,6 +740,23 @@ int trsv_lower(int dtype, const void *L, int64_t n, int64_t ldl, void *b, void *
     if (dtype == GPX_F64)
         return trsv_t<double>((const double *)L, n, ldl, (double *)b, (double *)x, transpose, st, -1, bt, ops, dtype);
     return trsv_t<float>((const float *)L, n, ldl, (float *)b, (float *)x, transpose, st, -1, bt, ops, dtype);
+}
+
+int trsv_ops_build(int dtype, const void *L, int64_t n, int64_t ldl, TrsvOps *ops, hipStream_t st)
+{
+    if (!ops || n < OB || n % OB != 0 || !trsv_ops_enabled() || ldl % (16 / (int64_t)esize(dtype)) != 0 || ((uintptr_t)L) % 16 != 0)
+        return GPX_OK;                                               // not eligible: the solve takes the step route
+    const size_t need = trsv_ops_bytes(dtype, n);
+    if (!ops->buf || ops->bytes < need) {
+        if (ops->buf) { GPX_HIP(hipStreamSynchronize(st)); (void)hipFree(ops->buf); ops->buf = nullptr; }
+        GPX_HIP(hipMalloc(&ops->buf, need));
+        ops->bytes = need;
+    }
+    ops->valid = false;
+    if (dtype == GPX_F64) GPX_TRY(trsv_ops_prepare<double>((const double *)L, n, ldl, ops->buf, st, dtype));
+    else GPX_TRY(trsv_ops_prepare<float>((const float *)L, n, ldl, ops->buf, st, dtype));
+    ops->valid = true;
+    return GPX_OK;
 }
 
 int trsv_lower_cols(int dtype, const void *L, int64_t n, int64_t ldl, int64_t ncols, void *b, void *x,
