@@ -5,6 +5,12 @@ module keeps the same schedule written out in Python over an `ops` object: `HipO
 points on torch CUDA tensors / streams, `CpuOps` (tests/_dist_helpers.py) emulates them on the CPU so that the
 ownership maps, buffer reuse and the order of the collectives are exercised by the gloo tests without a GPU.
 It lived in the product package until round 3; nothing in gaussian_processes_amd/ imports it.
+
+Its solves are the ROUND-2 formulation (forward substitution block by block with one all-reduce per block, backward
+substitution with a transposed panel product per block: `gpx_d_trsv_lower_cols`, `gpx_d_panel_gemv_t`, still
+exported building blocks of the ABI); the C schedule has since moved on (y rides along as a row of the matrix, the
+backward sweep is right-looking -- csrc/gpx_mg.hip).  Both must produce the oracle's alpha: two independent
+formulations over the same layout maps, checked against the same numbers.
 """
 import ctypes
 import math
