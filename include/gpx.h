@@ -209,7 +209,12 @@ int gpx_d_gemm_nt(int dtype, int64_t M, int64_t N, int64_t K, double alpha,
  * gp/gp.py:294 -> LAPACK dpotrf).  Only the lower triangle of A is read; the
  * strict upper triangle is left untouched (use gpx_d_tril to zero it).
  * info_dev: DEVICE int; 0 on success, j (1-based) if the j-th leading minor is
- * not positive definite (pivot <= 0 or NaN), as LAPACK reports it. */
+ * not positive definite (pivot <= 0 or NaN), as LAPACK reports it; negative: an
+ * internal failure (the host entry points turn that into GPX_ERR_INTERNAL).
+ * For n <= 12288 the call paces its panel launches on the device's progress (it
+ * waits on the host for the previous step's update instead of putting a barrier
+ * packet in front of every panel): it returns when most of the factorisation
+ * has run, not at once; the result is still only complete in stream order. */
 int gpx_d_potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev,
                 void *stream);
 

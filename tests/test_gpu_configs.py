@@ -366,3 +366,35 @@ def test_checkpoint_header_is_validated_and_writes_are_atomic(tmp_path):
     with pytest.raises(ValueError):
         g.save_fitted(str(tmp_path / "no_such_dir" / "x.gpx"))
     assert not os.path.exists(str(tmp_path / "no_such_dir"))
+
+
+def test_bench_three_ranks_choose_the_panel_broadcast_by_measurement():
+    """`python bench.py --gpus 3` from a plain invocation, the three ranks sharing GPU 0 over host callbacks: with more
+    than two ranks the run times one untimed fit with each panel-broadcast algorithm after the warm-up, the slower
+    rank decides and every rank takes the same one; the line says what the communicator reports per rank
+    (`rccl_nranks` = 0 here: no RCCL communicator behind callbacks), which mode won, and still matches the oracle."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "GPX_MG_BCAST", "GPX_BENCH_NO_BCAST_TUNE"):
+        env.pop(k, None)
+    env.update(GPX_DIST_BACKEND="gloo", GPX_BENCH_SINGLE_DEVICE="1", GPX_POTRF_NB="256")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    N, d = 6000, 4
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--problem-n", str(N),
+                        "--problem-d", str(d), "--problem-m", "64", "--steps", "1", "--warmup", "1"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 3 and out["rccl_nranks"] == 0 and len(out["comm_info_per_rank"]) == 3
+    assert [c["rank"] for c in out["comm_info_per_rank"]] == [0, 1, 2]
+    tune = out["panel_bcast_autotune"]
+    assert tune["one_collective_s"] > 0 and tune["scatter_allgather_s"] > 0
+    assert out["panel_bcast"].startswith("scatter") == (tune["chosen"] == "scatter+allgather")
+    X, y, _ = orc.synth_inputs(N, d, 64)
+    o = orc.OracleGP("gaussian", (1.0, 0.5 * np.sqrt(d)), X, y, 1.0)
+    np.testing.assert_allclose(out["log_lh"], o.log_lh, rtol=1e-10)
+    assert out["check"]["max_abs_residual_K_alpha_minus_y_over_max_y"] < 1e-9
