@@ -358,6 +358,12 @@ __device__ __forceinline__ void load_frag32(const T *__restrict__ p, T (&f)[PM<T
 // ~60 dependent fp64 operations, 8 LDS reads, 12 writes), strip solve + LDS 460, updates 510, barriers -- = 14.7 us a
 // leaf against 21.5 us for the pivot-wave VALU sweep (factor64_pipe), and no layout conversion on the way in or out.  Only the lower triangle of the block is read (the upper part of a diagonal block is stale in a
 // lower-only factorisation) and only it is meaningful on return; x must hold the identity on entry.
+// T = float (round 3): the same sweep on v_mfma_f32_16x16x4_f32.  Its accumulator layout differs -- lane (li, lq)
+// holds rows 4 lq + r of column li, not rows lq + 4 r -- which only matters where the fp64 form uses accumulator
+// registers as an MFMA operand "in place": the step's four rows of X sit in ONE lane group there, so they go through
+// LDS once (sXraw) to become the B operand and come back from sXd; both hops are inside the owning wave and one step
+// behind the pivot, off the critical path.  Everything else is layout-blind (operands come from LDS by row / column
+// index, results go back into the tile they came from) and is written with PM<T>::row().
 __device__ __forceinline__ void factor64_mfma(PM<double>::v4 (&a)[4], PM<double>::v4 (&x)[4], int64_t j0, int *__restrict__ info,
                                               int wave, int lane, unsigned long long *stamps = nullptr)
 {
@@ -511,5 +517,225 @@ __device__ __forceinline__ void factor64_mfma(PM<double>::v4 (&a)[4], PM<double>
         }
     }
 }
+
+
+template <typename T>
+__device__ __forceinline__ void factor64_mfma_t(typename PM<T>::v4 (&a)[4], typename PM<T>::v4 (&x)[4], int64_t j0,
+                                              int *__restrict__ info, int wave, int lane, unsigned long long *stamps = nullptr)
+{
+    typedef PM<T> M;
+    typedef typename M::v4 v4;
+    constexpr bool F64 = sizeof(T) == 8;
+    __shared__ __attribute__((aligned(16))) T sS[IB][4];        // the step's column strip as it is (S1) -- rows of the block
+    __shared__ T sLn[IB][4];              // the step's finished strip of L
+    __shared__ __attribute__((aligned(16))) T sWi[2][4][4];     // inv(L_dd) of the step (by parity), zero above the diagonal
+    __shared__ __attribute__((aligned(16))) T sDd[4][4];        // L_dd, zero above the diagonal
+    __shared__ T sXd[4][IB];              // four rows of X (of the step before: the X side runs one step behind)
+    __shared__ T sXraw[4][IB];            // fp32 only: the same four rows before inv(L_dd) is applied
+    const int li = lane & 15, lq = lane >> 4;
+    const v4 zero = {(T)0, (T)0, (T)0, (T)0};
+    if (threadIdx.x < 16) {
+        sWi[0][threadIdx.x >> 2][threadIdx.x & 3] = (T)0; sWi[1][threadIdx.x >> 2][threadIdx.x & 3] = (T)0;
+        sDd[threadIdx.x >> 2][threadIdx.x & 3] = (T)0;
+    }
+    // (the parts above the diagonal stay zero: the pivot lane only ever writes the lower ones; the first barrier of
+    //  step 0 orders this against the first reads)
+    T al_prev = (T)0;                     // the previous step's strip as (negated, masked) A operand: its X update is applied one step late
+    // X_d <- inv(L_dd) X_d for the four rows c0p .. c0p + 3 of X (held by wave jjp), by the wave that owns them
+    // (publish: the finished rows also go to sXd for the other waves' rank-4 update of X; not after the last step, when
+    //  nobody needs them and the others may still be reading the rows of the step before)
+    auto finish_x_rows = [&](int jjp, int qp, int parity, bool publish) {
+        const T wprev = (li < 4) ? sWi[parity][li][lq] : (T)0;
+        if constexpr (F64) {
+            // fp64: register qp of lane (li, lq) IS X[c0p + lq][col li]: the B operand is in place, the result lands back
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                if (jj > jjp) continue;                         // X is lower triangular: nothing to the right of the step
+                const v4 u = M::mfma(wprev, x[jj][qp], zero);
+                x[jj][qp] = u[0];
+                if (publish) sXd[lq][16 * jj + li] = u[0];
+            }
+        } else {
+            // fp32: the four rows are registers 0..3 of lane group qp -- through LDS (sXraw, private to this wave) to
+            // become the operand, and back the same way
+            if (lq == qp) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sXraw[r][16 * jj + li] = x[jj][r];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (one wave: program order + the wait orders its own LDS traffic)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                if (jj > jjp) continue;
+                const v4 u = M::mfma(wprev, sXraw[lq][16 * jj + li], zero);     // rows 0..3 of the result: lane group 0, registers 0..3
+                if (lq == 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        sXraw[r][16 * jj + li] = u[r];
+                        if (publish) sXd[r][16 * jj + li] = u[r];
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lq == qp) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    if (jj > jjp) continue;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[jj][r] = sXraw[r][16 * jj + li];
+                }
+            }
+        }
+    };
+    // The X side (the step's four rows X_d <- inv(L_dd) X_d by the wave that owns them, then x -= L_s X_d) is not on the
+    // path to the next pivot.  It runs ONE STEP BEHIND: X_d of step jt - 1 is formed while the pivot lane -- in another
+    // wave -- factors the diagonal tile of step jt, and its rank-4 update joins the accumulator updates of step jt.
+    // fully unrolled: the tile (jj0) and register (q) the step touches must be compile-time constants, or the
+    // accumulator arrays go to scratch memory (first version: 544 bytes of scratch a lane, 48 us a leaf)
+#pragma unroll
+    for (int jt = 0; jt < IB / 4; ++jt) {
+        const int c0 = 4 * jt, jj0 = jt >> 2, q = jt & 3;
+        const int jjp = (jt - 1) >> 2, qp = (jt - 1) & 3;        // the step before (jt > 0)
+        const int pw = (jj0 + 1) & 3;                              // the pivot lane's wave: never the wave busy with X_d
+        // ---- S1 ----
+        if ((li >> 2) == q) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sS[16 * wave + M::row(lane, r)][li & 3] = a[jj0][r];
+        }
+        __syncthreads();
+        if (stamps && jt == 9 && threadIdx.x == 0) stamps[0] = __builtin_amdgcn_s_memtime();
+        // ---- S2 ----
+        if (wave == pw && lane == 0) {
+            T d[4][4], wi[4][4], rk[4];
+            int bad = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                T row[4];
+                if constexpr (F64) load_frag32<T>(&sS[c0 + i][0], row);       // two 16-byte LDS reads a row
+                else { struct alignas(16) Q4 { T v[4]; }; const Q4 qv = *reinterpret_cast<const Q4 *>(&sS[c0 + i][0]); memcpy(row, &qv, 16); }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) d[i][k] = (k <= i) ? row[k] : (T)0;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const T piv = d[k][k];
+                if (bad == 0 && !(piv > (T)0)) bad = c0 + k + 1;                      // also catches NaN; reported after the chain
+                const T rinv = fast_rsqrt(piv);
+                rk[k] = rinv;
+                d[k][k] = piv * rinv;
+#pragma unroll
+                for (int r = k + 1; r < 4; ++r) d[r][k] *= rinv;
+#pragma unroll
+                for (int c = k + 1; c < 4; ++c)
+#pragma unroll
+                    for (int r = c; r < 4; ++r) d[r][c] = fma(-d[r][k], d[c][k], d[r][c]);
+            }
+            // inv(L_dd): column by column, wi[i][k] = -rk[i] * sum_{m = k}^{i - 1} l[i][m] wi[m][k]
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (i < k) { wi[i][k] = (T)0; continue; }
+                    if (i == k) { wi[i][k] = rk[i]; continue; }
+                    T s = (T)0;
+#pragma unroll
+                    for (int m = k; m < i; ++m) s = fma(d[i][m], wi[m][k], s);
+                    wi[i][k] = -rk[i] * s;
+                }
+            }
+            // lower parts only, in 16-byte pieces where a row has a pair (fp64) / one 16-byte row (fp32: the zeros above the
+            // diagonal are written too, they are zero anyway)
+            if constexpr (F64) {
+                struct alignas(16) D2 { T v[2]; };
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int k = 0; k + 1 <= i; k += 2) {
+                        *reinterpret_cast<D2 *>(&sWi[jt & 1][i][k]) = D2{{wi[i][k], wi[i][k + 1]}};
+                        *reinterpret_cast<D2 *>(&sDd[i][k]) = D2{{d[i][k], (k + 1 <= i) ? d[i][k + 1] : (T)0}};
+                    }
+                    if ((i & 1) == 0) { sWi[jt & 1][i][i] = wi[i][i]; sDd[i][i] = d[i][i]; }
+                }
+            } else {
+                struct alignas(16) Q4 { T v[4]; };
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    Q4 qw, qd;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { qw.v[k] = (k <= i) ? wi[i][k] : (T)0; qd.v[k] = (k <= i) ? d[i][k] : (T)0; }
+                    *reinterpret_cast<Q4 *>(&sWi[jt & 1][i][0]) = qw;
+                    *reinterpret_cast<Q4 *>(&sDd[i][0]) = qd;
+                }
+            }
+            if (bad != 0) atomicCAS(info, 0, (int)(j0 + bad));                         // first failure wins
+        }
+        if (jt > 0 && wave == jjp) finish_x_rows(jjp, qp, (jt - 1) & 1, true);       // (its inverse tile is still in the other half of sWi)
+        if (stamps && jt == 9 && wave == pw && lane == 0) stamps[1] = __builtin_amdgcn_s_memtime();
+        __syncthreads();
+        if (stamps && jt == 9 && threadIdx.x == 0) stamps[2] = __builtin_amdgcn_s_memtime();
+        // ---- S3: new strip = strip . inv(L_dd)^T ----
+        const T winv = (li < 4) ? sWi[jt & 1][li][lq] : (T)0;   // B operand: B[k][n] = Winv[n][k]
+        const v4 t = M::mfma(sS[16 * wave + li][lq], winv, zero);
+        // ---- S4 ----
+        if (li < 4) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * wave + M::row(lane, r);
+                sLn[row][li] = (row >= c0 && row < c0 + 4) ? sDd[row - c0][li] : t[r];
+            }
+        }
+        if (stamps && jt == 9 && threadIdx.x == 0) stamps[3] = __builtin_amdgcn_s_memtime();
+        __syncthreads();
+        if (stamps && jt == 9 && threadIdx.x == 0) stamps[4] = __builtin_amdgcn_s_memtime();
+        // ---- S5 ----
+        if ((li >> 2) == q) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[jj0][r] = sLn[16 * wave + M::row(lane, r)][li & 3];
+        }
+        const int arow = 16 * wave + li;
+        const T al = (arow > c0 + 3) ? -sLn[arow][lq] : (T)0;   // rows at or above the step: no update
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            // the tile that holds the NEXT step's strip first
+            const int tj = (jj + ((jt + 1) >> 2)) & 3;
+            if (tj >= jj0) {
+                const int bcol = 16 * tj + li;
+                const T bl = (bcol > c0 + 3) ? sLn[bcol][lq] : (T)0;          // columns up to the step are final
+                a[tj] = M::mfma(al, bl, a[tj]);
+            }
+        }
+        if (jt > 0) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                if (jj <= jjp) x[jj] = M::mfma(al_prev, sXd[lq][16 * jj + li], x[jj]);
+        }
+        al_prev = al;
+        if (stamps && jt == 9 && threadIdx.x == 0) stamps[5] = __builtin_amdgcn_s_memtime();
+        if (stamps && jt == 10 && threadIdx.x == 0) stamps[6] = __builtin_amdgcn_s_memtime();
+        // (no barrier: the next S1 writes sS, last read in S3 -- before the barrier after S4; sLn / sXd / sDd and the
+        //  parity half of sWi are rewritten only after the next step's first barrier, when every wave is past S5)
+    }
+    // the last step's X rows (its rank-4 update has no rows below it)
+    if (wave == 3) finish_x_rows(3, 3, 1, false);
+}
+
+// fp64: the round-2 function, untouched (its instruction stream is tuned: a refactoring of it into the generic form below
+// cost 4 % of an n = 8192 factorisation); fp32: the generic form
+template <typename T> struct LeafMfma;
+template <> struct LeafMfma<double> {
+    __device__ static __forceinline__ void run(PM<double>::v4 (&a)[4], PM<double>::v4 (&x)[4], int64_t j0, int *__restrict__ info,
+                                               int wave, int lane, unsigned long long *stamps)
+    {
+        factor64_mfma(a, x, j0, info, wave, lane, stamps);
+    }
+};
+template <> struct LeafMfma<float> {
+    __device__ static __forceinline__ void run(PM<float>::v4 (&a)[4], PM<float>::v4 (&x)[4], int64_t j0, int *__restrict__ info,
+                                               int wave, int lane, unsigned long long *stamps)
+    {
+        factor64_mfma_t<float>(a, x, j0, info, wave, lane, stamps);
+    }
+};
 
 }  // namespace gpx

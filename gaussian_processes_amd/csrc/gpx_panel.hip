@@ -9,8 +9,9 @@
 //   accumulator tiles (kb = 256 fp64: 64 doubles a lane), loaded once and stored once.
 //   Step j (64 columns, right-looking inside the panel):
 //     workgroup j   (the diagonal block, fully updated by the steps before) factors it and forms W = inv(L_jj)
-//                   -- fp64: in place in the accumulator tiles, on the MFMA pipe (factor64_mfma, gpx_leaf.h);
-//                   fp32: through LDS into the VALU leaf's thread-tile layout (factor64_pipe) --, stores L_jj,
+//                   in place in the accumulator tiles, on the MFMA pipe (gpx_leaf.h: factor64_mfma for fp64,
+//                   factor64_mfma_t<float> for fp32 panels of up to 16384 rows and the chain part of taller ones;
+//                   the lean fp32 instantiation keeps the VALU sweep factor64_pipe) --, stores L_jj,
 //                   publishes W and raises flag W_j; it is done.
 //     before step 0 the launch applies the kpre columns immediately to its left (left-looking pre-update): what
 //                   used to be one more dependent GEMM launch in front of every panel.
@@ -195,7 +196,10 @@ __device__ __forceinline__ void res_prod(const T (*sa)[PT], const T (*sb)[PT], t
     }
 }
 
-template <typename T>
+// LEAF_MFMA: the diagonal block's leaf on the MFMA pipe (fp64: always; fp32: the short-panel instantiation -- the
+// unrolled MFMA sweep costs the fp32 kernel 58 VGPRs, i.e. a third workgroup per CU, which tall panels miss more than
+// they gain from the faster leaf)
+template <typename T, bool LEAF_MFMA>
 __global__ __launch_bounds__(256, 2) void panel_res_kernel(T *__restrict__ A, int64_t lda, int64_t n, int64_t r0, int64_t c0,
                                                            int nsteps, int *__restrict__ info, T *__restrict__ pub,
                                                            int *__restrict__ flags, int serial, int64_t sM, int kpre,
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void panel_res_kernel(T *__restrict__ A, in
         }
     }
     stamp(1);
-    v4 dg[4];                                                   // fp64: the diagonal block of this workgroup when its step comes
+    v4 dg[4];                                                   // the diagonal block of this workgroup when its step comes
     int dg_step = -1;
 #pragma unroll
     for (int j = 0; j < RES_MAXSTEPS; ++j) {
@@ -283,14 +287,13 @@ __global__ __launch_bounds__(256, 2) void panel_res_kernel(T *__restrict__ A, in
         for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
             for (int r = 0; r < 4; ++r) sA[16 * wave + M::row(lane, r)][16 * jj + li] = acc[j][jj][r];
-        if constexpr (sizeof(T) == 8) {
-            if (w == j) {                                       // fp64: the MFMA leaf, after the loop (ONE copy of its code)
+        if (LEAF_MFMA && w == j) {                              // the MFMA leaf, after the loop (ONE copy of its code)
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) dg[jj] = acc[j][jj];
-                dg_step = j;
-                continue;
-            }
+            for (int jj = 0; jj < 4; ++jj) dg[jj] = acc[j][jj];
+            dg_step = j;
+            continue;
         }
+        if constexpr (!LEAF_MFMA) {
         if (w == j) {
             // ---- the diagonal block: leaf ----
             __syncthreads();
@@ -338,6 +341,7 @@ __global__ __launch_bounds__(256, 2) void panel_res_kernel(T *__restrict__ A, in
             }
             stamp(6);
             return;
+        }
         }
         // ---- rows below the diagonal block ----
         res_wait(flags + j, serial, &s_ok, !future_diag);
@@ -405,33 +409,31 @@ __global__ __launch_bounds__(256, 2) void panel_res_kernel(T *__restrict__ A, in
             res_prod<T, PT, true>(sA, sB, acc[c], wave, li, lq);
         }
     }
-    if constexpr (sizeof(T) == 8) {
-        if (dg_step >= 0) {
-            // ---- the diagonal block: the leaf on the MFMA pipe (gpx_leaf.h), in place in the accumulator tiles ----
-            const int j = dg_step;
-            v4 xw[4];
+    if constexpr (LEAF_MFMA) if (dg_step >= 0) {
+        // ---- the diagonal block: the leaf on the MFMA pipe (gpx_leaf.h), in place in the accumulator tiles ----
+        const int j = dg_step;
+        v4 xw[4];
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
+        for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) xw[jj][r] = (16 * wave + M::row(lane, r) == 16 * jj + li) ? (T)1 : (T)0;
-            factor64_mfma(dg, xw, r0 + (int64_t)IB * j, info, wave, lane, (stamps && w == 0 && blockIdx.y == 0) ? stamps + 2040 * 16 : nullptr);
-            T *W = pub + (int64_t)j * (IB * IB);
+            for (int r = 0; r < 4; ++r) xw[jj][r] = (16 * wave + M::row(lane, r) == 16 * jj + li) ? (T)1 : (T)0;
+        LeafMfma<T>::run(dg, xw, r0 + (int64_t)IB * j, info, wave, lane, (stamps && w == 0 && blockIdx.y == 0) ? stamps + 2040 * 16 : nullptr);
+        T *W = pub + (int64_t)j * (IB * IB);
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
+        for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * wave + M::row(lane, r), col = 16 * jj + li;
-                    if (jj <= wave) pub_store(W + row * IB + col, (col <= row) ? xw[jj][r] : (T)0);   // (tiles above: zero since the clear)
-                }
-            res_raise(flags + j, serial);
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * wave + M::row(lane, r), col = 16 * jj + li;
+                if (jj <= wave) pub_store(W + row * IB + col, (col <= row) ? xw[jj][r] : (T)0);   // (tiles above: zero since the clear)
+            }
+        res_raise(flags + j, serial);
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
+        for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * wave + M::row(lane, r), col = 16 * jj + li;
-                    if (col <= row) A[(r0 + (int64_t)IB * j + row) * lda + c0 + IB * j + col] = dg[jj][r];
-                }
-        }
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * wave + M::row(lane, r), col = 16 * jj + li;
+                if (col <= row) A[(r0 + (int64_t)IB * j + row) * lda + c0 + IB * j + col] = dg[jj][r];
+            }
     }
     stamp(6);
 }
@@ -534,17 +536,30 @@ static int panel_res_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int
     // short panels (rows <= GPX_POTRF_TWO_PART_ROWS) stay one launch.
     // (measured: n = 32768 fp32 96.7 -> 95.5 ms with 16384; n = 65536 fp64 unchanged; n = 16384 28.8 -> 29.3 with 12288)
     const int64_t two_part_rows = env_i64("GPX_POTRF_TWO_PART_ROWS", 16384);
+    // fp32: which instantiation holds the leaf (see panel_res_kernel): the MFMA leaf for single launches of up to
+    // GPX_LEAF_MFMA_F32_ROWS rows and for the chain part of a two-part panel; the lean kernel for everything taller
+    constexpr bool F64 = sizeof(T) == 8;
+    const bool mfma_single = F64 || rows <= env_i64("GPX_LEAF_MFMA_F32_ROWS", 16384);
     // (`done` is recorded behind the launch.  Carrying it as the completion signal of the dispatch packet itself --
     //  hipExtLaunchKernelGGL(..., stopEvent) -- saves ~2.5 us per panel (tools/sync_probe.hip) and was tried; one run of
     //  the parity suite then produced a wrong log_lh at n = 1990 that never reproduced.  Not worth 1 %: dropped.)
     hipEvent_t record_after = done;
     if (rows > two_part_rows && (int64_t)grid.x > nsteps) {
-        hipLaunchKernelGGL((panel_res_kernel<T>), dim3((unsigned)nsteps, grid.y), dim3(256), 0, st, A, lda, n, r0, c0, nsteps, info_dev,
-                           (T *)pub, flags, serial, bt ? bt->sA : (int64_t)0, (int)(kpre / IB), stamps, 0);
-        hipLaunchKernelGGL((panel_res_kernel<T>), dim3(grid.x - (unsigned)nsteps, grid.y), dim3(256), 0, st, A, lda, n, r0, c0, nsteps,
+        const bool mfma_chain = F64 || env_i64("GPX_LEAF_MFMA_F32_ROWS", 16384) > 0;
+        if (mfma_chain)
+            hipLaunchKernelGGL((panel_res_kernel<T, true>), dim3((unsigned)nsteps, grid.y), dim3(256), 0, st, A, lda, n, r0, c0, nsteps,
+                               info_dev, (T *)pub, flags, serial, bt ? bt->sA : (int64_t)0, (int)(kpre / IB), stamps, 0);
+        else
+            hipLaunchKernelGGL((panel_res_kernel<T, F64>), dim3((unsigned)nsteps, grid.y), dim3(256), 0, st, A, lda, n, r0, c0, nsteps,
+                               info_dev, (T *)pub, flags, serial, bt ? bt->sA : (int64_t)0, (int)(kpre / IB), stamps, 0);
+        // (the rows never run a leaf: the lean instantiation)
+        hipLaunchKernelGGL((panel_res_kernel<T, F64>), dim3(grid.x - (unsigned)nsteps, grid.y), dim3(256), 0, st, A, lda, n, r0, c0, nsteps,
                            info_dev, (T *)pub, flags, serial, bt ? bt->sA : (int64_t)0, (int)(kpre / IB), stamps, nsteps);
+    } else if (mfma_single) {
+        hipLaunchKernelGGL((panel_res_kernel<T, true>), grid, dim3(256), 0, st, A, lda, n, r0, c0, nsteps, info_dev, (T *)pub,
+                           flags, serial, bt ? bt->sA : (int64_t)0, (int)(kpre / IB), stamps, 0);
     } else {
-        hipLaunchKernelGGL((panel_res_kernel<T>), grid, dim3(256), 0, st, A, lda, n, r0, c0, nsteps, info_dev, (T *)pub,
+        hipLaunchKernelGGL((panel_res_kernel<T, F64>), grid, dim3(256), 0, st, A, lda, n, r0, c0, nsteps, info_dev, (T *)pub,
                            flags, serial, bt ? bt->sA : (int64_t)0, (int)(kpre / IB), stamps, 0);
     }
     GPX_LAUNCH_CHECK();
