@@ -1126,6 +1126,29 @@ def test_resident_panel_vs_launch_chain_and_oracle(monkeypatch, dtype, N, nb):
             np.testing.assert_allclose(np.tril(L), o.Lxx, rtol=2e-3, atol=2e-4, err_msg=label)
 
 
+@pytest.mark.parametrize("N", [700, 1990])
+def test_fp32_resident_panel_both_leaf_forms_vs_oracle(monkeypatch, N):
+    """The fp32 resident panel kernel exists in two instantiations: the leaf on the MFMA pipe (default for panels of up
+    to 16384 rows and for the chain part of taller ones) and the lean one with the VALU sweep (GPX_LEAF_MFMA_F32_ROWS=0
+    selects it everywhere).  Both against the oracle at the fp32 tolerances, and against each other."""
+    d = 3
+    X, y, Xo = orc.synth_inputs(N, d, 16)
+    h, w, s = 1.0, 0.5 * np.sqrt(d), 0.9
+    o = orc.OracleGP("gaussian", (h, w), X, y, s)
+    out = {}
+    for label, rows in (("mfma", None), ("valu", "0")):
+        if rows is None:
+            monkeypatch.delenv("GPX_LEAF_MFMA_F32_ROWS", raising=False)
+        else:
+            monkeypatch.setenv("GPX_LEAF_MFMA_F32_ROWS", rows)
+        g = gp.GP(gp.GaussianKernel(h, w), X, y, s=s, dtype="float32")
+        out[label] = (float(g.log_lh), np.array(g.Lxx, dtype=np.float64), np.array(g.mean(Xo), dtype=np.float64))
+        np.testing.assert_allclose(out[label][0], o.log_lh, rtol=1e-4, err_msg=label)
+        np.testing.assert_allclose(np.tril(out[label][1]), o.Lxx, rtol=2e-3, atol=2e-4, err_msg=label)
+        np.testing.assert_allclose(out[label][2], o.mean(Xo), rtol=1e-3, atol=1e-3, err_msg=label)
+    np.testing.assert_allclose(np.tril(out["mfma"][1]), np.tril(out["valu"][1]), rtol=1e-3, atol=1e-4)
+
+
 def test_resident_panel_reports_first_failing_minor():
     """A pivot <= 0 inside the resident kernel (diagonal workgroup 0, 1, 2 or 3 of a panel; first or later panel):
     info = LAPACK's first failing leading minor, nobody is left spinning, LinAlgError as the reference raises."""
