@@ -1166,6 +1166,16 @@ def test_resident_panel_reports_first_failing_minor():
         sync()
         assert int(info.to_host()[0]) == bad + 1, (bad, int(info.to_host()[0]))
         dA.free(); info.free()
+    # fp32 (the MFMA leaf's float instantiation): the same convention
+    for bad in (0, 70, 255, 700):
+        A = A0.astype(np.float32)
+        A[bad, bad] = -1.0
+        dA = DeviceBuffer.from_host(A)
+        info = DeviceBuffer((4,), np.int32).zero()
+        _lib.check(lib.gpx_d_potrf(_lib.F32, dA.ptr, N, N, info.ptr, None))
+        sync()
+        assert int(info.to_host()[0]) == bad + 1, ("f32", bad, int(info.to_host()[0]))
+        dA.free(); info.free()
     # and the same matrix without the defect still factors afterwards (flags / scratch left consistent)
     dA = DeviceBuffer.from_host(A0)
     info = DeviceBuffer((4,), np.int32).zero()
