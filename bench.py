@@ -133,8 +133,18 @@ def cpu_baseline(N, d, m, sample_n, sample_n2=0):
     if fitted is not None:
         fp = dict(powers); fp.update({k: max(1.0, min(3.0, v)) for k, v in fitted.items()})
         fitted_total = sum(base_t[k] * r ** fp[k] for k in powers)
+    cpu_model = None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     out = {
         "value": round(faithful, 3), "unit": "s", "cores": int(blas_threads), "kind": "port",
+        "os_cpu_count": os.cpu_count(), "cpu_model": cpu_model,
         "value_with_fitted_exponents": None if fitted_total is None else round(fitted_total, 3),
         "sample_seconds": round(sum(t.values()) + (sum(t2.values()) if t2 else 0.0), 3),
         "fair_value": round(fair, 3),
