@@ -140,6 +140,8 @@ int64_t panel_res_max();
 // this host thread's look-ahead stream of the blocked factorisation on the current device (nullptr before the first
 // one): it lives as long as the thread, so an event may be recorded on it at any time
 hipStream_t potrf_side_stream();
+// would K(x, x) + s^2 I hold only finite numbers for finite x?  (gpx_gp.hip; the check_finite of the reference's cho_factor)
+bool kernel_values_finite(int kernel, const double *p, double s);
 bool panel_res_fold(int64_t rows, int64_t kpre, int64_t kb, size_t es, int64_t lda, const void *base);
 // Per-factor block operators of the single-right-hand-side solves (gpx_solve.hip, "operator form"): owned by
 // whoever owns the factor; `valid` must be cleared whenever the factor changes.  nullptr: built per call.

@@ -141,7 +141,7 @@ int gp_scan_finite(gpx_gp *g)
 // Would K(x, x) + s^2 I hold only finite numbers for finite x?  The kernel's value at r = 0 and at r = 1 in the
 // host's double arithmetic: a NaN or infinite parameter (the reference's setters let both through:
 // gp/kernels/gaussian.py:62-69 only reject values < EPS, gp/gp.py:192-193 only s < 0) shows up there.
-static bool kernel_values_finite(int kernel, const double *p, double s)
+bool kernel_values_finite(int kernel, const double *p, double s)
 {
     double k0, k1;
     if (kernel == GPX_KERNEL_GAUSSIAN) {

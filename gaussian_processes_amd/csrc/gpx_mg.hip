@@ -736,6 +736,12 @@ int gpx_mg_set_data(gpx_mg_t *g, const double *x, const double *y)
     MG_ENTER(g);
     GPX_ARG(x && y, "NULL argument");
     const int64_t n = g->n;
+    // the check_finite of the reference's cho_factor / cho_solve (gp/gp.py:294, 332-334), on the host copies that
+    // every rank holds: all ranks refuse together, before any collective
+    for (int64_t i = 0; i < n * g->d; ++i)
+        if (!std::isfinite(x[i])) { set_error("array must not contain infs or NaNs (x)"); return GPX_ERR_ARG; }
+    for (int64_t i = 0; i < n; ++i)
+        if (!std::isfinite(y[i])) { set_error("array must not contain infs or NaNs (y)"); return GPX_ERR_ARG; }
     if (g->dtype == GPX_F64) {
         GPX_HIP(hipMemcpy(g->x, x, (size_t)n * g->d * 8, hipMemcpyHostToDevice));
         GPX_HIP(hipMemcpy(g->y, y, (size_t)n * 8, hipMemcpyHostToDevice));
@@ -755,6 +761,8 @@ int gpx_mg_fit(gpx_mg_t *g, const double *params, double s, double *log_lh, int 
     MG_ENTER(g);
     GPX_ARG(g->have_data && params, "set_data must be called before fit");
     GPX_ARG(!(s < 0), "invalid value for s");
+    if (!kernel_values_finite(g->kernel, params, s)) { set_error("array must not contain infs or NaNs"); return GPX_ERR_ARG; }
+    g->fitted = false;
     g->ev_next = 0; g->tev_next = 0;
     GPX_HIP(hipMemsetAsync(g->info, 0, 4 * sizeof(int), g->S));
     GPX_TRY(mg_build(g, params, s));

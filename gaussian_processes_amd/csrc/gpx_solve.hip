@@ -16,7 +16,6 @@
 namespace gpx {
 
 constexpr int SB = 64;
-constexpr int SBP = SB + 1;
 
 // ---- batched inverse of the 64 x 64 diagonal blocks --------------------------
 // One 256-thread workgroup per block (all blocks in one launch): the register-resident 4 x 4-tile sweep of the

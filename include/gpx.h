@@ -412,7 +412,8 @@ int gpx_debug_mg_inject_info(gpx_mg_t *mg, int value);
 int gpx_mg_create_cb(gpx_mg_t **mg, int dtype, int kernel, int64_t n, int d, int64_t nb, int world, int rank,
                      gpx_mg_bcast_fn bcast, gpx_mg_allreduce_fn allreduce, void *user);
 int gpx_mg_destroy(gpx_mg_t *mg);
-/* x: (n, d), y: (n,) HOST float64, the same on every rank */
+/* x: (n, d), y: (n,) HOST float64, the same on every rank.  NaN / infinite entries: GPX_ERR_ARG with the
+ * check_finite message (as gpx_gp_fit; gpx_mg_fit checks the kernel constants the same way) */
 int gpx_mg_set_data(gpx_mg_t *mg, const double *x, const double *y);
 /* kernel build (owned block columns) -> distributed Cholesky -> alpha (replicated) -> log_lh with the
  * reference's conventions (gp/gp.py:360-367, gp_c.pyx:17-31); *info = first failing leading minor over

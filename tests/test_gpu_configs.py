@@ -249,6 +249,23 @@ def test_check_finite_on_the_native_route_like_scipy():
     # the lock-step batch: NaN in y is a ValueError for the whole table
     with pytest.raises(ValueError, match="infs or NaNs"):
         mlii.log_lh_batch(X, yn, np.array([[1.0, 1.0, 1.0]]))
+    # the multi-GPU handle (one rank): the same refusals, and the handle is usable afterwards
+    from gaussian_processes_amd import multi_gpu
+    h = multi_gpu.NativeDistributedGP(N, 2, nb=64, backend="callbacks")
+    try:
+        for Xc, yc in ((Xn, y), (Xi, y), (X, yn)):
+            with pytest.raises(ValueError, match="infs or NaNs"):
+                h.set_data(Xc, yc)
+        h.set_data(X, y)
+        with pytest.raises(ValueError, match="infs or NaNs"):
+            h.fit([np.inf, 1.0], 1.0)
+        with pytest.raises(ValueError, match="infs or NaNs"):
+            h.fit([1.0, 1.0], np.nan)
+        ll = h.fit([1.0, 1.0], 1.0)
+        assert h.info == 0
+        np.testing.assert_allclose(ll, orc.OracleGP("gaussian", (1.0, 1.0), X, y, 1.0).log_lh, rtol=1e-10)
+    finally:
+        h.close()
 
 
 def test_internal_failure_is_a_runtime_error_never_minus_inf(tmp_path):
