@@ -544,7 +544,11 @@ static int panel_res_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int
     //  hipExtLaunchKernelGGL(..., stopEvent) -- saves ~2.5 us per panel (tools/sync_probe.hip) and was tried; one run of
     //  the parity suite then produced a wrong log_lh at n = 1990 that never reproduced.  Not worth 1 %: dropped.)
     hipEvent_t record_after = done;
-    if (rows > two_part_rows && (int64_t)grid.x > nsteps) {
+    // lock-step batches: the same trade per launch over ALL matrices -- many matrices' row workgroups crowd out the
+    // update of the step before (64 x n = 8192: 0.213 -> 0.199 s with two parts, 16 x: 55.0 -> 54.6 ms, 8 x: 29.4 -> 30.8)
+    const int64_t nmat = bt ? bt->count : 1;
+    const bool two_part = nmat > 1 ? rows * nmat > env_i64("GPX_POTRF_TWO_PART_BATCH", 98304) : rows > two_part_rows;
+    if (two_part && (int64_t)grid.x > nsteps) {
         const bool mfma_chain = F64 || env_i64("GPX_LEAF_MFMA_F32_ROWS", 16384) > 0;
         if (mfma_chain)
             hipLaunchKernelGGL((panel_res_kernel<T, true>), dim3((unsigned)nsteps, grid.y), dim3(256), 0, st, A, lda, n, r0, c0, nsteps,

@@ -1149,6 +1149,33 @@ def test_fp32_resident_panel_both_leaf_forms_vs_oracle(monkeypatch, N):
     np.testing.assert_allclose(np.tril(out["mfma"][1]), np.tril(out["valu"][1]), rtol=1e-3, atol=1e-4)
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_two_part_panel_launch_equals_one_launch(monkeypatch, dtype):
+    """Tall panels (and lock-step batches with many rows in total) go out as two launches: the diagonal workgroups,
+    then the rows, which then find every flag raised.  Forced here at sizes where one launch is the default
+    (GPX_POTRF_TWO_PART_ROWS / _BATCH = 0): same arithmetic per workgroup, so the factor and log_lh must be equal bit
+    for bit, single matrix and batch, and equal to the oracle's at the usual tolerance."""
+    from gaussian_processes_amd import mlii
+    N, d = 1990, 3
+    X, y, _ = orc.synth_inputs(N, d, 4)
+    thetas = np.array([[1.0, 0.9, 1.0], [0.7, 1.4, 0.8], [1.3, 0.6, 1.2]])
+    ref = [orc.OracleGP("gaussian", th[:2], X, y, th[2]).log_lh for th in thetas]
+    out = {}
+    for label, env in (("one", {}), ("two", {"GPX_POTRF_TWO_PART_ROWS": "0", "GPX_POTRF_TWO_PART_BATCH": "0"})):
+        for k in ("GPX_POTRF_TWO_PART_ROWS", "GPX_POTRF_TWO_PART_BATCH"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        g = gp.GP(gp.GaussianKernel(*thetas[0, :2]), X, y, s=thetas[0, 2], dtype=dtype)
+        out[label] = (float(g.log_lh), np.array(g.Lxx), np.array(mlii.log_lh_batch(X, y, thetas, dtype=dtype)))
+    assert out["one"][0] == out["two"][0]
+    assert np.array_equal(np.tril(out["one"][1]), np.tril(out["two"][1]))
+    assert np.array_equal(out["one"][2], out["two"][2])
+    rtol = 1e-10 if dtype == "float64" else 1e-4
+    np.testing.assert_allclose(out["two"][0], ref[0], rtol=rtol)
+    np.testing.assert_allclose(out["two"][2], ref, rtol=rtol)
+
+
 def test_resident_panel_reports_first_failing_minor():
     """A pivot <= 0 inside the resident kernel (diagonal workgroup 0, 1, 2 or 3 of a panel; first or later panel):
     info = LAPACK's first failing leading minor, nobody is left spinning, LinAlgError as the reference raises."""
