@@ -52,7 +52,7 @@ static inline int64_t env_i64(const char *name, int64_t dflt)
 // point of decision.  Tests that force a route through an environment switch assert it here.
 enum Route { RT_TRSV_OPS = 0, RT_TRSV_STEPS = 1, RT_PANEL_RES = 2, RT_PANEL_CHAIN = 3, RT_FIT_RIDE = 4,
              RT_FIT_TWO_SOLVES = 5, RT_GEMM_FAST = 6, RT_GEMM_GENERIC = 7, RT_SYRK_EXACT = 8, RT_SYRK_PATCH = 9,
-             RT_MG_BCAST_ONE = 10, RT_MG_BCAST_SAG = 11, RT_COUNT = 16 };
+             RT_MG_BCAST_ONE = 10, RT_MG_BCAST_SAG = 11, RT_FIT_OPS_AHEAD = 12, RT_COUNT = 16 };
 void route_hit(int route);
 
 // LAPACK-style info of a factorisation as the host sees it: > 0 "not positive definite" (the caller's business),
@@ -145,10 +145,20 @@ bool kernel_values_finite(int kernel, const double *p, double s);
 bool panel_res_fold(int64_t rows, int64_t kpre, int64_t kb, size_t es, int64_t lda, const void *base);
 // Per-factor block operators of the single-right-hand-side solves (gpx_solve.hip, "operator form"): owned by
 // whoever owns the factor; `valid` must be cleared whenever the factor changes.  nullptr: built per call.
-struct TrsvOps { void *buf = nullptr; size_t bytes = 0; bool valid = false; };
+struct TrsvOps { void *buf = nullptr; size_t bytes = 0; bool valid = false; int64_t built = 0; };   // built: leading 512-blocks done (trsv_ops_build_upto)
 // Build the operators of an n x n factor (n a multiple of 512) ahead of time on `st`; a later trsv_lower with these ops
 // takes the operator route whatever n is (the distributed solve prepares each diagonal block right after its panel).
 int trsv_ops_build(int dtype, const void *L, int64_t n, int64_t ldl, TrsvOps *ops, hipStream_t st);
+// The same in instalments, while the factorisation is still running: the operators of the 512-blocks [ops->built, kend) --
+// which need nothing but block columns < kend of L -- on `st`; ops->valid once kend reaches n / 512.  n % 512 == 0 only
+// (trsv_ops_ahead_ok); the first call of a factor passes ops->built == 0.
+bool trsv_ops_ahead_ok(int dtype, const void *L, int64_t n, int64_t ldl);
+size_t trsv_ops_bytes(int dtype, int64_t n);
+int trsv_ops_build_upto(int dtype, const void *L, int64_t n, int64_t ldl, TrsvOps *ops, int64_t kend, hipStream_t st);
+// potrf() progress hook of the calling host thread (null: none): called with the number of leading columns that are final
+// once `panel_done` has fired; single matrices with more than one outer block only.
+struct PotrfHook { int (*fn)(void *user, int64_t cols_done, hipEvent_t panel_done); void *user; };
+void potrf_set_hook(const PotrfHook *hook);
 int trsv_lower(int dtype, const void *L, int64_t n, int64_t ldl, void *b, void *x, int transpose,
                hipStream_t st, const Batch *bt = nullptr,   // bt: sA = stride of L, sB = stride of b / x
                TrsvOps *ops = nullptr);

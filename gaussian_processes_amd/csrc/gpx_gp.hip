@@ -214,6 +214,8 @@ int gpx_gp_destroy(gpx_gp_t *g)
     if (!g) return GPX_OK;
     gpx::DeviceGuard guard__(g->device);
     if (g->st) (void)hipStreamSynchronize(g->st);
+    if (g->st_ops) { (void)hipStreamSynchronize(g->st_ops); (void)hipStreamDestroy(g->st_ops); }
+    if (g->ev_ops) (void)hipEventDestroy(g->ev_ops);
     void *bufs[] = {g->x, g->y, g->A, g->alpha, g->t0, g->t1, g->scal, g->bw, g->ops.buf};
     for (void *b : bufs) if (b) (void)hipFree(b);
     for (int i = 0; i < 6; ++i) if (g->ev[i]) (void)hipEventDestroy(g->ev[i]);
@@ -279,6 +281,22 @@ int gpx_gp_set_K(gpx_gp_t *g, const double *Kxx, int64_t ld)
     return GPX_OK;
 }
 
+// The block operators of the triangular solves (csrc/gpx_solve.hip: W_k = inv(L_kk) and its products with the neighbour
+// blocks, 512 columns a block) need nothing but the block columns of L up to their own.  potrf() reports its progress
+// (PotrfHook), and every `group` finished blocks their operators are built on a stream of their own, beside the
+// rest of the factorisation: when it ends only the last group is still to do, and the solves take the operator route --
+// one launch per block with no chain inside it -- at every size (n = 8192: backward solve 0.53 -> see DESIGN 3.3).
+struct OpsAhead { gpx_gp *g; int64_t group, last; };
+static int ops_ahead_step(void *user, int64_t cols_done, hipEvent_t panel_done)
+{
+    OpsAhead *o = (OpsAhead *)user;
+    gpx_gp *g = o->g;
+    const int64_t ready = std::min(cols_done / 512, o->last);   // (the trailing blocks are left to the sweep's own steps)
+    if (ready - g->ops.built < o->group) return GPX_OK;
+    GPX_HIP(hipStreamWaitEvent(g->st_ops, panel_done, 0));
+    return trsv_ops_build_upto(g->dtype, g->A, g->n, g->lda, &g->ops, ready, g->st_ops);
+}
+
 int gpx_gp_fit(gpx_gp_t *g, int *info)
 {
     GP_ENTER(g);
@@ -310,10 +328,47 @@ int gpx_gp_fit(gpx_gp_t *g, int *info)
     route_hit(ride ? RT_FIT_RIDE : RT_FIT_TWO_SOLVES);
     char *row_n = (char *)g->A + (size_t)g->n * g->lda * es;
     if (ride) GPX_HIP(hipMemcpyAsync(row_n, g->y, (size_t)g->n * es, hipMemcpyDeviceToDevice, st));
-    GPX_TRY(potrf(g->dtype, g->A, g->n, g->lda, info_dev, st, nullptr, ride ? 1 : 0));
+    g->ops.valid = false; g->ops.built = 0;               // a new factor: its block operators are rebuilt once
+    const bool ahead = env_i64("GPX_FIT_OPS_AHEAD", 1) != 0 && g->n >= env_i64("GPX_FIT_OPS_AHEAD_MIN", 8192) &&
+                       trsv_ops_ahead_ok(g->dtype, g->A, g->n, g->lda);
+    // ONE instalment, when all but the last `tail` blocks are final: the build is a chain of ~11 launches batched over its
+    // blocks (~0.6 ms whatever their number), so instalments of 4 blocks cost the factorisation what the solve saves
+    // (n = 8192: fit 6.71 -> 6.73 ms with groups of 4, 6.62 with one; n = 12288: 15.57 -> 15.04; n = 4096: no gain), and
+    // the last blocks' operators would only be waited for: the backward sweep takes those blocks by steps
+    const int64_t nfull = g->n / 512, tail = env_i64("GPX_FIT_OPS_TAIL", 4);
+    const int64_t group = std::max<int64_t>(1, std::min(env_i64("GPX_FIT_OPS_GROUP", nfull), nfull - tail));
+    OpsAhead oa = {g, group, std::max<int64_t>(0, nfull - tail)};
+    PotrfHook hook = {ops_ahead_step, &oa};
+    if (ahead) {
+        if (!g->st_ops) {
+            int least = 0, greatest = 0;
+            GPX_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            GPX_HIP(hipStreamCreateWithPriority(&g->st_ops, hipStreamNonBlocking, least));
+            GPX_HIP(hipEventCreateWithFlags(&g->ev_ops, hipEventDisableTiming));
+        }
+        const size_t need = trsv_ops_bytes(g->dtype, g->n);
+        if (!g->ops.buf || g->ops.bytes < need) {             // (here, not inside the factorisation's launch loop)
+            if (g->ops.buf) { GPX_HIP(hipStreamSynchronize(st)); (void)hipFree(g->ops.buf); g->ops.buf = nullptr; g->ops.bytes = 0; }
+            GPX_HIP(hipMalloc(&g->ops.buf, need));
+            g->ops.bytes = need;
+        }
+        // (the operator buffer may still be read by solves of the factor before this one, queued on st)
+        GPX_HIP(hipEventRecord(g->ev_ops, st));
+        GPX_HIP(hipStreamWaitEvent(g->st_ops, g->ev_ops, 0));
+        potrf_set_hook(&hook);
+    }
+    const int prc = potrf(g->dtype, g->A, g->n, g->lda, info_dev, st, nullptr, ride ? 1 : 0);
+    potrf_set_hook(nullptr);
+    GPX_TRY(prc);
+    if (ahead) {
+        // the solves wait for the operator stream.  The backward sweep takes the blocks that have no operators yet by
+        // steps; a forward sweep (n > ride_max) and every later solve of this factor complete the set first (trsv_lower)
+        GPX_HIP(hipEventRecord(g->ev_ops, g->st_ops));
+        GPX_HIP(hipStreamWaitEvent(st, g->ev_ops, 0));
+        if (g->ops.built > 0) route_hit(RT_FIT_OPS_AHEAD);
+    }
     GPX_HIP(hipEventRecord(g->ev[2], st));
     // inv_Kxx_y = cho_solve((L, True), y) (gp/gp.py:332-334)
-    g->ops.valid = false;                                 // a new factor: its block operators are rebuilt once
     if (ride) {
         GPX_TRY(trsv_lower(g->dtype, g->A, g->n, g->lda, row_n, g->alpha, 1, st, nullptr, &g->ops));
     } else {

@@ -19,6 +19,8 @@ struct gpx_gp {
     void *bw; size_t bw_bytes; int64_t bw_cap;
     // block operators of the triangular solves (built once per factor, reused by every later solve)
     gpx::TrsvOps ops;
+    hipStream_t st_ops;   // lazily created: where gpx_gp_fit builds `ops` while the factorisation is still running
+    hipEvent_t ev_ops;
 };
 
 namespace gpx {

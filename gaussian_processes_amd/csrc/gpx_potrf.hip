@@ -404,6 +404,10 @@ struct LookAhead {
 };
 static thread_local LookAhead g_la;
 
+// progress hook of this host thread (gpx_gp_fit builds the solves' block operators while the factorisation runs)
+static thread_local const PotrfHook *g_hook = nullptr;
+void potrf_set_hook(const PotrfHook *hook) { g_hook = hook; }
+
 hipStream_t potrf_side_stream()
 {
     int dev = -1;
@@ -544,7 +548,11 @@ int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t
         const int64_t r = k0 + kb;
         if (masked && n - r <= reserve_below) GPX_TRY(switch_to(masked));
         GPX_HIP(hipStreamWaitEvent(st, ep, 0));                 // panel k is factored
-        if (r >= n) break;
+        if (r >= n) {
+            if (g_hook && !bt) GPX_TRY(g_hook->fn(g_hook->user, n, ep));
+            break;
+        }
+        const hipEvent_t ep_k = ep;
         const int64_t w1 = nominal(r), kb1 = std::min(w1, n - r);
         // block column k + 1 first, so that its panel can start ... (small n: the panel kernel applies panel k to its
         // own columns itself -- it then only waits for the trailing update of step k - 1, not for this stream's turn)
@@ -572,6 +580,8 @@ int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t
             GPX_TRY(syrk_bc(dtype, N, r, A, lda, r + kb1, n, at(k0, k0), lda, k0, kb, w1, 1, 0, st, info_dev, bt));
         GPX_TRY(g_la.get(&e_rest));
         GPX_HIP(hipEventRecord(e_rest, st));
+        // (after the next panel and this step's update are on their way: the hook's launches never delay the chain)
+        if (g_hook && !bt) GPX_TRY(g_hook->fn(g_hook->user, r, ep_k));
         k0 = r; kb = kb1;
     }
     if (st != user) {

@@ -552,46 +552,59 @@ size_t trsv_ops_bytes(int dtype, int64_t n)
     return (size_t)(5 * nfull * (int64_t)OB * OB + nfull * 8 * (int64_t)SB * SB) * esize(dtype) + 256;
 }
 
-// build W, Wt, Tf, Tb for the leading nfull = n / 512 blocks of L into `buf` (trsv_ops_bytes)
+// build W, Wt, Tf, Tb of the 512-blocks [kbeg, kend) of L into `buf` (trsv_ops_bytes): everything is batched over the
+// blocks of the range with the pointers moved to its first block.  Block k needs L_kk, L_{k,k-1} and L_{k+1,k}: block
+// columns <= k of the factor.  kbeg = 0 also clears the triangular operators' zero halves for ALL blocks, so ranges go
+// out in increasing order.
 template <typename T>
-static int trsv_ops_prepare(const T *L, int64_t n, int64_t ldl, void *buf, hipStream_t st, int dtype)
+static int trsv_ops_prepare(const T *L, int64_t n, int64_t ldl, void *buf, hipStream_t st, int dtype, int64_t kbeg = 0,
+                            int64_t kend = -1)
 {
     const int64_t nfull = n / OB, rag = n - nfull * OB;
+    if (kend < 0 || kend > nfull) kend = nfull;
+    const int64_t cnt = kend - kbeg;
     const int64_t BS = (int64_t)OB * OB;
-    T *W = (T *)buf, *Wt = W + nfull * BS, *P = Wt + nfull * BS, *Tf = P + nfull * BS, *Tb = Tf + nfull * BS,
-      *inv64 = Tb + nfull * BS;
-    (void)inv64;
-    GPX_HIP(hipMemsetAsync(W, 0, (size_t)2 * nfull * BS * sizeof(T), st));
-    hipLaunchKernelGGL((inv64_kernel<T>), dim3((unsigned)(nfull * 8)), dim3(256), 0, st, L, ldl, nfull * OB, (T *)nullptr, 0,
-                       W, Wt, (int64_t)0, (int64_t)0);
-    GPX_LAUNCH_CHECK();
+    T *W = (T *)buf, *Wt = W + nfull * BS, *P = Wt + nfull * BS, *Tf = P + nfull * BS, *Tb = Tf + nfull * BS;
+    if (kbeg == 0) GPX_HIP(hipMemsetAsync(W, 0, (size_t)2 * nfull * BS * sizeof(T), st));
+    if (cnt <= 0) return GPX_OK;
     const int64_t dLk = (int64_t)OB * (ldl + 1);                     // L_kk -> L_{k+1,k+1}
+    const T *Lk = L + kbeg * dLk;
+    T *Wk = W + kbeg * BS, *Wtk = Wt + kbeg * BS, *Pk = P + kbeg * BS;
+    hipLaunchKernelGGL((inv64_kernel<T>), dim3((unsigned)(cnt * 8)), dim3(256), 0, st, Lk, ldl, cnt * OB, (T *)nullptr, 0,
+                       Wk, Wtk, (int64_t)0, (int64_t)0);
+    GPX_LAUNCH_CHECK();
     for (int64_t s2 = SB; s2 < OB; s2 *= 2) {
         Batch b;
-        b.count = (int)nfull; b.count2 = (int)(OB / (2 * s2));
+        b.count = (int)cnt; b.count2 = (int)(OB / (2 * s2));
         const int64_t tW = 2 * s2 * OB + 2 * s2, tL = 2 * s2 * ldl + 2 * s2;
         // Pt = W11^T L21^T
         b.sA = BS; b.sB = dLk; b.sC = BS; b.tA = tW; b.tB = tL; b.tC = tW;
-        GPX_TRY(gemm_nt(dtype, s2, s2, s2, Wt, OB, L + s2 * ldl, ldl, P, OB, 1.0, GPX_FULL, 0, 0, st, 1, 0, &b));
+        GPX_TRY(gemm_nt(dtype, s2, s2, s2, Wtk, OB, Lk + s2 * ldl, ldl, Pk, OB, 1.0, GPX_FULL, 0, 0, st, 1, 0, &b));
         // W21 = -W22 Pt^T
         b.sA = BS; b.sB = BS; b.sC = BS; b.tA = tW; b.tB = tW; b.tC = tW;
-        GPX_TRY(gemm_nt(dtype, s2, s2, s2, W + s2 * OB + s2, OB, P, OB, W + s2 * OB, OB, -1.0, GPX_FULL, 0, 0, st, 1, 0, &b));
+        GPX_TRY(gemm_nt(dtype, s2, s2, s2, Wk + s2 * OB + s2, OB, Pk, OB, Wk + s2 * OB, OB, -1.0, GPX_FULL, 0, 0, st, 1, 0, &b));
         // (W^T)12 = -Pt W22^T
-        GPX_TRY(gemm_nt(dtype, s2, s2, s2, P, OB, W + s2 * OB + s2, OB, Wt + s2, OB, -1.0, GPX_FULL, 0, 0, st, 1, 0, &b));
+        GPX_TRY(gemm_nt(dtype, s2, s2, s2, Pk, OB, Wk + s2 * OB + s2, OB, Wtk + s2, OB, -1.0, GPX_FULL, 0, 0, st, 1, 0, &b));
     }
-    if (nfull > 1) {
-        hipLaunchKernelGGL((transpose_subdiag_kernel<T>), dim3(64, (unsigned)(nfull - 1)), dim3(256), 0, st, L, ldl, P);
+    const int64_t ka = std::max<int64_t>(kbeg, 1);                   // Tf_k = W_k L_{k,k-1} = W_k LT_k^T,  k = ka .. kend - 1
+    if (kend > ka) {
+        // (the transpose kernel numbers its blocks from 1 relative to the base it is given)
+        hipLaunchKernelGGL((transpose_subdiag_kernel<T>), dim3(64, (unsigned)(kend - ka)), dim3(256), 0, st, L + (ka - 1) * dLk, ldl,
+                           P + (ka - 1) * BS);
         GPX_LAUNCH_CHECK();
         Batch b;
-        b.count = (int)(nfull - 1);
-        // Tf_k = W_k L_{k,k-1} = W_k LT_k^T,  k = 1 .. nfull - 1
+        b.count = (int)(kend - ka);
         b.sA = BS; b.sB = BS; b.sC = BS;
-        GPX_TRY(gemm_nt(dtype, OB, OB, OB, W + BS, OB, P + BS, OB, Tf + BS, OB, 1.0, GPX_FULL, 0, 0, st, 1, 0, &b));
-        // Tb_k = W_k^T L_{k+1,k}^T,  k = 0 .. nfull - 2
-        b.sA = BS; b.sB = dLk; b.sC = BS;
-        GPX_TRY(gemm_nt(dtype, OB, OB, OB, Wt, OB, L + (int64_t)OB * ldl, ldl, Tb, OB, 1.0, GPX_FULL, 0, 0, st, 1, 0, &b));
+        GPX_TRY(gemm_nt(dtype, OB, OB, OB, W + ka * BS, OB, P + ka * BS, OB, Tf + ka * BS, OB, 1.0, GPX_FULL, 0, 0, st, 1, 0, &b));
     }
-    if (rag > 0) {                                                   // the last full block against the ragged one
+    const int64_t kb_end = std::min(kend, nfull - 1);                // Tb_k = W_k^T L_{k+1,k}^T,  k = kbeg .. kb_end - 1
+    if (kb_end > kbeg) {
+        Batch b;
+        b.count = (int)(kb_end - kbeg);
+        b.sA = BS; b.sB = dLk; b.sC = BS;
+        GPX_TRY(gemm_nt(dtype, OB, OB, OB, Wtk, OB, Lk + (int64_t)OB * ldl, ldl, Tb + kbeg * BS, OB, 1.0, GPX_FULL, 0, 0, st, 1, 0, &b));
+    }
+    if (rag > 0 && kend == nfull) {                                  // the last full block against the ragged one
         T *tb = Tb + (nfull - 1) * BS;
         GPX_HIP(hipMemsetAsync(tb, 0, (size_t)BS * sizeof(T), st));
         GPX_TRY(gemm_nt(dtype, OB, rag, OB, Wt + (nfull - 1) * BS, OB, L + nfull * OB * ldl + (nfull - 1) * OB, ldl, tb, OB,
@@ -634,7 +647,12 @@ static int trsv_t(const T *L, int64_t n, int64_t ldl, T *b, T *x, int transpose,
     auto width = [&](int64_t blk) { return (int)std::min<int64_t>(TB, ncols - blk * TB); };
     // operator form: square systems of at least two full blocks, aligned rows, one system
     const bool prebuilt = ops && ops->valid && ops->buf && n % OB == 0 && ops->bytes >= trsv_ops_bytes(dtype, n);
-    if (trsv_ops_enabled() && !bt && ncols == n && (n >= trsv_ops_min_n() || prebuilt) && aligned &&
+    // operators of the LEADING blocks only (built beside the factorisation, gpx_gp_fit; the caller has ordered `st` behind
+    // them): a backward sweep takes the trailing blocks by steps and switches to one launch per block where they begin
+    const int64_t kpart = (ops && !ops->valid && ops->buf && ops->built > 0 && n % OB == 0 && transpose && !bt && ncols == n &&
+                           ops->bytes >= trsv_ops_bytes(dtype, n) && trsv_ops_enabled() && aligned &&
+                           ldl % (16 / (int64_t)sizeof(T)) == 0 && ((uintptr_t)L) % 16 == 0) ? std::min(ops->built, n / OB) : 0;
+    if (kpart == 0 && trsv_ops_enabled() && !bt && ncols == n && (n >= trsv_ops_min_n() || prebuilt) && aligned &&
         ldl % (16 / (int64_t)sizeof(T)) == 0 && ((uintptr_t)L) % 16 == 0) {
         const int64_t nfull = n / OB, rag = n - nfull * OB, BS = (int64_t)OB * OB;
         route_hit(RT_TRSV_OPS);
@@ -652,8 +670,9 @@ static int trsv_t(const T *L, int64_t n, int64_t ldl, T *b, T *x, int transpose,
         } else {
             GPX_TRY(ops_scratch(trsv_ops_bytes(dtype, n), &buf));
         }
-        if (fresh) GPX_TRY(trsv_ops_prepare<T>(L, n, ldl, buf, st, dtype));
-        if (ops) ops->valid = true;
+        // (a factor whose leading blocks already have their operators: only the rest)
+        if (fresh) GPX_TRY(trsv_ops_prepare<T>(L, n, ldl, buf, st, dtype, ops ? std::min(ops->built, nfull) : 0, nfull));
+        if (ops) { ops->valid = true; ops->built = nfull; }
         const T *W = (const T *)buf, *Wt = W + nfull * BS, *Tf = Wt + 2 * nfull * BS, *Tb = Tf + nfull * BS;
         constexpr int NCH = OB / 64;
         if (!transpose) {
@@ -715,9 +734,11 @@ static int trsv_t(const T *L, int64_t n, int64_t ldl, T *b, T *x, int transpose,
                                ldl, Linv, b, x, n, ncols, 0, (nb - 1) * TB, width(nb - 1), ncols, aligned, ablate,
                                sL, sLinv, sv);
     } else {
-        hipLaunchKernelGGL((inv64_kernel<T>), dim3((unsigned)nblk, nbt), dim3(256), 0, st, L, ldl, ncols, Linv, 0,
-                           (T *)nullptr, (T *)nullptr, sL, sLinv);
-        for (int64_t blk = nb - 1; blk >= 0; --blk) {
+        // (kpart > 0: blocks [kpart, nb) here, the leading kpart blocks by their operators below)
+        const int64_t b64 = kpart * (OB / SB);
+        hipLaunchKernelGGL((inv64_kernel<T>), dim3((unsigned)(nblk - b64), nbt), dim3(256), 0, st, L + b64 * SB * (ldl + 1), ldl,
+                           ncols - b64 * SB, Linv + b64 * SB * SB, 0, (T *)nullptr, (T *)nullptr, sL, sLinv);
+        for (int64_t blk = nb - 1; blk >= kpart; --blk) {
             const int64_t k0 = blk * TB, q0 = k0 + TB;
             const int jb = width(blk), qjb = blk + 1 < nb ? width(blk + 1) : 0;
             if (qjb > 0)
@@ -726,6 +747,17 @@ static int trsv_t(const T *L, int64_t n, int64_t ldl, T *b, T *x, int transpose,
             hipLaunchKernelGGL((trsv_bwd_fused<T, 128>), dim3((unsigned)(1 + (qjb > 0 ? cdiv(k0, 128) : 0)), nbt),
                                dim3(TBT), 0, st, L, ldl, Linv, b, x, k0, jb, q0, qjb, (int64_t)0, k0, aligned,
                                ablate, sL, sLinv, sv);
+        }
+        if (kpart > 0) {
+            route_hit(RT_TRSV_OPS);
+            const int64_t nfull = n / OB, BS = (int64_t)OB * OB;
+            const T *W = (const T *)ops->buf, *Wt = W + nfull * BS, *Tb = Wt + 3 * nfull * BS;
+            constexpr int NCH = OB / 64;
+            for (int64_t k = kpart - 1; k >= 0; --k) {
+                const int64_t k0 = k * OB, q0 = k0 + OB;
+                hipLaunchKernelGGL((trsv_op_kernel<T, false>), dim3((unsigned)(NCH + cdiv(k0, 128))), dim3(TBT), 0, st, Wt + k * BS,
+                                   Tb + k * BS, L, ldl, b, x, n, k0, q0, OB, (int64_t)0, k0, NCH, aligned);
+            }
         }
     }
     GPX_LAUNCH_CHECK();
@@ -755,6 +787,35 @@ int trsv_ops_build(int dtype, const void *L, int64_t n, int64_t ldl, TrsvOps *op
     if (dtype == GPX_F64) GPX_TRY(trsv_ops_prepare<double>((const double *)L, n, ldl, ops->buf, st, dtype));
     else GPX_TRY(trsv_ops_prepare<float>((const float *)L, n, ldl, ops->buf, st, dtype));
     ops->valid = true;
+    ops->built = n / OB;
+    return GPX_OK;
+}
+
+bool trsv_ops_ahead_ok(int dtype, const void *L, int64_t n, int64_t ldl)
+{
+    return n >= 2 * OB && n % OB == 0 && trsv_ops_enabled() && ldl % (16 / (int64_t)esize(dtype)) == 0 && ((uintptr_t)L) % 16 == 0 &&
+           ((uintptr_t)L) % (2 * esize(dtype)) == 0 && ldl % 2 == 0;
+}
+
+int trsv_ops_build_upto(int dtype, const void *L, int64_t n, int64_t ldl, TrsvOps *ops, int64_t kend, hipStream_t st)
+{
+    if (!ops || !trsv_ops_ahead_ok(dtype, L, n, ldl)) return GPX_OK;
+    const int64_t nfull = n / OB;
+    kend = std::min(kend, nfull);
+    const size_t need = trsv_ops_bytes(dtype, n);
+    if (ops->built == 0) {
+        if (!ops->buf || ops->bytes < need) {
+            if (ops->buf) { GPX_HIP(hipDeviceSynchronize()); (void)hipFree(ops->buf); ops->buf = nullptr; }
+            GPX_HIP(hipMalloc(&ops->buf, need));
+            ops->bytes = need;
+        }
+        ops->valid = false;
+    }
+    if (kend <= ops->built || !ops->buf) return GPX_OK;
+    if (dtype == GPX_F64) GPX_TRY(trsv_ops_prepare<double>((const double *)L, n, ldl, ops->buf, st, dtype, ops->built, kend));
+    else GPX_TRY(trsv_ops_prepare<float>((const float *)L, n, ldl, ops->buf, st, dtype, ops->built, kend));
+    ops->built = kend;
+    if (kend == nfull) ops->valid = true;
     return GPX_OK;
 }
 

@@ -1086,6 +1086,54 @@ def test_trsv_operator_form_vs_numpy(dtype, n, monkeypatch):
     assert _lib.route_count(_lib.ROUTE_TRSV_OPS) == 0 and _lib.route_count(_lib.ROUTE_TRSV_STEPS) == 1
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("N,ride,tail", [(3072, True, 4), (2560, True, 2), (4096, True, 4), (3072, False, 4), (1024, True, 1)])
+def test_fit_builds_solve_operators_beside_the_factorisation(monkeypatch, dtype, N, ride, tail):
+    """gpx_gp_fit (n a multiple of 512, by default from n = 8192): potrf() reports its progress, the block operators of
+    the leading n / 512 - tail blocks are built on a stream of their own while the last panels are still being factored,
+    and the backward sweep takes the trailing blocks by steps and the leading ones by their operators -- forced here at
+    small n.  Against the route without it (bit-for-bit factor; alpha, log_lh, mean at the solve tolerance) and against
+    the oracle; twice with one handle (the operator buffer is reused across factors), through the two-solve route
+    (a forward sweep completes the set), and a later solve of the same factor (the gradient) completes it too."""
+    d = 3
+    X, y, Xo = orc.synth_inputs(N, d, 16)
+    h, w, s = 1.0, 0.5 * np.sqrt(d), 0.9
+    o = orc.OracleGP("gaussian", (h, w), X, y, s)
+    monkeypatch.setenv("GPX_FIT_OPS_AHEAD_MIN", "1024")
+    monkeypatch.setenv("GPX_FIT_OPS_TAIL", str(tail))
+    if not ride:
+        monkeypatch.setenv("GPX_FIT_RIDE_MAX", "0")
+    out = {}
+    for label, on in (("ahead", "1"), ("plain", "0")):
+        monkeypatch.setenv("GPX_FIT_OPS_AHEAD", on)
+        _lib.route_reset()
+        g = gp.GP(gp.GaussianKernel(h, w), X, y, s=s, dtype=dtype)
+        first = (float(g.log_lh), np.array(g.inv_Kxx_y, dtype=np.float64), np.array(g.mean(Xo), dtype=np.float64),
+                 np.array(g.Lxx, dtype=np.float64))
+        assert (_lib.route_count(_lib.ROUTE_FIT_OPS_AHEAD) > 0) == (on == "1" and N // 512 > tail), (label, N, tail)
+        grad = np.array(g.dloglh_dtheta, dtype=np.float64)       # later solves of the same factor
+        g.set_param("w", 1.3 * w)                                  # a second factor with the same handle ...
+        _ = float(g.log_lh)
+        g.set_param("w", w)                                        # ... and back: must reproduce the first
+        again = (float(g.log_lh), np.array(g.inv_Kxx_y, dtype=np.float64))
+        out[label] = (first, grad, again)
+    (lla, aa, ma, La), ga, (lla2, aa2) = out["ahead"]
+    (llp, ap, mp, Lp), gp_, _ = out["plain"]
+    assert np.array_equal(np.tril(La), np.tril(Lp))
+    assert lla2 == lla and np.array_equal(aa2, aa)
+    if dtype == "float64":
+        np.testing.assert_allclose(aa, ap, rtol=1e-9, atol=1e-12 * np.abs(ap).max())
+        np.testing.assert_allclose(lla, o.log_lh, rtol=1e-10)
+        np.testing.assert_allclose(aa, o.inv_Kxx_y, rtol=1e-8, atol=1e-11 * np.abs(ap).max())
+        np.testing.assert_allclose(ma, o.mean(Xo), rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(ga, o.dloglh_dtheta, rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(ga, gp_, rtol=1e-9, atol=1e-11)
+    else:
+        np.testing.assert_allclose(aa, ap, rtol=2e-3, atol=2e-4 * np.abs(ap).max())
+        np.testing.assert_allclose(lla, o.log_lh, rtol=1e-4)
+        np.testing.assert_allclose(ma, o.mean(Xo), rtol=1e-3, atol=1e-3)
+
+
 # ---- resident panel kernel (gpx_panel.hip): the default route of every panel of <= 256 columns ----
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
