@@ -145,7 +145,12 @@ bool kernel_values_finite(int kernel, const double *p, double s);
 bool panel_res_fold(int64_t rows, int64_t kpre, int64_t kb, size_t es, int64_t lda, const void *base);
 // Per-factor block operators of the single-right-hand-side solves (gpx_solve.hip, "operator form"): owned by
 // whoever owns the factor; `valid` must be cleared whenever the factor changes.  nullptr: built per call.
-struct TrsvOps { void *buf = nullptr; size_t bytes = 0; bool valid = false; int64_t built = 0; };   // built: leading 512-blocks done (trsv_ops_build_upto)
+struct TrsvOps {
+    void *buf = nullptr; size_t bytes = 0;
+    bool valid = false;          // all blocks of the CURRENT factor have their operators
+    int64_t built = 0;           // leading 512-blocks of the current factor that have them (trsv_ops_build_upto)
+    void invalidate() { valid = false; built = 0; }   // a new factor: every owner calls this, never `valid = false` alone
+};
 // Build the operators of an n x n factor (n a multiple of 512) ahead of time on `st`; a later trsv_lower with these ops
 // takes the operator route whatever n is (the distributed solve prepares each diagonal block right after its panel).
 int trsv_ops_build(int dtype, const void *L, int64_t n, int64_t ldl, TrsvOps *ops, hipStream_t st);

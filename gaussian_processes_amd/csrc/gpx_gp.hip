@@ -328,7 +328,7 @@ int gpx_gp_fit(gpx_gp_t *g, int *info)
     route_hit(ride ? RT_FIT_RIDE : RT_FIT_TWO_SOLVES);
     char *row_n = (char *)g->A + (size_t)g->n * g->lda * es;
     if (ride) GPX_HIP(hipMemcpyAsync(row_n, g->y, (size_t)g->n * es, hipMemcpyDeviceToDevice, st));
-    g->ops.valid = false; g->ops.built = 0;               // a new factor: its block operators are rebuilt once
+    g->ops.invalidate();                                  // a new factor: its block operators are rebuilt once
     const bool ahead = env_i64("GPX_FIT_OPS_AHEAD", 1) != 0 && g->n >= env_i64("GPX_FIT_OPS_AHEAD_MIN", 8192) &&
                        trsv_ops_ahead_ok(g->dtype, g->A, g->n, g->lda);
     // ONE instalment, when all but the last `tail` blocks are final: the build is a chain of ~11 launches batched over its

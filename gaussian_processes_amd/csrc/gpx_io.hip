@@ -267,7 +267,7 @@ int gpx_gp_load(gpx_gp_t **out, const char *path)
     for (int i = 0; i < 3; ++i) g->params[i] = hd.params[i];
     g->s = hd.s;
     g->have_data = true; g->have_params = hd.nparams > 0; g->fitted = true; g->have_K = false;
-    g->ops.valid = false;
+    g->ops.invalidate();
     guard.g = nullptr;
     *out = g;
     return GPX_OK;

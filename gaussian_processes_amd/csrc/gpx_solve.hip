@@ -663,7 +663,7 @@ static int trsv_t(const T *L, int64_t n, int64_t ldl, T *b, T *x, int transpose,
                 if (ops->buf) { GPX_HIP(hipStreamSynchronize(st)); (void)hipFree(ops->buf); ops->buf = nullptr; }
                 GPX_HIP(hipMalloc(&ops->buf, trsv_ops_bytes(dtype, n)));
                 ops->bytes = trsv_ops_bytes(dtype, n);
-                ops->valid = false;
+                ops->invalidate();
             }
             buf = ops->buf;
             fresh = !ops->valid;
@@ -783,7 +783,7 @@ int trsv_ops_build(int dtype, const void *L, int64_t n, int64_t ldl, TrsvOps *op
         GPX_HIP(hipMalloc(&ops->buf, need));
         ops->bytes = need;
     }
-    ops->valid = false;
+    ops->invalidate();
     if (dtype == GPX_F64) GPX_TRY(trsv_ops_prepare<double>((const double *)L, n, ldl, ops->buf, st, dtype));
     else GPX_TRY(trsv_ops_prepare<float>((const float *)L, n, ldl, ops->buf, st, dtype));
     ops->valid = true;

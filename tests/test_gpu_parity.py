@@ -1101,6 +1101,7 @@ def test_fit_builds_solve_operators_beside_the_factorisation(monkeypatch, dtype,
     o = orc.OracleGP("gaussian", (h, w), X, y, s)
     monkeypatch.setenv("GPX_FIT_OPS_AHEAD_MIN", "1024")
     monkeypatch.setenv("GPX_FIT_OPS_TAIL", str(tail))
+    monkeypatch.setenv("GPX_TRSV_OPS_MIN", "1024")                 # later solves of the factor take the operator form: they complete the set
     if not ride:
         monkeypatch.setenv("GPX_FIT_RIDE_MAX", "0")
     out = {}
