@@ -4,13 +4,14 @@
 // gp/ext/periodic_c.pyx:18-235 (one exp per entry, single CPU thread) and the
 // `K += eye(n) * s**2` temporaries of gp/gp.py:265.
 //
-// Roofline: HBM write bandwidth.  Algorithmic bytes per launch = n*m*sizeof(T)
-// written (+ (n+m)*d*sizeof(T) read, negligible).  One workgroup owns a
-// 64 x (64*VEC) output tile; both point sets of the tile are staged in LDS once,
-// every lane owns VEC consecutive columns so that a wave stores 1 KiB contiguous
-// per row (16 B per lane), and the squared distance is accumulated directly as
-// sum_k (a_k - b_k)^2 (never |a|^2+|b|^2-2ab: that loses the digits near r = 0
-// that the reference keeps).
+// Roofline: HBM write bandwidth for small d (d = 1: 4.2 TB/s written), the fp64 vector pipe from d ~ 12 up (d = 32:
+// 64 instructions per entry for the distance, ~28 for the exp).  Algorithmic bytes per launch = n*m*sizeof(T)
+// written (+ (n+m)*d*sizeof(T) read, negligible).  One workgroup owns a 64 x (64*VEC) output tile; its column points
+// are staged in LDS once (transposed), every lane owns VEC consecutive columns so that a wave stores 1 KiB contiguous
+// per row (16 B per lane); the row points, the same for every lane of a wave, come through the scalar cache into
+// SGPRs (as LDS broadcasts they made the LDS return path the bound: N = 65536, d = 32: 9.1-9.6 -> 8.05 ms).  The
+// squared distance is accumulated directly as sum_k (a_k - b_k)^2 (never |a|^2+|b|^2-2ab: that loses the digits near
+// r = 0 that the reference keeps).
 #include "gpx_common.h"
 #include "gpx_kernels_dev.h"
 #include <vector>
@@ -79,8 +80,9 @@ __global__ __launch_bounds__(256) void kmat_kernel(const T *__restrict__ x1, int
     constexpr int TNP = TN + VEC;                     // padded row of s2: the transposing stores below
                                                       // (consecutive threads -> consecutive k) spread over the banks
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    // (the row points are staged only where lanes read them as vectors, MODE 4; elsewhere they come through SGPRs)
     T *s1 = reinterpret_cast<T *>(smem_raw);          // [KM_ROWS][d]
-    T *s2 = s1 + (size_t)KM_ROWS * d;                 // [d][TNP]  (transposed: lanes contiguous)
+    T *s2 = s1 + (MODE == 4 ? (size_t)KM_ROWS * d : (size_t)0);   // [d][TNP]  (transposed: lanes contiguous)
 
     const int64_t row0 = (int64_t)blockIdx.y * KM_ROWS;
     const int64_t col0 = (int64_t)blockIdx.x * TN;
@@ -92,7 +94,8 @@ __global__ __launch_bounds__(256) void kmat_kernel(const T *__restrict__ x1, int
     {
         const int64_t lim1 = (n - row0) * d;
         const T *g1 = x1 + row0 * d;
-        for (int idx = tid; idx < KM_ROWS * d; idx += 256) s1[idx] = (idx < lim1) ? g1[idx] : (T)0;
+        if (MODE == 4)
+            for (int idx = tid; idx < KM_ROWS * d; idx += 256) s1[idx] = (idx < lim1) ? g1[idx] : (T)0;
         const int64_t lim2 = (m - col0) * d;
         const T *g2 = x2 + col0 * d;
         const int qd = 256 / d, rd = 256 - qd * d;    // idx += 256  <=>  (c, k) += (qd, rd) with carry
@@ -106,6 +109,7 @@ __global__ __launch_bounds__(256) void kmat_kernel(const T *__restrict__ x1, int
     __syncthreads();
 
     const int lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);      // (uniform by construction; this tells the compiler)
     const int cbase = lane * VEC;
     const T c1 = (T)kp.c[0], c2 = (T)kp.c[1], c3 = (T)kp.c[2], c4 = (T)kp.c[3];
     const T dadd = (T)kp.diag_add;
@@ -130,13 +134,20 @@ __global__ __launch_bounds__(256) void kmat_kernel(const T *__restrict__ x1, int
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) acc[r][v] = s1[rloc + r] - s2[cbase + v];
         } else {
+            // the row points are the same for every lane of a wave: they come through the scalar cache into SGPRs
+            // (wave-uniform addresses), not as four 512-byte LDS broadcasts per coordinate -- with those the LDS return
+            // path, shared by the four SIMDs, was the bound (24 of its cycles per 64 VALU cycles and SIMD)
+            const T *arow[KM_RB];
+#pragma unroll
+            for (int r = 0; r < KM_RB; ++r)
+                arow[r] = x1 + min(row0 + wave_u * 16 + rb + r, n - 1) * d;
             for (int k = 0; k < d; ++k) {
                 T b[VEC];
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) b[v] = s2[(size_t)k * TNP + cbase + v];
 #pragma unroll
                 for (int r = 0; r < KM_RB; ++r) {
-                    const T a = s1[(rloc + r) * d + k];
+                    const T a = arow[r][k];
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) {
                         if (MODE == 3) {
@@ -220,9 +231,9 @@ static int launch_kmat(const void *x1, int64_t n, const void *x2, int64_t m, int
         set_error("periodic derivative members need d == 1 (got %d)", d);
         return GPX_ERR_UNSUPPORTED;
     }
-    const size_t smem = ((size_t)KM_ROWS * d + (size_t)d * (TN + VEC)) * sizeof(T);
+    const size_t smem = ((mode == 4 ? (size_t)KM_ROWS * d : (size_t)0) + (size_t)d * (TN + VEC)) * sizeof(T);
     if (smem > 96 * 1024) {
-        set_error("kmat: d = %d too large for the LDS-staged tile (max 64 for f64)", d);
+        set_error("kmat: d = %d too large for the LDS-staged tile (96 KiB of column points)", d);
         return GPX_ERR_UNSUPPORTED;
     }
     const int aligned = (ld % VEC == 0) && (((uintptr_t)out) % 16 == 0);
