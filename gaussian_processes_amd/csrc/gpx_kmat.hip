@@ -295,19 +295,16 @@ __global__ __launch_bounds__(256) void mean_kernel(const T *__restrict__ xo, int
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *sx = reinterpret_cast<T *>(smem_raw);            // [d][MCP] chunk of x, transposed
-    T *so = sx + (size_t)d * MCP;                       // [MP][d] test points
     __shared__ double red[4][MP];
 
     const int tid = threadIdx.x;
     const int64_t p0 = (int64_t)blockIdx.x * MP;
-    {
-        const int64_t lim = (m - p0) * d;
-        const T *g = xo + p0 * d;
-        for (int idx = tid; idx < MP * d; idx += 256) so[idx] = (idx < lim) ? g[idx] : (T)0;
-    }
     double acc[MP];
 #pragma unroll
     for (int pp = 0; pp < MP; ++pp) acc[pp] = 0.0;
+    const T *orow[MP];
+#pragma unroll
+    for (int pp = 0; pp < MP; ++pp) orow[pp] = xo + min(p0 + pp, m - 1) * d;
 
     const T c1 = (T)kp.c[0], c2 = (T)kp.c[1], c3 = (T)kp.c[2], c4 = (T)kp.c[3];
     const int qd = 256 / d, rd = 256 - qd * d;          // idx += 256  <=>  (c, k) += (qd, rd) with carry
@@ -332,17 +329,19 @@ __global__ __launch_bounds__(256) void mean_kernel(const T *__restrict__ xo, int
             T r[MP];
 #pragma unroll
             for (int pp = 0; pp < MP; ++pp) r[pp] = (T)0;
+            // (the test points are the same for every lane: SGPR operands through the scalar cache, as in kmat_kernel)
             for (int k = 0; k < d; ++k) {
                 const T b = sx[(size_t)k * MCP + tid];
 #pragma unroll
                 for (int pp = 0; pp < MP; ++pp) {
+                    const T a = orow[pp][k];
                     if (KIND == GPX_KERNEL_GAUSSIAN) {
-                        const T t = so[pp * d + k] - b;
+                        const T t = a - b;
                         r[pp] = fma(t, t, r[pp]);
                     } else if (FORM == 1) {
-                        r[pp] = so[pp * d + k] - b;                   // d == 1: the signed difference
+                        r[pp] = a - b;                                // d == 1: the signed difference
                     } else {
-                        const T sn = sin((T)0.5 * (so[pp * d + k] - b) / (T)kp.c[2]);
+                        const T sn = sin((T)0.5 * (a - b) / (T)kp.c[2]);
                         r[pp] = fma(sn, sn, r[pp]);
                     }
                 }
@@ -408,7 +407,7 @@ template <typename T>
 static int launch_mean(int kernel, const void *xo, int64_t m, const void *x, int64_t n, int d,
                        const KParams &kp, const void *alpha, void *out, hipStream_t st)
 {
-    const size_t smem = ((size_t)d * MCP + (size_t)MP * d) * sizeof(T);
+    const size_t smem = (size_t)d * MCP * sizeof(T);
     if (smem > 96 * 1024) {
         set_error("mean: d = %d too large", d);
         return GPX_ERR_UNSUPPORTED;
