@@ -475,7 +475,9 @@ __global__ __launch_bounds__(256) void transpose_subdiag_kernel(const T *__restr
 }
 
 // one block step: workgroups [0, nchain) solve block k (rows k0 ..), the others stream the neighbour's far panel
-template <typename T, bool FWD>
+// PARTS lanes per row: 8 (64 rows per workgroup, 8 workgroups a block) or 32 (16 rows, 32 workgroups -- a workgroup
+// streams 128 KB of operators instead of 512: the block's two mat-vecs are bound by what ONE CU can pull)
+template <typename T, bool FWD, int PARTS>
 __global__ __launch_bounds__(TBT) void trsv_op_kernel(const T *__restrict__ Wk, const T *__restrict__ Tk,
                                                       const T *__restrict__ L, int64_t ldl, T *__restrict__ rhs,
                                                       T *__restrict__ x, int64_t n, int64_t k0, int64_t p0, int pjb,
@@ -497,16 +499,17 @@ __global__ __launch_bounds__(TBT) void trsv_op_kernel(const T *__restrict__ Wk, 
         szp[i] = (Tk && i < pjb) ? x[p0 + i] : (T)0;
     }
     __syncthreads();
-    const int r = tid >> 3, part = tid & 7;
-    const int row = 64 * (int)blockIdx.x + r;
+    constexpr int ROWS = TBT / PARTS;                 // rows per workgroup
+    const int r = tid / PARTS, part = tid % PARTS;
+    const int row = ROWS * (int)blockIdx.x + r;
     const T *wrow = Wk + (int64_t)row * OB, *trow = Tk ? Tk + (int64_t)row * OB : nullptr;
     T acc = (T)0;
     // branch-free on purpose (the zero half of the triangular W_k is read too): with a per-row triangle test
     // the loads cannot be batched and every iteration pays a memory round trip (measured 30 us instead of 8)
     if (trow) {
 #pragma unroll 8
-        for (int i = 0; i < OB / 16; ++i) {
-            const int c = 16 * i + 2 * part;
+        for (int i = 0; i < OB / (2 * PARTS); ++i) {
+            const int c = 2 * PARTS * i + 2 * part;
             T w0, w1, t0, t1;
             load2(wrow + c, true, w0, w1);
             load2(trow + c, true, t0, t1);
@@ -517,15 +520,15 @@ __global__ __launch_bounds__(TBT) void trsv_op_kernel(const T *__restrict__ Wk, 
         }
     } else {
 #pragma unroll 8
-        for (int i = 0; i < OB / 16; ++i) {
-            const int c = 16 * i + 2 * part;
+        for (int i = 0; i < OB / (2 * PARTS); ++i) {
+            const int c = 2 * PARTS * i + 2 * part;
             T w0, w1;
             load2(wrow + c, true, w0, w1);
             acc = fma(w0, sv[c], acc);
             acc = fma(w1, sv[c + 1], acc);
         }
     }
-    acc = lanes8_sum(acc);
+    acc = PARTS == 8 ? lanes8_sum(acc) : lanes32_sum(acc);
     if (part == 0) x[k0 + row] = acc;
 }
 
@@ -674,14 +677,20 @@ static int trsv_t(const T *L, int64_t n, int64_t ldl, T *b, T *x, int transpose,
         if (fresh) GPX_TRY(trsv_ops_prepare<T>(L, n, ldl, buf, st, dtype, ops ? std::min(ops->built, nfull) : 0, nfull));
         if (ops) { ops->valid = true; ops->built = nfull; }
         const T *W = (const T *)buf, *Wt = W + nfull * BS, *Tf = Wt + 2 * nfull * BS, *Tb = Tf + nfull * BS;
-        constexpr int NCH = OB / 64;
+        const bool wide = env_i64("GPX_TRSV_OP_PARTS", 32) == 32;
+        const int NCH = wide ? OB / (TBT / 32) : OB / (TBT / 8);
         if (!transpose) {
             for (int64_t k = 0; k < nfull; ++k) {
                 const int64_t k0 = k * OB, far0 = k0 + OB;
                 const int64_t nfar = k > 0 ? cdiv(n - far0, 64) : 0;
-                hipLaunchKernelGGL((trsv_op_kernel<T, true>), dim3((unsigned)(NCH + nfar)), dim3(TBT), 0, st, W + k * BS,
-                                   k > 0 ? Tf + k * BS : (const T *)nullptr, L, ldl, b, x, n, k0, k0 - OB, k > 0 ? OB : 0, far0, n,
-                                   NCH, aligned);
+                if (wide)
+                    hipLaunchKernelGGL((trsv_op_kernel<T, true, 32>), dim3((unsigned)(NCH + nfar)), dim3(TBT), 0, st, W + k * BS,
+                                       k > 0 ? Tf + k * BS : (const T *)nullptr, L, ldl, b, x, n, k0, k0 - OB, k > 0 ? OB : 0, far0, n,
+                                       NCH, aligned);
+                else
+                    hipLaunchKernelGGL((trsv_op_kernel<T, true, 8>), dim3((unsigned)(NCH + nfar)), dim3(TBT), 0, st, W + k * BS,
+                                       k > 0 ? Tf + k * BS : (const T *)nullptr, L, ldl, b, x, n, k0, k0 - OB, k > 0 ? OB : 0, far0, n,
+                                       NCH, aligned);
             }
             if (rag > 0) {                                           // ragged last block: the near tile, then the old chain
                 const int64_t k0 = nfull * OB, p0 = k0 - OB;
@@ -704,9 +713,14 @@ static int trsv_t(const T *L, int64_t n, int64_t ldl, T *b, T *x, int transpose,
                 const int64_t k0 = k * OB, q0 = k0 + OB;
                 const int qjb = (k + 1 < nfull) ? OB : (int)rag;
                 const int64_t nfar = qjb > 0 ? cdiv(k0, 128) : 0;
-                hipLaunchKernelGGL((trsv_op_kernel<T, false>), dim3((unsigned)(NCH + nfar)), dim3(TBT), 0, st, Wt + k * BS,
-                                   qjb > 0 ? Tb + k * BS : (const T *)nullptr, L, ldl, b, x, n, k0, q0, qjb, (int64_t)0, k0, NCH,
-                                   aligned);
+                if (wide)
+                    hipLaunchKernelGGL((trsv_op_kernel<T, false, 32>), dim3((unsigned)(NCH + nfar)), dim3(TBT), 0, st, Wt + k * BS,
+                                       qjb > 0 ? Tb + k * BS : (const T *)nullptr, L, ldl, b, x, n, k0, q0, qjb, (int64_t)0, k0, NCH,
+                                       aligned);
+                else
+                    hipLaunchKernelGGL((trsv_op_kernel<T, false, 8>), dim3((unsigned)(NCH + nfar)), dim3(TBT), 0, st, Wt + k * BS,
+                                       qjb > 0 ? Tb + k * BS : (const T *)nullptr, L, ldl, b, x, n, k0, q0, qjb, (int64_t)0, k0, NCH,
+                                       aligned);
             }
         }
         GPX_LAUNCH_CHECK();
@@ -752,11 +766,16 @@ static int trsv_t(const T *L, int64_t n, int64_t ldl, T *b, T *x, int transpose,
             route_hit(RT_TRSV_OPS);
             const int64_t nfull = n / OB, BS = (int64_t)OB * OB;
             const T *W = (const T *)ops->buf, *Wt = W + nfull * BS, *Tb = Wt + 3 * nfull * BS;
-            constexpr int NCH = OB / 64;
+            const bool wide = env_i64("GPX_TRSV_OP_PARTS", 32) == 32;
+            const int NCH = wide ? OB / (TBT / 32) : OB / (TBT / 8);
             for (int64_t k = kpart - 1; k >= 0; --k) {
                 const int64_t k0 = k * OB, q0 = k0 + OB;
-                hipLaunchKernelGGL((trsv_op_kernel<T, false>), dim3((unsigned)(NCH + cdiv(k0, 128))), dim3(TBT), 0, st, Wt + k * BS,
-                                   Tb + k * BS, L, ldl, b, x, n, k0, q0, OB, (int64_t)0, k0, NCH, aligned);
+                if (wide)
+                    hipLaunchKernelGGL((trsv_op_kernel<T, false, 32>), dim3((unsigned)(NCH + cdiv(k0, 128))), dim3(TBT), 0, st, Wt + k * BS,
+                                       Tb + k * BS, L, ldl, b, x, n, k0, q0, OB, (int64_t)0, k0, NCH, aligned);
+                else
+                    hipLaunchKernelGGL((trsv_op_kernel<T, false, 8>), dim3((unsigned)(NCH + cdiv(k0, 128))), dim3(TBT), 0, st, Wt + k * BS,
+                                       Tb + k * BS, L, ldl, b, x, n, k0, q0, OB, (int64_t)0, k0, NCH, aligned);
             }
         }
     }
