@@ -467,17 +467,18 @@ static int reserve_cus(int64_t n)
     return n <= 12288 ? 32 : 0;      // measured: n = 8192 13.3 -> 12.3 ms per factorisation, n = 16384 41.9 -> 42.5
 }
 
-// Lock-step batches: without reserved CUs the panel stream's first kernel of every step (a handful of leaf
-// workgroups) is not dispatched until the trailing update of all matrices has drained -- measured with 8
-// matrices of n = 8192: that leaf "takes" 950 - 1030 us, the length of the update it should run under -- so
-// the look-ahead overlaps nothing and every step is update + chain.
-// With many matrices the trailing update is so long that the exposed chain no longer matters and the masked
-// CUs cost more (64 matrices: 0.214 s without, 0.225 s with 16 reserved; 8 matrices: 0.290 / 0.272 s).
+// Lock-step batches: no reservation.  (Rounds 1-2 set 16 CUs aside for batches of up to 16 matrices: with the chain of
+// small launches a panel then was, its first kernel was not dispatched until the update of all matrices had drained.
+// With one resident launch per panel 0 / 16 / 32 reserved CUs are within 1 % of each other for 8, 16 and 64 matrices
+// (tools/r3_batch8.py) -- and a SECOND CU-masked stream beside the single fits' one costs a later batch 6 % whenever a
+// single-matrix factorisation ran earlier on the thread (tools/r3_batch_after_fit.py: 29.3 -> 31.0 ms for 8 x 8192;
+// 29.4 either way with one masked stream).  GPX_POTRF_RESERVE_CUS_BATCH still forces a value.)
 static int reserve_cus_batch(int64_t n, int count)
 {
     const int64_t env = env_i64("GPX_POTRF_RESERVE_CUS_BATCH", -1);
     if (env >= 0) return (int)std::min<int64_t>(128, env);
-    return (n <= 12288 && count <= 16) ? 16 : 0;
+    (void)n; (void)count;
+    return 0;
 }
 
 // Right-looking blocked Cholesky with one-panel look-ahead: while the main stream
