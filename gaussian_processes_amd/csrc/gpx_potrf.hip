@@ -464,7 +464,12 @@ static int reserve_cus(int64_t n)
 {
     const int64_t env = env_i64("GPX_POTRF_RESERVE_CUS", -1);
     if (env >= 0) return (int)std::min<int64_t>(128, env);
-    return n <= 12288 ? 32 : 0;      // measured: n = 8192 13.3 -> 12.3 ms per factorisation, n = 16384 41.9 -> 42.5
+    // Round 1 (a panel = a dozen small launches): 32 CUs for n <= 12288, n = 8192 13.3 -> 12.3 ms.  With one resident
+    // launch per panel the reservation no longer pays -- round 3, 32 vs 0 reserved: n = 2048 0.965 / 0.957 ms, 4096
+    // 2.084 / 2.086, 8192 6.209 / 6.169 (fp32 4.633 / 4.604), 12288 14.42 / 14.38 -- and no CU-masked stream is created
+    // at all by default (they have no priority, must outlive every pooled event, and two of them slow each other down).
+    (void)n;
+    return 0;
 }
 
 // Lock-step batches: no reservation.  (Rounds 1-2 set 16 CUs aside for batches of up to 16 matrices: with the chain of

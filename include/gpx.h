@@ -43,8 +43,8 @@
  *     they synchronise their stream before they return -- the one exception is
  *     gpx_gp_fit(gp, NULL), which only enqueues -- and different handles are
  *     safe to use concurrently from different host threads.
- *     The first factorisation a host thread issues creates that thread's streams
- *     (one of them CU-masked) and scratch blocks: ~30 ms once (measured: 8 x n = 8192
+ *     The first factorisation a host thread issues creates that thread's look-ahead
+ *     stream and scratch blocks: tens of ms once (measured with round 2's streams: 8 x n = 8192
  *     lock-step, 29 ms from a long-lived thread, 58 ms from a thread started per call)
  *     -- keep worker threads alive across calls.
  *   - "host" entry points (gpx_gaussian_c_*, gpx_periodic_c_*, gpx_gp_c_*,
