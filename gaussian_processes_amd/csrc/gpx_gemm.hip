@@ -1025,7 +1025,7 @@ int syrk_bc(int dtype, int64_t n, int64_t row_begin, void *Cloc, int64_t ldc, in
                 // ~75 us where 4 / 3 / 2 would do (gpurun_out/r3_timeline8192.txt).  Up to GPX_GEMM_FINE_TILES tiles the
                 // chunk is one tile COLUMN of a band (8 tiles: the same 8 A-slices as its neighbours on that XCD, one
                 // B-slice), which keeps the slices per resident tile the same and evens the XCDs out to within 8 tiles.
-                int cl = total <= env_i64("GPX_GEMM_FINE_TILES", 8192) ? 3 : 6;
+                int cl = total <= env_i64("GPX_GEMM_FINE_TILES", 16384) ? 3 : 6;
                 while (cl > 2 && ((int64_t)8 << cl) > total) --cl;   // few tiles: smaller chunks, every XCD still gets some
                 fm.ecl = cl;
                 if (total <= 0) return GPX_OK;

@@ -549,7 +549,7 @@ int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t
     GPX_TRY(g_la.get(&ep));
     GPX_TRY(potrf_panel(dtype, A, lda, N, 0, 0, kb, info_dev, q, bt, 0, ep));
     hipEvent_t e_rest = nullptr;                                // fires when the trailing update of the step before is done
-    const bool host_paced = !bt && n <= env_i64("GPX_POTRF_HOST_PACED", 12288);
+    const bool host_paced = !bt && n <= env_i64("GPX_POTRF_HOST_PACED", 16384);
     while (true) {
         const int64_t r = k0 + kb;
         if (masked && n - r <= reserve_below) GPX_TRY(switch_to(masked));
@@ -569,7 +569,7 @@ int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t
             GPX_HIP(hipEventRecord(e, st));
             GPX_HIP(hipStreamWaitEvent(q, e, 0));
         } else if (e_rest) {
-            // Host-paced panels (single matrices, n <= 12288: the sizes whose factorisation is a chain of panels).  A wait on an
+            // Host-paced panels (single matrices, n <= 16384: the sizes whose panels take the update to their left themselves).  A wait on an
             // event of another stream that is still pending at ENQUEUE time becomes a barrier packet in front of the panel;
             // the command processor takes ~6 us over it even when the event has long fired by then (tools/sync_probe.hip:
             // 1.5 us between two kernels of a stream, 6.7 with a record, 15 - 18 with a cross-stream wait).  The update of

@@ -216,7 +216,7 @@ int gpx_d_gemm_nt(int dtype, int64_t M, int64_t N, int64_t K, double alpha,
  * info_dev: DEVICE int; 0 on success, j (1-based) if the j-th leading minor is
  * not positive definite (pivot <= 0 or NaN), as LAPACK reports it; negative: an
  * internal failure (the host entry points turn that into GPX_ERR_INTERNAL).
- * For n <= 12288 the call paces its panel launches on the device's progress (it
+ * For n <= 16384 the call paces its panel launches on the device's progress (it
  * waits on the host for the previous step's update instead of putting a barrier
  * packet in front of every panel): it returns when most of the factorisation
  * has run, not at once; the result is still only complete in stream order. */
@@ -299,7 +299,7 @@ int gpx_gp_set_params(gpx_gp_t *gp, const double *params, double s);
 int gpx_gp_set_K(gpx_gp_t *gp, const double *Kxx, int64_t ld);
 /* kernel build (lower) -> potrf -> alpha -> logdet, y^T alpha.  info != NULL: *info (HOST)
  * is filled and the call returns after the fit has completed.  info == NULL: the call returns without waiting for
- * the end of the fit (the next gpx_gp_* getter synchronises); for n <= 12288 it paces its panel launches on the
+ * the end of the fit (the next gpx_gp_* getter synchronises); for n <= 16384 it paces its panel launches on the
  * device's progress, so it returns when most of the factorisation has run, not at once. */
 int gpx_gp_fit(gpx_gp_t *gp, int *info);
 /* log marginal likelihood with the reference's conventions (gp/gp.py:360-367,
