@@ -316,7 +316,7 @@ static int d2lh_t(gpx_gp *g, double *dlh_out, double *d2lh_out, double *d2loglh_
         hipLaunchKernelGGL((eye_fill_kernel<T>), grid, block, 0, st, (T *)X.p, n, lda);
         GPX_LAUNCH_CHECK();
         GPX_HIP(hipMemsetAsync(D.W.p, 0, (size_t)n * lda * sizeof(T), st));
-        GPX_TRY(trsm_right_lt(g->dtype, g->A, n, lda, X.p, n, lda, st, 1));
+        GPX_TRY(trsm_right_lt(g->dtype, g->A, n, lda, X.p, n, lda, st, 1, &g->ops));
         GPX_TRY(gemm_nt(g->dtype, n, n, n, X.p, lda, X.p, lda, D.W.p, lda, 1.0, GPX_FULL, 0, 0, st, 0, 1));
     }
     // a_i = alpha . v_i ; vu_ij = v_j . u_i   (device dots, one launch each: count = 1)

@@ -467,7 +467,7 @@ int gpx_gp_cov(gpx_gp_t *g, const double *xo, int64_t m, double *out)
     // X = Kxox (m x n); V^T = X L^-T; cov = Kxoxo - V^T V   (gp/gp.py:622-625 without K^-1)
     GPX_TRY(kmat(g->dtype, g->kernel, GPX_K, dxo.p, m, g->x, g->n, g->d, g->params, 0.0, GPX_FULL, X.p,
                  ldx, g->st));
-    GPX_TRY(trsm_right_lt(g->dtype, g->A, g->n, g->lda, X.p, m, ldx, g->st));
+    GPX_TRY(trsm_right_lt(g->dtype, g->A, g->n, g->lda, X.p, m, ldx, g->st, 0, &g->ops));
     GPX_TRY(kmat(g->dtype, g->kernel, GPX_K, dxo.p, m, dxo.p, m, g->d, g->params, 0.0, GPX_FULL, C.p,
                  ldc, g->st));
     GPX_TRY(gemm_nt(g->dtype, m, m, g->n, X.p, ldx, X.p, ldx, C.p, ldc, -1.0, GPX_FULL, 0, 0, g->st));
@@ -520,7 +520,7 @@ int gpx_gp_cov_from_K(gpx_gp_t *g, const double *Kxox, const double *Kxoxo, int6
             GPX_TRY(upload_f64(g->dtype, (float *)C.p + r * ldc, Kxoxo + r * m, m, g->st));
         }
     }
-    GPX_TRY(trsm_right_lt(g->dtype, g->A, n, g->lda, X.p, m, ldx, g->st));
+    GPX_TRY(trsm_right_lt(g->dtype, g->A, n, g->lda, X.p, m, ldx, g->st, 0, &g->ops));
     GPX_TRY(gemm_nt(g->dtype, m, m, n, X.p, ldx, X.p, ldx, C.p, ldc, -1.0, GPX_FULL, 0, 0, g->st));
     return download_f64(g->dtype, out, m, C.p, ldc, m, m, 0, g->st);
 }
@@ -567,7 +567,7 @@ int gpx_gp_get_inv_Kxx(gpx_gp_t *g, double *out, int64_t ld)
     GPX_LAUNCH_CHECK();
     GPX_HIP(hipMemsetAsync(C.p, 0, (size_t)n * lda * es, g->st));
     // X = I L^-T = L^-T ; K^-1 = L^-T L^-1 = X X^T   (gp/gp.py:311-312)
-    GPX_TRY(trsm_right_lt(g->dtype, g->A, n, lda, X.p, n, lda, g->st, 1));
+    GPX_TRY(trsm_right_lt(g->dtype, g->A, n, lda, X.p, n, lda, g->st, 1, &g->ops));
     GPX_TRY(gemm_nt(g->dtype, n, n, n, X.p, lda, X.p, lda, C.p, lda, 1.0, GPX_FULL, 0, 0, g->st, 0, 1));
     return download_f64(g->dtype, out, ld, C.p, lda, n, n, 0, g->st);
 }
@@ -603,7 +603,7 @@ int gpx_gp_dloglh_dtheta(gpx_gp_t *g, double *out)
     else hipLaunchKernelGGL((eye_kernel<float>), grid, block, 0, g->st, (float *)X.p, n, lda);
     GPX_LAUNCH_CHECK();
     GPX_HIP(hipMemsetAsync(W.p, 0, (size_t)n * lda * es, g->st));
-    GPX_TRY(trsm_right_lt(g->dtype, g->A, n, lda, X.p, n, lda, g->st, 1));
+    GPX_TRY(trsm_right_lt(g->dtype, g->A, n, lda, X.p, n, lda, g->st, 1, &g->ops));
     GPX_TRY(gemm_nt(g->dtype, n, n, n, X.p, lda, X.p, lda, W.p, lda, 1.0, GPX_LOWER, 0, 0, g->st, 0, 1));
     double p4[4];
     GPX_TRY(dloglh_reduce(g->dtype, g->kernel, g->x, n, g->d, g->params, g->alpha, W.p, lda, (double *)part.p,

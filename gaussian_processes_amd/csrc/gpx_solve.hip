@@ -910,11 +910,56 @@ int panel_gemv_t(int dtype, const void *Lp, int64_t ldl, int64_t rows, int64_t n
 // x_upper: X is upper triangular on entry (the identity, when L^-T itself is wanted): rows beyond
 // the current block are still zero in its columns, so every step works on the leading k0 + kb rows
 // only -- a third of the flops.
+// grow-only device scratch of trsm_right_lt's operator route: one m x 512 block of X (one per host thread)
+struct TrsmScratch { void *p = nullptr; size_t bytes = 0; int device = -1; };
+static thread_local TrsmScratch g_trsm_scr;
+static int trsm_scratch(size_t bytes, void **out)
+{
+    int dev = 0;
+    GPX_HIP(hipGetDevice(&dev));
+    if (g_trsm_scr.device != dev || g_trsm_scr.bytes < bytes) {
+        if (g_trsm_scr.p && g_trsm_scr.device == dev) { GPX_HIP(hipDeviceSynchronize()); (void)hipFree(g_trsm_scr.p); }
+        g_trsm_scr.p = nullptr; g_trsm_scr.bytes = 0; g_trsm_scr.device = dev;
+        GPX_HIP(hipMalloc(&g_trsm_scr.p, bytes));
+        g_trsm_scr.bytes = bytes;
+    }
+    *out = g_trsm_scr.p;
+    return GPX_OK;
+}
+
 int trsm_right_lt(int dtype, const void *L, int64_t n, int64_t ldl, void *X, int64_t m, int64_t ldx,
-                  hipStream_t st, int x_upper)
+                  hipStream_t st, int x_upper, TrsvOps *ops)
 {
     if (n <= 0 || m <= 0) return GPX_OK;
     const size_t es = esize(dtype);
+    // Operator route (the caller's TrsvOps of THIS factor, n a multiple of 512): the substitution inside a 512-block,
+    //   X[:, blk] <- X[:, blk] inv(L_kk)^T,
+    // is ONE product with W_k = inv(L_kk) (into a scratch block, copied back) instead of eight 64-wide substitutions with
+    // seven small products between them -- 16 latency-bound launches a block, which were most of a posterior covariance
+    // (n = 8192, m = 1024: cov 11.0 -> see DESIGN 3.3).  The operators are completed here if the factor has only some.
+    if (ops && trsv_ops_ahead_ok(dtype, L, n, ldl) && env_i64("GPX_TRSM_OPS", 1) != 0 && ldx % (16 / (int64_t)es) == 0 &&
+        ((uintptr_t)X) % 16 == 0) {
+        const int64_t nfull = n / OB, BS = (int64_t)OB * OB;
+        if (!ops->valid) GPX_TRY(trsv_ops_build_upto(dtype, L, n, ldl, ops, nfull, st));
+        if (ops->valid && ops->buf) {
+            route_hit(RT_TRSM_OPS);
+            void *scr = nullptr;
+            GPX_TRY(trsm_scratch((size_t)m * OB * es, &scr));
+            const char *W = (const char *)ops->buf;
+            for (int64_t k = 0; k < nfull; ++k) {
+                const int64_t k0 = k * OB, r = k0 + OB;
+                const int64_t me = x_upper ? std::min(m, r) : m;
+                char *Xk = (char *)X + k0 * es;
+                GPX_TRY(gemm_nt(dtype, me, OB, OB, Xk, ldx, W + (size_t)k * BS * es, OB, scr, OB, 1.0, GPX_FULL, 0, 0, st, 1));
+                GPX_HIP(hipMemcpy2DAsync(Xk, (size_t)ldx * es, scr, (size_t)OB * es, (size_t)OB * es, (size_t)me,
+                                         hipMemcpyDeviceToDevice, st));
+                if (r < n)
+                    GPX_TRY(gemm_nt(dtype, me, n - r, OB, Xk, ldx, (const char *)L + (r * ldl + k0) * es, ldl, (char *)X + r * es, ldx,
+                                    -1.0, GPX_FULL, 0, 0, st));
+            }
+            return GPX_OK;
+        }
+    }
     const int64_t nb_env = env_i64("GPX_TRSM_NB", 0);
     const int64_t NB = nb_env > 0 ? nb_env : (n >= 8192 ? 512 : 256);
     auto Lp = [&](int64_t r, int64_t c) { return (const char *)L + (r * ldl + c) * es; };

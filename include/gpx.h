@@ -172,6 +172,7 @@ int gpx_prof_read(int cls, double *launches, double *total_ms, double *total_wor
 #define GPX_ROUTE_MG_BCAST_ONE   10   /* multi-GPU panel broadcast: one collective per row chunk              */
 #define GPX_ROUTE_MG_BCAST_SAG   11   /* multi-GPU panel broadcast: scatter + all-gather (point to point)     */
 #define GPX_ROUTE_FIT_OPS_AHEAD  12   /* gpx_gp_fit: block operators of the solves built beside the factorisation */
+#define GPX_ROUTE_TRSM_OPS       13   /* X L^-T (posterior covariance, inverse): in-block step as one product with inv(L_kk) */
 int gpx_debug_route_count(int route, int64_t *count);
 int gpx_debug_route_reset(void);
 

@@ -1135,6 +1135,37 @@ def test_fit_builds_solve_operators_beside_the_factorisation(monkeypatch, dtype,
         np.testing.assert_allclose(ma, o.mean(Xo), rtol=1e-3, atol=1e-3)
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("N", [1024, 1536, 2048])
+def test_cov_and_inverse_through_the_block_operators(monkeypatch, dtype, N):
+    """X L^-T of the posterior covariance (gp/gp.py:599-625) and of inv_Kxx (:296-312) with n a multiple of 512: the
+    substitution inside a 512-block is one product with inv(L_kk) from the factor's block operators (completed on
+    demand) instead of eight 64-wide substitutions.  Against the 64-wide route (GPX_TRSM_OPS=0) and the oracle; the route
+    counter says which one ran."""
+    d = 2
+    X, y, Xo = orc.synth_inputs(N, d, 37)
+    h, w, s = 1.0, 0.5 * np.sqrt(d), 0.9
+    o = orc.OracleGP("gaussian", (h, w), X, y, s)
+    out = {}
+    for label, on in (("ops", "1"), ("steps", "0")):
+        monkeypatch.setenv("GPX_TRSM_OPS", on)
+        _lib.route_reset()
+        g = gp.GP(gp.GaussianKernel(h, w), X, y, s=s, dtype=dtype)
+        out[label] = (np.array(g.cov(Xo), dtype=np.float64), np.array(g.inv_Kxx, dtype=np.float64),
+                      np.array(g.dloglh_dtheta, dtype=np.float64))
+        assert (_lib.route_count(_lib.ROUTE_TRSM_OPS) > 0) == (on == "1"), label
+    if dtype == "float64":
+        for label in out:
+            np.testing.assert_allclose(out[label][0], o.cov(Xo), rtol=1e-7, atol=1e-10, err_msg=label)
+            np.testing.assert_allclose(out[label][1], o.inv_Kxx, rtol=1e-7, atol=1e-9, err_msg=label)
+            np.testing.assert_allclose(out[label][2], o.dloglh_dtheta, rtol=1e-7, atol=1e-9, err_msg=label)
+        np.testing.assert_allclose(out["ops"][0], out["steps"][0], rtol=1e-10, atol=1e-12)
+    else:
+        for label in out:
+            np.testing.assert_allclose(out[label][0], o.cov(Xo), rtol=1e-2, atol=5e-3, err_msg=label)
+            np.testing.assert_allclose(out[label][2], o.dloglh_dtheta, rtol=2e-2, atol=1e-1, err_msg=label)
+
+
 # ---- resident panel kernel (gpx_panel.hip): the default route of every panel of <= 256 columns ----
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
