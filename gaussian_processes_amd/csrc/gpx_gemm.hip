@@ -900,7 +900,11 @@ int gemm_nt(int dtype, int64_t M, int64_t N, int64_t K, const void *A, int64_t l
                       ((uintptr_t)A) % 16 == 0 && ((uintptr_t)B) % 16 == 0;
     route_hit(fast ? RT_GEMM_FAST : RT_GEMM_GENERIC);
     if (fast) {
-        if (N <= 64 && fast_bm() == 128) {
+        // few 128 x 128 tiles (a product that cannot fill the chip anyway): 128 x 64 tiles halve the time of the one round
+        // there is -- the posterior covariance's in-block products, 1024 x 512 x 512: 32 tiles
+        const int64_t t128 = cdiv(M, 128) * cdiv(N, 128) * (bt ? (int64_t)bt->count * std::max(1, bt->count2) : 1);
+        const bool few = !ktri && tri == GPX_FULL && t128 <= env_i64("GPX_GEMM_BN64_TILES", 256);
+        if ((N <= 64 || few) && fast_bm() == 128) {
             if (dtype == GPX_F64)
                 return launch_gemm_nt_fast<double, 64, 0, 128>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0, col0,
                                                                st, nullptr, -1.0, beta0, 0, bt);
