@@ -469,6 +469,7 @@ struct GemmMap {
     // block-cyclic ranks (P > 1): local tile column j is GLOBAL tile column j + (j / etpb) * epm1t (etpb = nb / 128
     // tile columns per block column, epm1t = (P - 1) * etpb); the triangle is tested in global columns
     int etpb, epm1t;
+    int ecs;           // 1: tile columns are 64 wide (BN = 64; etpb, epm1t, eTC and j count 64-column units, eD / rows stay in 128s)
     int epre[66];
 };
 static unsigned long long *g_gemm_stamps = nullptr;
@@ -527,7 +528,8 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_nt_fast_kernel(int64_t M, int6
         // columns that hold all h rows: local columns whose global column is <= dj
         int jfull = 0;
         if (dj >= 0) {
-            const int period = fm.etpb + fm.epm1t, qd = (dj + 1) / period, rem = (dj + 1) - qd * period;
+            const int djc = (dj + 1) << fm.ecs;                       // tile columns (of BN) up to the band's first row tile
+            const int period = fm.etpb + fm.epm1t, qd = djc / period, rem = djc - qd * period;
             jfull = min(fm.eTC, qd * fm.etpb + min(rem, fm.etpb));
         }
         int j, r;
@@ -535,9 +537,9 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_nt_fast_kernel(int64_t M, int6
         else {
             tt -= jfull * h;
             j = jfull;
-            for (;;) {                                                // at most 8 partial columns
+            for (;;) {                                                // at most 8 (16 with 64-wide columns) partial columns
                 const int gj = j + (j / fm.etpb) * fm.epm1t;
-                const int rmin = max(0, gj - dj), cnt = max(0, h - rmin);
+                const int rmin = max(0, (gj >> fm.ecs) - dj), cnt = max(0, h - rmin);
                 if (tt < cnt) { r = rmin + tt; break; }
                 tt -= cnt; ++j;
             }
@@ -992,29 +994,41 @@ int syrk_bc(int dtype, int64_t n, int64_t row_begin, void *Cloc, int64_t ldc, in
         fm.np = (int)np;
         fm.stamps = nullptr; fm.ablate = 0;
         fm.abort_flag = abort_flag; fm.sflag = bt ? 1 : 0;
-        fm.exact = 0;
+        fm.exact = 0; fm.ecs = 0;
+        bool bn64 = false;
         {
             // single rank, triangle aligned to the 128 x 128 tiles: enumerate exactly the tiles that exist
             const int64_t exact_env = env_i64("GPX_GEMM_EXACT", 1);
             const int64_t off = row_begin - G0;                       // row origin minus column origin (global)
             if (exact_env && fast_bm() == 128 && off % 128 == 0 && cdiv(M, 1024) <= 64 && cl0 % nb == 0) {
-                const int TR = (int)cdiv(M, 128), TC = (int)cdiv(Ncols, 128), D = (int)(off / 128);
+                // Short updates take 128 x 64 tiles: twice the tiles at little more than half the time each, so the
+                // last, partly filled round of workgroups costs half as much and the 2 - 5 rounds of an n <= 8192 step
+                // lose less to it (full products of these shapes, K = 256: 7680 x 3840 46 -> 55 TF/s, 5632 x 2816
+                // 35 -> 47, 2048 x 1024 14 -> 24; tools/bn64_probe.py).  Decided on the 128 x 128 tile count of the launch
+                // (all matrices of a lock-step batch together): potrf n = 8192 6.22 -> 5.73 ms, 4096 2.08 -> 1.97, 12288
+                // 14.32 -> 13.83, 16384 28.37 -> 27.79; thresholds 1024 / 2100 / 2600 / 3400 / 5000 at n = 12288: 13.9x /
+                // 13.86 / 13.83 / 13.96 / 14.08; fp32 n = 8192 4.60 -> 4.47, N = 32768 94.45 -> 93.89 with 4000.
+                const int64_t t128 = (int64_t)cdiv(M, 128) * (cdiv(M, 128) + 1) / 2 * (bt ? bt->count : 1);
+                bn64 = t128 <= env_i64("GPX_SYRK_BN64_TILES", dtype == GPX_F64 ? 2600 : 4000) && nb % 64 == 0;
+                const int cs = bn64 ? 1 : 0, cw = 128 >> cs;
+                const int TR = (int)cdiv(M, 128), TC = (int)cdiv(Ncols, cw), D = (int)(off / 128);
                 const int bands = (int)cdiv(TR, 8);
-                const int tpb = (int)(nb / 128), pm1t = (P - 1) * tpb;
-                fm.etpb = tpb; fm.epm1t = pm1t;
+                const int tpb = (int)(nb / cw), pm1t = (P - 1) * tpb;
+                fm.etpb = tpb; fm.epm1t = pm1t; fm.ecs = cs;
                 int total = 0;
                 for (int b = 0; b < bands; ++b) {
                     fm.epre[b] = total;
                     const int h = std::min(8, TR - 8 * b), dj = 8 * b + D;
                     int jfull = 0;
                     if (dj >= 0) {
-                        const int period = tpb + pm1t, qd = (dj + 1) / period, rem = (dj + 1) - qd * period;
+                        const int djc = (dj + 1) << cs;
+                        const int period = tpb + pm1t, qd = djc / period, rem = djc - qd * period;
                         jfull = std::min(TC, qd * tpb + std::min(rem, tpb));
                     }
                     total += jfull * h;
                     for (int j = jfull; j < TC; ++j) {
                         const int gj = j + (j / tpb) * pm1t;
-                        const int cnt = std::max(0, h - std::max(0, gj - dj));
+                        const int cnt = std::max(0, h - std::max(0, (gj >> cs) - dj));
                         if (cnt == 0) break;
                         total += cnt;
                     }
@@ -1036,6 +1050,13 @@ int syrk_bc(int dtype, int64_t n, int64_t row_begin, void *Cloc, int64_t ldc, in
             }
         }
         route_hit(fm.exact ? RT_SYRK_EXACT : RT_SYRK_PATCH);
+        if (fm.exact && bn64) {
+            if (dtype == GPX_F64)
+                return launch_gemm_nt_fast<double, 64, 1, 128>(M, Ncols, kb, A, ldp, Pb, ldp, C, ldc, -1.0, GPX_LOWER,
+                                                               row_begin, cl0 + (int64_t)rank * nb, st, &fm, work, 0, 0, bt);
+            return launch_gemm_nt_fast<float, 64, 1, 128>(M, Ncols, kb, A, ldp, Pb, ldp, C, ldc, -1.0, GPX_LOWER,
+                                                          row_begin, cl0 + (int64_t)rank * nb, st, &fm, work, 0, 0, bt);
+        }
         if (fast_bm() == 128) {
             if (dtype == GPX_F64)
                 return launch_gemm_nt_fast<double, 128, 1, 128>(M, Ncols, kb, A, ldp, Pb, ldp, C, ldc, -1.0, GPX_LOWER,
