@@ -1008,7 +1008,8 @@ int syrk_bc(int dtype, int64_t n, int64_t row_begin, void *Cloc, int64_t ldc, in
                 // (all matrices of a lock-step batch together): potrf n = 8192 6.22 -> 5.73 ms, 4096 2.08 -> 1.97, 12288
                 // 14.32 -> 13.83, 16384 28.37 -> 27.79; thresholds 1024 / 2100 / 2600 / 3400 / 5000 at n = 12288: 13.9x /
                 // 13.86 / 13.83 / 13.96 / 14.08; fp32 n = 8192 4.60 -> 4.47, N = 32768 94.45 -> 93.89 with 4000.
-                const int64_t t128 = (int64_t)cdiv(M, 128) * (cdiv(M, 128) + 1) / 2 * (bt ? bt->count : 1);
+                const int64_t t128 = std::min<int64_t>((int64_t)cdiv(M, 128) * (cdiv(M, 128) + 1) / 2, (int64_t)cdiv(M, 128) * cdiv(Ncols, 128)) *
+                                     (bt ? bt->count : 1);
                 bn64 = t128 <= env_i64("GPX_SYRK_BN64_TILES", dtype == GPX_F64 ? 2600 : 4000) && nb % 64 == 0;
                 const int cs = bn64 ? 1 : 0, cw = 128 >> cs;
                 const int TR = (int)cdiv(M, 128), TC = (int)cdiv(Ncols, cw), D = (int)(off / 128);
