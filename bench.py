@@ -388,7 +388,7 @@ def measure_single(args, lib, _lib, N, d, m, dtid, npdt, steps, warmup, local_ra
     prof = {}
     if prof_on:
         names = ["kmat", "gemm_trailing", "potrf_diag", "trsm_rows", "trsv", "mean", "reduce",
-                 "gemm_panel_bn64", "gemm_generic", "gemm_panel_bn128"]
+                 "gemm_panel_bn64", "gemm_generic", "gemm_panel_bn128", "gemm_trailing_bn64"]
         for cls, nm in enumerate(names):
             a, b, c = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
             _lib.check(lib.gpx_prof_read(cls, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))

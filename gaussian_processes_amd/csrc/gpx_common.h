@@ -67,7 +67,8 @@ static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // ---- live per-kernel-class timing (HIP events around each launch; off by default) ----
 enum ProfClass { PC_KMAT = 0, PC_GEMM = 1, PC_POTRF_DIAG = 2, PC_TRSM_ROWS = 3, PC_TRSV = 4,
-                 PC_MEAN = 5, PC_REDUCE = 6, PC_GEMM_SKINNY = 7, PC_GEMM_GENERIC = 8, PC_GEMM_PANEL = 9, PC_COUNT = 10 };
+                 PC_MEAN = 5, PC_REDUCE = 6, PC_GEMM_SKINNY = 7, PC_GEMM_GENERIC = 8, PC_GEMM_PANEL = 9, PC_GEMM_N64 = 10,
+                 PC_COUNT = 11 };
 extern bool g_prof_on;
 // the registry is shared by all host threads (mutex inside); a scope ends its OWN record
 int  prof_begin(int cls, double work, hipStream_t st);    // record index, -1 when nothing was recorded

@@ -875,7 +875,7 @@ static int launch_gemm_nt_fast(int64_t M, int64_t N, int64_t K, const void *A, i
     if (dblocks) fm.dbegin = (int)ablocks;
     int64_t blocks = ablocks + dblocks;
     if (BM == 128 && fm.exact) blocks = cdiv(fm.eT, (int64_t)8 << fm.ecl) * ((int64_t)8 << fm.ecl);
-    ProfScope prof(TAG == 1 ? PC_GEMM : (BN == 128 ? PC_GEMM_PANEL : PC_GEMM_SKINNY),
+    ProfScope prof(TAG == 1 ? (BN == 64 ? PC_GEMM_N64 : PC_GEMM) : (BN == 128 ? PC_GEMM_PANEL : PC_GEMM_SKINNY),
                    (work >= 0 ? work : 2.0 * (double)K * updated_elements(M, N, tri, row0, col0)) * nbatch * nbatch2, st);
     hipLaunchKernelGGL((gemm_nt_fast_kernel<T, BN, TAG, BM>), dim3((unsigned)blocks, (unsigned)nbatch, (unsigned)nbatch2), dim3(BM * 2), F_SMEM, st, M, N, K,
                        (const T *)A, lda, (const T *)B, ldb, (T *)C, ldc, (T)alpha, tri, row0, col0, fm, beta0);

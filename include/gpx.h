@@ -144,7 +144,7 @@ int gpx_stream_wait_event(void *stream, void *event);
  * (flops for GPX_PROF_GEMM, bytes for the others).  bench.py derives
  * roofline.achieved from these. */
 #define GPX_PROF_KMAT       0   /* bytes written                                  */
-#define GPX_PROF_GEMM       1   /* gemm_nt_fast_kernel<T,128,1>: trailing updates (gpx_d_syrk_bc); flops: 2*K per updated element */
+#define GPX_PROF_GEMM       1   /* gemm_nt_fast_kernel<T,128,1>: trailing updates (gpx_d_syrk_bc) on 128 x 128 tiles; flops: 2*K per updated element */
 #define GPX_PROF_POTRF_DIAG 2   /* flops jb^3/3                                   */
 #define GPX_PROF_TRSM_ROWS  3   /* flops rows*jb^2                                */
 #define GPX_PROF_TRSV       4   /* bytes of L read                                */
@@ -153,6 +153,7 @@ int gpx_stream_wait_event(void *stream, void *event);
 #define GPX_PROF_GEMM_SKINNY  7 /* gemm_nt_fast_kernel<T,64> (panel products); flops */
 #define GPX_PROF_GEMM_GENERIC 8 /* gemm_nt_kernel<T> (unaligned / K-tail shapes); flops */
 #define GPX_PROF_GEMM_PANEL   9 /* gemm_nt_fast_kernel<T,128,0>: panel / covariance products; flops */
+#define GPX_PROF_GEMM_N64    10 /* gemm_nt_fast_kernel<T,64,1>: trailing updates of few tiles on 128 x 64 tiles; flops */
 int gpx_prof_enable(int on);    /* also clears the registry */
 int gpx_prof_read(int cls, double *launches, double *total_ms, double *total_work);
 

@@ -52,15 +52,37 @@ if key:
     # algorithmic bytes of one fit's trailing updates: every element of the lower triangle to the right of a panel is
     # read and written once per panel (8 B each way is counted once: WRITE_SIZE sees the atomic add's write), and the
     # panel itself is read once; divided by the launches of that kernel per fit
-    c_tot = sum(8.0 * (N - (k0 + w)) * ((N - (k0 + w)) + 1) / 2 for k0, w in schedule(N))
-    p_tot = sum(8.0 * (N - (k0 + w)) * w for k0, w in schedule(N))
-    c_bytes, p_bytes = c_tot / per_fit, p_tot / per_fit
+    # Which launches are this kernel's: every outer step updates the next block column first (rows x w1) and then the rest
+    # of the lower triangle; a launch of at most 2600 tiles of 128 x 128 goes to the 128 x 64 kernel instead
+    # (csrc/gpx_gemm.hip, GPX_SYRK_BN64_TILES) and is not counted here.
+    BN64_TILES = 2600
+    sched = schedule(N)
+    c_tot = p_tot = 0.0
+    modelled = 0
+    for i, (k0, w) in enumerate(sched):
+        r = k0 + w
+        if r >= N:
+            break
+        w1 = sched[i + 1][1]
+        rows = N - r
+        launches = [(rows, w1, 8.0 * (rows * w1 - w1 * (w1 - 1) / 2.0))]              # next block column (its triangle's upper part is not touched)
+        rest = rows - w1
+        if rest > 0:
+            launches.append((rest, rest, 8.0 * rest * (rest + 1) / 2.0))
+        for m_, n_, cb in launches:
+            tr, tc = -(-rows // 128), -(-n_ // 128)                                     # (both launches start at row r: syrk_bc's M)
+            if min(tr * (tr + 1) // 2, tr * tc) <= BN64_TILES:
+                continue
+            c_tot += cb
+            p_tot += 8.0 * m_ * w                                                       # the panel rows this launch reads once
+            modelled += 1
+    c_bytes, p_bytes = c_tot / max(1, modelled), p_tot / max(1, modelled)
     src = open(os.path.join(root, "gaussian_processes_amd", "csrc", "gpx_gemm.hip"), "rb").read()
     json.dump({
         "command": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE> --output-format csv -- python3 bench.py --steps 1 "
                    "--warmup 1 --no-cpu-baseline --no-secondary --no-prof  (two separate passes)",
         "workload": "N=65536 d=32 f64, 1 GPU", "kernel": "gpx::gemm_nt_fast_kernel<double, 128, 1, 128>",
-        "dispatches_profiled": n, "launches_per_step": per_fit,
+        "dispatches_profiled": n, "launches_per_step": per_fit, "launches_per_step_modelled": modelled,
         "fetch_bytes_per_launch_corrected": fetch, "write_bytes_per_launch": write,
         "traffic_bytes_per_launch": fetch + write,
         "correction": "FETCH_SIZE doubled (gfx950 wide-read correction, MI355X_MICROARCH.md HBM section); WRITE_SIZE as read; unit KB",
