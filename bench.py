@@ -45,7 +45,8 @@ def parse_args():
     ap.add_argument("--problem-m", dest="m", type=int, default=1000)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--cpu-sample-n", type=int, default=12288)    # 15-20 s of host work on the GPU box
-    ap.add_argument("--cpu-sample-n2", type=int, default=18432)   # second sample (~45 s): the N^3 exponent is fitted
+    ap.add_argument("--cpu-sample-n2", type=int, default=18432)   # second sample (~30 s)
+    ap.add_argument("--cpu-sample-n3", type=int, default=24576)   # third sample (~60 s): the one `value` is scaled from
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip per-launch HIP-event profiling")
     ap.add_argument("--no-secondary", action="store_true",
@@ -102,37 +103,52 @@ def _cpu_sample(orc, ns, d, m):
     return t, float(llh)
 
 
-def cpu_baseline(N, d, m, sample_n, sample_n2=0):
-    """Oracle stage sequence (the reference's own: C kernel loop, scipy cholesky / cho_solve, numpy slogdet LU, dot)
-    on the host cores, on bounded samples; scaled stage by stage to N.  With two samples the exponent of the
-    O(N^3) stages is FITTED from them (log t2/t1 / log n2/n1) instead of assumed."""
-    from oracle import gp_oracle as orc
+def _blas_info():
+    """Which BLAS / LAPACK the reference's scipy / numpy calls run on here, and with how many threads."""
+    info = []
     try:
         from threadpoolctl import threadpool_info
-        blas_threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-    except Exception:
-        blas_threads = os.cpu_count()
-    ns = min(sample_n, N)
+        for pool in threadpool_info():
+            info.append({k: pool.get(k) for k in ("user_api", "internal_api", "version", "threading_layer", "architecture",
+                                                  "num_threads")})
+    except Exception:                  # noqa: BLE001 -- informational only
+        pass
+    return info
+
+
+def cpu_baseline(N, d, m, sample_ns):
+    """Oracle stage sequence (the reference's own: C kernel loop, scipy cholesky / cho_solve, numpy slogdet LU, dot)
+    on the host cores, on bounded samples (`sample_ns`, increasing), scaled stage by stage to N.
+
+    ONE number: `value` scales the LARGEST sample with the stages' nominal exponents (N^2, N^3, N^2, N^3, N), i.e. it
+    assumes the host keeps the per-stage rate it showed at that sample.  The rate is still rising there (64 BLAS
+    threads are not saturated by a 24576^3 / 3 factorisation), so `value` is an upper estimate; `spread.low` is the
+    same scaling with the exponents FITTED from the two largest samples (a lower estimate: it extrapolates the rise).
+    Achieved GFLOP/s per O(N^3) stage and sample, and the BLAS build, are reported beside it."""
+    from oracle import gp_oracle as orc
+    blas = _blas_info()
+    blas_threads = max([p.get("num_threads") or 1 for p in blas] or [os.cpu_count() or 1])
+    ns_list = sorted(set(min(int(v), N) for v in sample_ns if v))
     _cpu_sample(orc, min(768, N), d, 8)                     # untimed: library loading / thread-pool start-up
-    t, llh = _cpu_sample(orc, ns, d, m)
+    samples, llh = [], None
+    for ns in ns_list:
+        t, llh_s = _cpu_sample(orc, ns, d, m)
+        if llh is None:
+            llh = llh_s
+        samples.append((ns, t))
     powers = {"kmat": 2.0, "potrf": 3.0, "solve": 2.0, "slogdet_lu": 3.0, "mean": 1.0}
-    fitted = None
-    t2 = None
-    ns2 = min(sample_n2, N) if sample_n2 else 0
-    if ns2 > ns:
-        t2, _ = _cpu_sample(orc, ns2, d, m)
-        fitted = {k: float(np.log(max(t2[k], 1e-9) / max(t[k], 1e-9)) / np.log(ns2 / float(ns))) for k in ("potrf", "slogdet_lu", "kmat")}
-    base_n, base_t = (ns2, t2) if t2 is not None else (ns, t)
+    flops = {"potrf": lambda n: n ** 3 / 3.0, "slogdet_lu": lambda n: 2.0 * n ** 3 / 3.0}
+    base_n, base_t = samples[-1]
     r = N / float(base_n)
-    scaled = {k: base_t[k] * r ** powers[k] for k in powers}                 # nominal exponents from the larger sample
-    faithful = sum(scaled.values())
-    fair = faithful - scaled["slogdet_lu"]
-    # with the FITTED exponents instead (the host BLAS is still gaining parallel efficiency at these sizes, so its
-    # measured exponent is below 3): a lower estimate; the truth lies between the two
-    fitted_total = None
-    if fitted is not None:
+    scaled = {k: base_t[k] * r ** powers[k] for k in powers}
+    value = sum(scaled.values())
+    fair = value - scaled["slogdet_lu"]
+    fitted, low = None, None
+    if len(samples) >= 2:
+        (n1, t1), (n2, t2) = samples[-2], samples[-1]
+        fitted = {k: float(np.log(max(t2[k], 1e-9) / max(t1[k], 1e-9)) / np.log(n2 / float(n1))) for k in ("potrf", "slogdet_lu", "kmat")}
         fp = dict(powers); fp.update({k: max(1.0, min(3.0, v)) for k, v in fitted.items()})
-        fitted_total = sum(base_t[k] * r ** fp[k] for k in powers)
+        low = sum(base_t[k] * r ** fp[k] for k in powers)
     cpu_model = None
     try:
         with open("/proc/cpuinfo") as f:
@@ -143,13 +159,19 @@ def cpu_baseline(N, d, m, sample_n, sample_n2=0):
     except OSError:
         pass
     out = {
-        "value": round(faithful, 3), "unit": "s", "cores": int(blas_threads), "kind": "port",
-        "os_cpu_count": os.cpu_count(), "cpu_model": cpu_model,
-        "value_with_fitted_exponents": None if fitted_total is None else round(fitted_total, 3),
-        "sample_seconds": round(sum(t.values()) + (sum(t2.values()) if t2 else 0.0), 3),
+        "value": round(value, 3), "unit": "s", "cores": int(blas_threads), "kind": "port",
+        "spread": {"low": None if low is None else round(low, 3), "high": round(value, 3),
+                   "meaning": "high = nominal exponents from the largest sample (rate held); low = exponents fitted from the "
+                              "two largest samples (rate keeps rising)"},
+        "os_cpu_count": os.cpu_count(), "cpu_model": cpu_model, "blas": blas,
+        "sample_seconds": round(sum(sum(t.values()) for _, t in samples), 3),
         "fair_value": round(fair, 3),
         "log_lh_sample": llh,
+        "samples": [{"N": ns, "seconds": {k: round(v, 3) for k, v in t.items()},
+                     "gflops": {k: round(f(ns) / max(t[k], 1e-9) / 1e9, 1) for k, f in flops.items()}} for ns, t in samples],
     }
+    if fitted is not None:
+        out["fitted_exponents"] = {k: round(v, 3) for k, v in fitted.items()}
     # what stands between this host and running the workload itself: memory (K, L and the LU's copy as float64, plus
     # LAPACK work space: ~3.2 N^2 x 8 bytes) and time (the extrapolation itself) -- measured, not asserted
     need_gib = 3.2 * N * N * 8 / 2.0 ** 30
@@ -157,28 +179,25 @@ def cpu_baseline(N, d, m, sample_n, sample_n2=0):
         host_gib = os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE") / 2.0 ** 30
     except (ValueError, OSError, AttributeError):
         host_gib = None
-    limits = "needs ~%.0f GiB of host memory (this host: %s) and ~%.0f s" % (
-        need_gib, ("%.0f GiB" % host_gib) if host_gib else "unknown", faithful)
     out["full_size_run"] = {"host_mem_gib": None if host_gib is None else round(host_gib, 1),
-                            "needed_mem_gib": round(need_gib, 1), "estimated_seconds": round(faithful, 1),
+                            "needed_mem_gib": round(need_gib, 1), "estimated_seconds": round(value, 1),
                             "binding_limit": ("memory" if (host_gib is not None and host_gib < need_gib) else "time")}
-    desc = ("oracle stage sequence (C kernel loop 1 thread; scipy cholesky/cho_solve, numpy slogdet LU on %d BLAS "
-            "threads) measured at N=%d d=%d m=%d: %s" % (blas_threads, ns, d, m, ", ".join("%s %.2fs" % kv for kv in t.items())))
-    if t2 is not None:
-        desc += "; and at N=%d: %s; fitted exponents %s" % (
-            ns2, ", ".join("%s %.2fs" % kv for kv in t2.items()), ", ".join("%s %.2f" % kv for kv in fitted.items()))
-        out["fitted_exponents"] = {k: round(v, 3) for k, v in fitted.items()}
-        out["samples"] = [{"N": ns, "seconds": {k: round(v, 3) for k, v in t.items()}},
-                          {"N": ns2, "seconds": {k: round(v, 3) for k, v in t2.items()}}]
-    desc += ("; scaled per stage (N^2, N^3, N^2, N^3, N) from N=%d to N=%d -- EXTRAPOLATED: the full-size run %s; "
-             "without the reference's redundant LU (logdet from diag L): %.1f s" % (base_n, N, limits, fair))
-    out["sample"] = desc
+    api = next((p for p in blas if p.get("user_api") == "blas"), {})
+    out["sample"] = (
+        "oracle stage sequence (C kernel loop 1 thread; scipy cholesky / cho_solve, numpy slogdet LU on %d threads of %s %s) at d=%d "
+        "m=%d: %s; value = the N=%d sample scaled per stage (N^2, N^3, N^2, N^3, N) to N=%d -- EXTRAPOLATED (the full-size run "
+        "needs ~%.0f GiB and ~%.0f s); potrf ran at %s GFLOP/s, the LU at %s; without the reference's redundant LU: %.1f s"
+        % (blas_threads, api.get("internal_api", "BLAS"), api.get("version", "?"), d, m,
+           "; ".join("N=%d: %s" % (ns, ", ".join("%s %.2fs" % kv for kv in t.items())) for ns, t in samples),
+           base_n, N, need_gib, value,
+           " / ".join("%.0f" % smp["gflops"]["potrf"] for smp in out["samples"]),
+           " / ".join("%.0f" % smp["gflops"]["slogdet_lu"] for smp in out["samples"]), fair))
     return out
 
 
-def self_launch(nproc):
+def _launch_once(nproc, extra_env):
     """Start `nproc` ranks of this script under torch.distributed.run (one per GPU, rendezvous on
-    127.0.0.1), relay rank 0's JSON line, return the launcher's exit code."""
+    127.0.0.1); returns (the launcher's exit code, rank 0's JSON line or None)."""
     import socket
     import subprocess
     sock = socket.socket()
@@ -186,6 +205,7 @@ def self_launch(nproc):
     port = sock.getsockname()[1]
     sock.close()
     env = dict(os.environ)
+    env.update(extra_env)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this driver (RCCL needs it)
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // nproc)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
@@ -199,6 +219,29 @@ def self_launch(nproc):
         elif out:
             sys.stderr.write(out + "\n")                   # anything else a rank printed: keep stdout to one line
     rc = proc.wait()
+    return rc, line
+
+
+def self_launch(nproc):
+    """`python bench.py --gpus P` from a plain shell: launch the ranks; when they end because a rank's watchdog fired
+    (multi_gpu.Watchdog: communicator set-up or the first collective hung) start ONE more set of fresh child
+    processes with the host-callback data plane (GPX_DIST_BACKEND=gloo: same C schedule, collectives staged through
+    the host), so that the run still yields a labelled line.  This launcher process never touches the GPU; a process
+    that did is never re-executed."""
+    rc, line = _launch_once(nproc, {})
+    if line is None and rc != 0 and os.environ.get("GPX_DIST_BACKEND", "nccl") != "gloo" and \
+            not os.environ.get("GPX_BENCH_NO_RETRY"):
+        sys.stderr.write("bench.py: the RCCL run ended with status %d and no result line; retrying ONCE in fresh "
+                         "processes over the host-callback data plane\n" % rc)
+        rc, line = _launch_once(nproc, {"GPX_DIST_BACKEND": "gloo"})
+        if line is not None:
+            try:
+                obj = json.loads(line)
+                obj["data_plane_fallback"] = ("first attempt over RCCL ended without a result (launcher status "
+                                              "non-zero, see stderr); this line: host callbacks over gloo")
+                line = json.dumps(obj)
+            except ValueError:
+                pass
     if line is not None:
         print(line)
         sys.stdout.flush()
@@ -262,7 +305,7 @@ def main():
     if not args.no_secondary and (N, d) != (8192, 8):
         result["secondary"] = secondary_measurements(args, lib, _lib, local_rank, result)
     if not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(N, d, m, args.cpu_sample_n, args.cpu_sample_n2)
+        result["cpu_baseline"] = cpu_baseline(N, d, m, (args.cpu_sample_n, args.cpu_sample_n2, args.cpu_sample_n3))
     print(json.dumps(result))
 
 
@@ -286,6 +329,7 @@ def secondary_measurements(args, lib, _lib, local_rank, headline):
                 "potrf_frac_of_peak": sec["potrf_frac_of_peak"], "roofline": prof["roofline"],
                 "value_with_event_profiling": prof["value"], "log_lh": sec["log_lh"], "check": sec["check"]})
     out.append(measure_mlii(_lib))
+    out.append(measure_periodic_build(lib, _lib))
     if headline["config"]["N"] >= 4096:
         out.append(measure_api(headline))
     return out
@@ -317,6 +361,39 @@ def measure_mlii(_lib, N=8192, d=8):
                                          "finite_rows": int(np.isfinite(llh).sum()),
                                          "minus_inf_rows_logdet_below_MIN": int(np.isneginf(llh).sum())}
     res["value"] = res["restarts_64"]["value"]
+    return res
+
+
+def measure_periodic_build(lib, _lib, N=8192):
+    """The periodic kernel-matrix build (gp/ext/periodic_c.pyx:18-30: one sin and one exp per entry, no clamp) at
+    N = 8192, fp64: full square and lower tiles only, d = 1 (the reference's case) and d = 8; HIP events around 10
+    launches each.  GB/s by SURVEY 8(d)'s accounting: N^2 * 8 bytes written per build (the lower-only build writes
+    the tiles that touch the lower triangle and is still divided by N^2 * 8, as 8(d) says)."""
+    from gaussian_processes_amd.device import DeviceBuffer, Event, sync
+    res = {"name": "periodic_build", "unit": "ms",
+           "config": "PeriodicKernel(1.1, 0.8, 2.3) K(x, x) + s^2 I at N=%d fp64 (gpx_d_kmat, kmat_kernel MODE periodic)" % N}
+    prm = np.array([1.1, 0.8, 2.3])
+    ld = N
+    out = DeviceBuffer((N, ld), np.float64)
+    for d in (1, 8):
+        X, _, _ = synth(N, d, 4, np.float64)
+        dX = DeviceBuffer.from_host(X)
+        for tri_name, tri in (("full", _lib.FULL), ("lower", _lib.LOWER)):
+            def build():
+                _lib.check(lib.gpx_d_kmat(_lib.F64, _lib.KERNEL_PERIODIC, _lib.K, dX.ptr, N, dX.ptr, N, d, _lib.dptr(prm), 0.25,
+                                          tri, out.ptr, ld, None))
+            build(); sync()
+            e0, e1 = Event(), Event()
+            reps = 10
+            e0.record()
+            for _ in range(reps):
+                build()
+            e1.record(); e1.sync()
+            ms = e0.elapsed_ms(e1) / reps
+            res["d%d_%s" % (d, tri_name)] = {"ms": round(ms, 4), "GBps_N2T": round(N * N * 8 / (ms * 1e-3) / 1e9, 1)}
+        dX.free()
+    out.free()
+    res["value"] = res["d1_lower"]["ms"]
     return res
 
 
@@ -419,6 +496,15 @@ def measure_single(args, lib, _lib, N, d, m, dtid, npdt, steps, warmup, local_ra
                     "launches_per_step": g["launches"] / steps,
                     "avg_launch_ms": round(g["ms"] / g["launches"], 4),
                     "flops_per_step": g["work"] / steps}
+        # the same fraction over ALL trailing-update launches of the factorisation -- the 128 x 128 class above plus the
+        # short updates on 128 x 64 tiles (gemm_trailing_bn64) -- so that rounds which move launches between the two
+        # classes stay comparable
+        g64 = prof.get("gemm_trailing_bn64", {"launches": 0.0, "ms": 0.0, "work": 0.0})
+        all_ms, all_work = g["ms"] + g64["ms"], g["work"] + g64["work"]
+        roofline["all_trailing"] = {"achieved": round(all_work / (all_ms * 1e-3) / 1e12, 3),
+                                    "frac": round(all_work / (all_ms * 1e-3) / 1e12 / peak, 4),
+                                    "launches_per_step": (g["launches"] + g64["launches"]) / steps,
+                                    "ms_per_step": round(all_ms / steps, 3), "flops_per_step": all_work / steps}
         # HBM-side bytes per launch of that kernel: PMC counters cannot be read from inside this process, so
         # the figure is the committed rocprofv3 --pmc measurement of THIS command and workload (two separate
         # passes, FETCH_SIZE with the gfx950 x2 correction + WRITE_SIZE; tools/profile_round.sh).  It is only

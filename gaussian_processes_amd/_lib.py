@@ -124,6 +124,7 @@ _SIGNATURES = {
     "gpx_debug_route_count": (c_int, [c_int, POINTER(c_int64)]),
     "gpx_debug_route_reset": (c_int, []),
     "gpx_debug_mg_inject_info": (c_int, [c_void_p, c_int]),
+    "gpx_debug_mg_plan": (c_int, [c_int64, c_int64, c_int, c_int, c_int64, POINTER(c_int64), c_int]),
     "gpx_mg_probe": (c_int, []),
     "gpx_mg_create_local": (c_int, [POINTER(c_void_p), c_int, c_int, c_int64, c_int, c_int64, c_int, c_int]),
     "gpx_mg_connect": (c_int, [c_void_p, c_void_p]),
@@ -157,6 +158,14 @@ _SIGNATURES = {
     "gpx_cholesky": (c_int, [c_double_p, c_double_p, c_int64, c_int_p]),
     "gpx_cho_solve": (c_int, [c_double_p, c_int64, c_double_p]),
     "gpx_gp_c_log_lh": (c_int, [c_double_p, c_double_p, c_double_p, c_int64, c_double_p]),
+    "gpx_gp_c_dloglh_dtheta": (c_int, [c_double_p, c_double_p, c_double_p, c_double_p, c_double, c_int64, c_int,
+                                       c_double_p]),
+    "gpx_gp_c_dlh_dtheta": (c_int, [c_double_p, c_double_p, c_double_p, c_double_p, c_double, c_double, c_int64, c_int,
+                                    c_double_p]),
+    "gpx_gp_c_d2lh_dtheta2": (c_int, [c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double, c_double,
+                                      c_double_p, c_int64, c_int, c_double_p]),
+    "gpx_gp_c_dm_dtheta": (c_int, [c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double, c_int64, c_int,
+                                   c_int64, c_double_p]),
     "gpx_gemm_nt_host": (c_int, [c_double_p, c_double_p, c_double_p, c_int64, c_int64, c_int64]),
 }
 

@@ -133,7 +133,9 @@ int potrf_panel(int dtype, void *A, int64_t lda, int64_t n, int64_t r0, int64_t 
                 int *info_dev, hipStream_t st, const Batch *bt = nullptr, int64_t kpre = 0,   // kpre: see potrf_panel_res
                 hipEvent_t done = nullptr);
 int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t st, const Batch *bt = nullptr,
-          int64_t xrows = 0);      // xrows: extra rows below the matrix that ride along (A has n + xrows rows)
+          int64_t xrows = 0,       // xrows: extra rows below the matrix that ride along (A has n + xrows rows)
+          bool may_block = false); // may_block: the caller allows the host to pace the panel launches (hipEventSynchronize
+                                   // inside the call); false: a pure enqueue (gpx_d_potrf, anything under stream capture)
 // the same panel in ONE launch (gpx_panel.hip): kb a multiple of 64, at most panel_res_max()
 int potrf_panel_res(int dtype, void *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int64_t kb, int *info_dev,
                     hipStream_t st, const Batch *bt = nullptr, int64_t kpre = 0, hipEvent_t done = nullptr);
@@ -142,7 +144,7 @@ int64_t panel_res_max();
 // one): it lives as long as the thread, so an event may be recorded on it at any time
 hipStream_t potrf_side_stream();
 // would K(x, x) + s^2 I hold only finite numbers for finite x?  (gpx_gp.hip; the check_finite of the reference's cho_factor)
-bool kernel_values_finite(int kernel, const double *p, double s);
+bool kernel_values_finite(int kernel, const double *p, double s, int dtype);   // in the handle's arithmetic
 bool panel_res_fold(int64_t rows, int64_t kpre, int64_t kb, size_t es, int64_t lda, const void *base);
 // Per-factor block operators of the single-right-hand-side solves (gpx_solve.hip, "operator form"): owned by
 // whoever owns the factor; `valid` must be cleared whenever the factor changes.  nullptr: built per call.

@@ -468,6 +468,309 @@ static int dm_t(gpx_gp *g, const double *xo, int64_t m, double *out)
     return GPX_OK;
 }
 
+
+// =====================================================================================================================
+// The dense-matrix glue of gp/ext/gp_c.pyx:34-131 for PLUGIN kernels (any Kernel subclass without a native id): the
+// caller holds K^-1, the Jacobian and the Hessian of its own kernel as HOST float64 matrices, exactly the arguments of
+// the reference's four functions.  The reference evaluates them as O(n_p^2) dense n x n x n products; here every
+// matrix crosses PCIe ONCE, every term that is a quadratic form becomes matrix-vector work (O(n^2)), every trace of a
+// product becomes a transposed-tile reduction (O(n^2), no product formed), and only the n_p products N_i = dK_i K^-1
+// that the second-derivative trace terms need run as n^3 GEMMs on the MFMA kernel.  With
+//     z = Ki^T y      w = Ki y       v_i = dK_i Kiy      u_i = Ki v_i      g_i = dK_i^T z      k_i = dK_i^T Kiy
+//     p_i = dK_i w    r_i = Ki p_i   N_i = dK_i Ki       (noise, i = n_p: dK = 2 s I, so each is 2 s times a known vector)
+// nothing assumes Ki or dK_i symmetric, and term by term (names of gp_c.pyx in brackets)
+//     [y . (Ki dK_i) Kiy]          = z . v_i                      [trace(Ki dK_i)]        = sum_ab Ki[a,b] dK_i[b,a]
+//     [t1a = y . dKi_j dK_i Kiy]   = -g_j . u_i                   [t1b = Kiy . d2k Kiy]   = Kiy . (d2K_ij Kiy)
+//     [t1c = Kiy . dK_i dKi_j y]   = -k_i . r_j                   [trace(dKi_j dK_i)]     = -sum_ab N_j[a,b] N_i[b,a]
+//     [trace(Ki d2k)]              = sum_ab Ki[a,b] d2K_ij[b,a]   [dm_i]                  = dKxox_i w - Kxox r_i
+// Only the (n_p + 1) / (n_p + 1)^2 scalars, or the (n_p + 1) x m matrix of dm, return to the host.
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T *__restrict__ src, int64_t lds, T *__restrict__ dst,
+                                                        int64_t ldd, int64_t n)
+{
+    __shared__ T tile[DR_T][DR_T + 1];
+    const int64_t r0 = (int64_t)blockIdx.y * DR_T, c0 = (int64_t)blockIdx.x * DR_T;
+    const int col = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    for (int i = 0; i < 16; ++i) {
+        const int r = rg + 4 * i;
+        tile[r][col] = (r0 + r < n && c0 + col < n) ? src[(r0 + r) * lds + c0 + col] : (T)0;
+    }
+    __syncthreads();
+    for (int i = 0; i < 16; ++i) {
+        const int r = rg + 4 * i;
+        if (c0 + r < n && r0 + col < n) dst[(c0 + r) * ldd + r0 + col] = tile[col][r];
+    }
+}
+
+// partial[chunk][c] = sum over the chunk's rows r of M[r][c] v[r]   (M^T v in two passes, fixed summation order)
+template <typename T>
+__global__ __launch_bounds__(256) void gemv_t_partial_kernel(const T *__restrict__ M, int64_t ld, int64_t rows, int64_t cols,
+                                                             const T *__restrict__ v, double *__restrict__ partial,
+                                                             int64_t rows_per_chunk)
+{
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    const int64_t rb = (int64_t)blockIdx.y * rows_per_chunk, re = rb + rows_per_chunk < rows ? rb + rows_per_chunk : rows;
+    double acc = 0.0;
+    for (int64_t r = rb; r < re; ++r) acc = fma((double)M[r * ld + c], (double)v[r], acc);
+    partial[(int64_t)blockIdx.y * cols + c] = acc;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void gemv_t_sum_kernel(const double *__restrict__ partial, int64_t cols, int nchunks,
+                                                         T *__restrict__ out)
+{
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    double acc = 0.0;
+    for (int k = 0; k < nchunks; ++k) acc += partial[(int64_t)k * cols + c];
+    out[c] = (T)acc;
+}
+
+// fp64 only: the reference's boundary is float64 host arrays (gp_c.pyx signatures)
+struct Glue {
+    int64_t n = 0, ld = 0;
+    hipStream_t st = nullptr;
+    DevBuf part, sc, gpart;
+    std::vector<double> hsc;          // host copy of the dot products, filled by flush()
+    int nsc = 0;
+    static constexpr int SC_MAX = 4096;
+
+    int init(int64_t n_)
+    {
+        n = n_; ld = round_up(n_, 16);
+        GPX_TRY(part.alloc((size_t)DR_BLOCKS * sizeof(double)));
+        GPX_TRY(sc.alloc((size_t)SC_MAX * sizeof(double)));
+        GPX_TRY(gpart.alloc((size_t)64 * ld * sizeof(double)));
+        return GPX_OK;
+    }
+    // host (rows x cols, dense) -> device (rows x ldd)
+    int upload(DevBuf &b, const double *h, int64_t rows, int64_t cols, int64_t ldd)
+    {
+        if (!b.p) GPX_TRY(b.alloc((size_t)rows * ldd * 8));
+        GPX_HIP(hipMemcpy2DAsync(b.p, (size_t)ldd * 8, h, (size_t)cols * 8, (size_t)cols * 8, (size_t)rows, hipMemcpyHostToDevice, st));
+        GPX_HIP(hipStreamSynchronize(st));           // (the host buffer is the caller's: done with it on return)
+        return GPX_OK;
+    }
+    int vec(DevBuf &b, int64_t len) { return b.alloc((size_t)round_up(len, 16) * 8); }
+    // out (rows) = M (rows x cols, ldm) v (cols)
+    int mv(const void *M, int64_t rows, int64_t cols, int64_t ldm, const void *v, void *out)
+    {
+        GPX_HIP(hipMemsetAsync(out, 0, (size_t)rows * 8, st));
+        return gemm_nt(GPX_F64, rows, 1, cols, M, ldm, v, round_up(cols, 16), out, 1, 1.0, GPX_FULL, 0, 0, st);
+    }
+    // out (cols) = M^T v, M rows x cols
+    int mtv(const void *M, int64_t rows, int64_t cols, int64_t ldm, const void *v, void *out)
+    {
+        const int nch = (int)std::min<int64_t>(64, cdiv(rows, 64));
+        const int64_t rpc = cdiv(rows, nch);
+        dim3 grid((unsigned)cdiv(cols, 256), (unsigned)nch);
+        hipLaunchKernelGGL((gemv_t_partial_kernel<double>), grid, dim3(256), 0, st, (const double *)M, ldm, rows, cols,
+                           (const double *)v, (double *)gpart.p, rpc);
+        hipLaunchKernelGGL((gemv_t_sum_kernel<double>), dim3(grid.x), dim3(256), 0, st, (const double *)gpart.p, cols, nch, (double *)out);
+        GPX_LAUNCH_CHECK();
+        return GPX_OK;
+    }
+    int scale(const void *src, void *dst, int64_t len, double f)
+    {
+        hipLaunchKernelGGL((scale_copy_kernel<double>), dim3((unsigned)cdiv(len, 256)), dim3(256), 0, st, (const double *)src,
+                           (double *)dst, len, f);
+        GPX_LAUNCH_CHECK();
+        return GPX_OK;
+    }
+    // queue a . b; returns its slot (value in hsc after flush())
+    int qdot(const void *a, const void *b, int64_t len, int *slot)
+    {
+        if (nsc >= SC_MAX) { set_error("gp_c glue: too many parameters"); return GPX_ERR_ARG; }
+        *slot = nsc++;
+        return dot(GPX_F64, a, b, len, (double *)sc.p + *slot, st);
+    }
+    int flush()
+    {
+        hsc.resize((size_t)std::max(nsc, 1));
+        GPX_HIP(hipMemcpyAsync(hsc.data(), sc.p, (size_t)std::max(nsc, 1) * 8, hipMemcpyDeviceToHost, st));
+        GPX_HIP(hipStreamSynchronize(st));
+        return GPX_OK;
+    }
+    // sum_ab A[a, b] B[b, a] for n x n device matrices (ld)
+    int trace_prod(const void *A, const void *B, double *out)
+    {
+        const int64_t ntl = cdiv(n, DR_T);
+        const int blocks = (int)std::min<int64_t>(DR_BLOCKS, ntl * ntl);
+        hipLaunchKernelGGL((trace_prod_kernel<double>), dim3(blocks), dim3(256), 0, st, (const double *)A, ld, (const double *)B, ld,
+                           n, ntl, (double *)part.p);
+        GPX_LAUNCH_CHECK();
+        int rc = GPX_OK;
+        *out = host_sum(st, (const double *)part.p, blocks, 1, 0, &rc);
+        return rc;
+    }
+    int trace(const void *A, double *out)
+    {
+        hipLaunchKernelGGL((strided_sum_kernel<double>), dim3(1), dim3(1024), 0, st, (const double *)A, n, ld + 1, (double *)part.p);
+        GPX_LAUNCH_CHECK();
+        GPX_HIP(hipMemcpyAsync(out, part.p, 8, hipMemcpyDeviceToHost, st));
+        GPX_HIP(hipStreamSynchronize(st));
+        return GPX_OK;
+    }
+};
+
+// a_i = y . (Ki dK_i) Kiy and tr_i = trace(Ki dK_i), i = 0 .. np (np: the noise) -- gp_c.pyx:42-48 and :60-66
+static int glue_first_order(const double *y, const double *Ki, const double *Kj, const double *Kiy, double s, int64_t n, int np,
+                            double *a, double *tr)
+{
+    Glue G;
+    GPX_TRY(G.init(n));
+    DevBuf dKi, dD, dy, dKiy, dz, dv;
+    GPX_TRY(G.upload(dKi, Ki, n, n, G.ld));
+    GPX_TRY(G.vec(dy, n)); GPX_TRY(G.vec(dKiy, n)); GPX_TRY(G.vec(dz, n)); GPX_TRY(G.vec(dv, n));
+    GPX_HIP(hipMemcpyAsync(dy.p, y, (size_t)n * 8, hipMemcpyHostToDevice, G.st));
+    GPX_HIP(hipMemcpyAsync(dKiy.p, Kiy, (size_t)n * 8, hipMemcpyHostToDevice, G.st));
+    GPX_TRY(G.mtv(dKi.p, n, n, G.ld, dy.p, dz.p));                       // z = Ki^T y
+    std::vector<int> slot(np + 1);
+    for (int i = 0; i < np; ++i) {
+        GPX_TRY(G.upload(dD, Kj + (size_t)i * n * n, n, n, G.ld));
+        GPX_TRY(G.mv(dD.p, n, n, G.ld, dKiy.p, dv.p));                  // v_i = dK_i Kiy
+        GPX_TRY(G.qdot(dz.p, dv.p, n, &slot[i]));
+        GPX_TRY(G.trace_prod(dKi.p, dD.p, &tr[i]));                     // (synchronises: dD may be overwritten next)
+    }
+    GPX_TRY(G.qdot(dz.p, dKiy.p, n, &slot[np]));
+    double trKi = 0.0;
+    GPX_TRY(G.trace(dKi.p, &trKi));
+    GPX_TRY(G.flush());
+    for (int i = 0; i < np; ++i) a[i] = G.hsc[slot[i]];
+    a[np] = 2.0 * s * G.hsc[slot[np]];
+    tr[np] = 2.0 * s * trKi;
+    return GPX_OK;
+}
+
+static int glue_d2lh(const double *y, const double *Ki, const double *Kj, const double *Kh, const double *Kiy, double s, double lh,
+                     const double *dlh, int64_t n, int np, double *d2lh)
+{
+    const int P = np + 1;
+    Glue G;
+    GPX_TRY(G.init(n));
+    const int64_t ld = G.ld, vs = round_up(n, 16);                      // vs: stride between the vectors of a family
+    DevBuf dKi, dKiT, dH, dy, dKiy, dz, dw, dt;
+    std::vector<DevBuf> dD(np), dN(np);
+    DevBuf V, U, Gv, Kv, Pv, Rv;                                          // v_i, u_i, g_i, k_i, p_i, r_i: P vectors each
+    for (DevBuf *b : {&V, &U, &Gv, &Kv, &Pv, &Rv}) GPX_TRY(b->alloc((size_t)P * vs * 8));
+    auto at = [&](DevBuf &b, int i) { return (void *)((double *)b.p + (size_t)i * vs); };
+    GPX_TRY(G.upload(dKi, Ki, n, n, ld));
+    GPX_TRY(dKiT.alloc((size_t)n * ld * 8));
+    {
+        dim3 grid((unsigned)cdiv(n, DR_T), (unsigned)cdiv(n, DR_T));
+        hipLaunchKernelGGL((transpose_kernel<double>), grid, dim3(256), 0, G.st, (const double *)dKi.p, ld, (double *)dKiT.p, ld, n);
+        GPX_LAUNCH_CHECK();
+    }
+    GPX_TRY(G.vec(dy, n)); GPX_TRY(G.vec(dKiy, n)); GPX_TRY(G.vec(dz, n)); GPX_TRY(G.vec(dw, n)); GPX_TRY(G.vec(dt, n));
+    GPX_HIP(hipMemcpyAsync(dy.p, y, (size_t)n * 8, hipMemcpyHostToDevice, G.st));
+    GPX_HIP(hipMemcpyAsync(dKiy.p, Kiy, (size_t)n * 8, hipMemcpyHostToDevice, G.st));
+    GPX_TRY(G.mv(dKiT.p, n, n, ld, dy.p, dz.p));                         // z = Ki^T y
+    GPX_TRY(G.mv(dKi.p, n, n, ld, dy.p, dw.p));                          // w = Ki y
+    for (int i = 0; i < np; ++i) {
+        GPX_TRY(G.upload(dD[i], Kj + (size_t)i * n * n, n, n, ld));
+        GPX_TRY(G.mv(dD[i].p, n, n, ld, dKiy.p, at(V, i)));
+        GPX_TRY(G.mv(dKi.p, n, n, ld, at(V, i), at(U, i)));
+        GPX_TRY(G.mtv(dD[i].p, n, n, ld, dz.p, at(Gv, i)));
+        GPX_TRY(G.mtv(dD[i].p, n, n, ld, dKiy.p, at(Kv, i)));
+        GPX_TRY(G.mv(dD[i].p, n, n, ld, dw.p, at(Pv, i)));
+        GPX_TRY(G.mv(dKi.p, n, n, ld, at(Pv, i), at(Rv, i)));
+        GPX_TRY(dN[i].alloc((size_t)n * ld * 8));
+        GPX_TRY(gemm_nt(GPX_F64, n, n, n, dD[i].p, ld, dKiT.p, ld, dN[i].p, ld, 1.0, GPX_FULL, 0, 0, G.st, 1));   // N_i = dK_i Ki
+    }
+    // the noise: dK = 2 s I
+    GPX_TRY(G.scale(dKiy.p, at(V, np), n, 2.0 * s));
+    GPX_TRY(G.mv(dKi.p, n, n, ld, at(V, np), at(U, np)));
+    GPX_TRY(G.scale(dz.p, at(Gv, np), n, 2.0 * s));
+    GPX_TRY(G.scale(dKiy.p, at(Kv, np), n, 2.0 * s));
+    GPX_TRY(G.scale(dw.p, at(Pv, np), n, 2.0 * s));
+    GPX_TRY(G.mv(dKi.p, n, n, ld, at(Pv, np), at(Rv, np)));
+    // scalars: a_i, t1a_ij, t1c_ij
+    std::vector<int> sa(P), s1a((size_t)P * P), s1c((size_t)P * P), s1b((size_t)P * P, -1);
+    for (int i = 0; i < P; ++i) GPX_TRY(G.qdot(dz.p, at(V, i), n, &sa[i]));
+    for (int i = 0; i < P; ++i)
+        for (int j = 0; j < P; ++j) {
+            GPX_TRY(G.qdot(at(Gv, j), at(U, i), n, &s1a[(size_t)i * P + j]));
+            GPX_TRY(G.qdot(at(Kv, i), at(Rv, j), n, &s1c[(size_t)i * P + j]));
+        }
+    int s_kk = 0;
+    GPX_TRY(G.qdot(dKiy.p, dKiy.p, n, &s_kk));
+    // traces
+    std::vector<double> tr(P), T2((size_t)P * P, 0.0), hh((size_t)P * P, 0.0);
+    double trKi = 0.0, trKiKi = 0.0;
+    GPX_TRY(G.trace(dKi.p, &trKi));
+    for (int i = 0; i < np; ++i) GPX_TRY(G.trace_prod(dKi.p, dD[i].p, &tr[i]));
+    tr[np] = 2.0 * s * trKi;
+    for (int i = 0; i < np; ++i)
+        for (int j = 0; j < np; ++j) {
+            if (j < i) { T2[(size_t)i * P + j] = T2[(size_t)j * P + i]; continue; }     // trace(N_j N_i) = trace(N_i N_j)
+            GPX_TRY(G.trace_prod(dN[j].p, dN[i].p, &T2[(size_t)i * P + j]));
+        }
+    for (int i = 0; i < np; ++i) {
+        double v = 0.0;
+        GPX_TRY(G.trace_prod(dKi.p, dN[i].p, &v));                        // N_noise = 2 s Ki
+        T2[(size_t)i * P + np] = T2[(size_t)np * P + i] = 2.0 * s * v;
+    }
+    GPX_TRY(G.trace_prod(dKi.p, dKi.p, &trKiKi));
+    T2[(size_t)np * P + np] = 4.0 * s * s * trKiKi;
+    // second kernel derivatives: each (m, m) block of Kh crosses once; t1b and trace(Ki d2K)
+    for (int i = 0; i < np; ++i)
+        for (int j = 0; j < np; ++j) {
+            GPX_TRY(G.upload(dH, Kh + ((size_t)i * np + j) * n * n, n, n, ld));
+            GPX_TRY(G.mv(dH.p, n, n, ld, dKiy.p, dt.p));
+            GPX_TRY(G.qdot(dKiy.p, dt.p, n, &s1b[(size_t)i * P + j]));
+            GPX_TRY(G.trace_prod(dKi.p, dH.p, &hh[(size_t)i * P + j]));   // (synchronises before dH / dt are reused)
+        }
+    hh[(size_t)np * P + np] = 2.0 * trKi;                                  // d2k = 2 I (gp_c.pyx:93-94)
+    GPX_TRY(G.flush());
+    for (int i = 0; i < P; ++i) {
+        const double a_i = G.hsc[sa[i]];                                   // (the noise's factor 2 s is inside v_np already)
+        for (int j = 0; j < P; ++j) {
+            const size_t ij = (size_t)i * P + j;
+            const double t0 = dlh[j] * (a_i - tr[i]);                                       // gp_c.pyx:100
+            const double t1a = -G.hsc[s1a[ij]];
+            const double t1b = (i < np && j < np) ? G.hsc[s1b[ij]] : ((i == np && j == np) ? 2.0 * G.hsc[s_kk] : 0.0);
+            const double t1c = -G.hsc[s1c[ij]];
+            const double t1 = lh * (t1a + t1b + t1c + T2[ij] - hh[ij]);                      // gp_c.pyx:102-105
+            d2lh[ij] = 0.5 * (t0 + t1);
+        }
+    }
+    return GPX_OK;
+}
+
+static int glue_dm(const double *y, const double *Ki, const double *Kj, const double *Kjxo, const double *Kxox, double s, int64_t n,
+                   int np, int64_t m, double *dm)
+{
+    const int P = np + 1;
+    Glue G;
+    GPX_TRY(G.init(n));
+    const int64_t ld = G.ld;
+    DevBuf dKi, dD, dX, dJ, dy, dw, dp, dr, o1, o2;
+    GPX_TRY(G.upload(dKi, Ki, n, n, ld));
+    GPX_TRY(G.upload(dX, Kxox, m, n, ld));
+    GPX_TRY(G.vec(dy, n)); GPX_TRY(G.vec(dw, n)); GPX_TRY(G.vec(dp, n)); GPX_TRY(G.vec(dr, n));
+    GPX_TRY(G.vec(o1, m)); GPX_TRY(G.vec(o2, m));
+    GPX_HIP(hipMemcpyAsync(dy.p, y, (size_t)n * 8, hipMemcpyHostToDevice, G.st));
+    GPX_TRY(G.mv(dKi.p, n, n, ld, dy.p, dw.p));                          // w = Ki y
+    std::vector<double> h1((size_t)m), h2((size_t)m);
+    for (int i = 0; i < P; ++i) {
+        if (i < np) {
+            GPX_TRY(G.upload(dD, Kj + (size_t)i * n * n, n, n, ld));
+            GPX_TRY(G.upload(dJ, Kjxo + (size_t)i * m * n, m, n, ld));
+            GPX_TRY(G.mv(dD.p, n, n, ld, dw.p, dp.p));                   // p = dK_i w
+            GPX_TRY(G.mv(dJ.p, m, n, ld, dw.p, o1.p));                   // dKxox_i w
+        } else {
+            GPX_TRY(G.scale(dw.p, dp.p, n, 2.0 * s));
+        }
+        GPX_TRY(G.mv(dKi.p, n, n, ld, dp.p, dr.p));                      // r = Ki p
+        GPX_TRY(G.mv(dX.p, m, n, ld, dr.p, o2.p));                       // Kxox r
+        if (i < np) GPX_HIP(hipMemcpyAsync(h1.data(), o1.p, (size_t)m * 8, hipMemcpyDeviceToHost, G.st));
+        GPX_HIP(hipMemcpyAsync(h2.data(), o2.p, (size_t)m * 8, hipMemcpyDeviceToHost, G.st));
+        GPX_HIP(hipStreamSynchronize(G.st));
+        for (int64_t k = 0; k < m; ++k) dm[(size_t)i * m + k] = (i < np ? h1[(size_t)k] : 0.0) - h2[(size_t)k];   // gp_c.pyx:130-131
+    }
+    return GPX_OK;
+}
+
 }  // namespace gpx
 
 using namespace gpx;
@@ -505,6 +808,47 @@ int gpx_gp_dm_dtheta(gpx_gp_t *g, const double *xo, int64_t m, double *out)
     GPX_TRY(deriv_supported(g));
     if (g->dtype == GPX_F64) return dm_t<double>(g, xo, m, out);
     return dm_t<float>(g, xo, m, out);
+}
+
+
+/* ---- gp/ext/gp_c.pyx:34-131 with the reference's own arguments (host float64, C order); see the Glue section ---- */
+int gpx_gp_c_dloglh_dtheta(const double *y, const double *Ki, const double *Kj, const double *Kiy, double s, int64_t n, int np,
+                           double *dloglh)
+{
+    GPX_TRY(ensure_device());
+    GPX_ARG(n >= 1 && np >= 0 && y && Ki && Kiy && dloglh && (np == 0 || Kj), "bad arguments");
+    std::vector<double> a(np + 1), tr(np + 1);
+    GPX_TRY(glue_first_order(y, Ki, Kj, Kiy, s, n, np, a.data(), tr.data()));
+    for (int i = 0; i <= np; ++i) dloglh[i] = 0.5 * a[i] + -0.5 * tr[i];                  // gp_c.pyx:47-49
+    return GPX_OK;
+}
+
+int gpx_gp_c_dlh_dtheta(const double *y, const double *Ki, const double *Kj, const double *Kiy, double s, double lh, int64_t n,
+                        int np, double *dlh)
+{
+    GPX_TRY(ensure_device());
+    GPX_ARG(n >= 1 && np >= 0 && y && Ki && Kiy && dlh && (np == 0 || Kj), "bad arguments");
+    std::vector<double> a(np + 1), tr(np + 1);
+    GPX_TRY(glue_first_order(y, Ki, Kj, Kiy, s, n, np, a.data(), tr.data()));
+    for (int i = 0; i <= np; ++i) dlh[i] = 0.5 * lh * (a[i] - tr[i]);                     // gp_c.pyx:65-67
+    return GPX_OK;
+}
+
+int gpx_gp_c_d2lh_dtheta2(const double *y, const double *Ki, const double *Kj, const double *Kh, const double *Kiy, double s,
+                          double lh, const double *dlh, int64_t n, int np, double *d2lh)
+{
+    GPX_TRY(ensure_device());
+    GPX_ARG(n >= 1 && np >= 0 && y && Ki && Kiy && dlh && d2lh && (np == 0 || (Kj && Kh)), "bad arguments");
+    return glue_d2lh(y, Ki, Kj, Kh, Kiy, s, lh, dlh, n, np, d2lh);
+}
+
+int gpx_gp_c_dm_dtheta(const double *y, const double *Ki, const double *Kj, const double *Kjxo, const double *Kxox, double s,
+                       int64_t n, int np, int64_t m, double *dm)
+{
+    GPX_TRY(ensure_device());
+    GPX_ARG(n >= 1 && np >= 0 && m >= 0 && y && Ki && (m == 0 || (Kxox && dm)) && (np == 0 || (Kj && (m == 0 || Kjxo))), "bad arguments");
+    if (m == 0) return GPX_OK;
+    return glue_dm(y, Ki, Kj, Kjxo, Kxox, s, n, np, m, dm);
 }
 
 }  // extern "C"

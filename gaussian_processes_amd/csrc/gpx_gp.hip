@@ -141,17 +141,25 @@ int gp_scan_finite(gpx_gp *g)
 // Would K(x, x) + s^2 I hold only finite numbers for finite x?  The kernel's value at r = 0 and at r = 1 in the
 // host's double arithmetic: a NaN or infinite parameter (the reference's setters let both through:
 // gp/kernels/gaussian.py:62-69 only reject values < EPS, gp/gp.py:192-193 only s < 0) shows up there.
-bool kernel_values_finite(int kernel, const double *p, double s)
+// The kernel's value at r = 0 (plus s^2) and at r = 1, evaluated in the arithmetic the build will use: an fp32 handle
+// whose h^2 exceeds FLT_MAX builds an infinite K although the constants are finite in double.
+template <typename T>
+static bool kernel_values_finite_t(int kernel, const double *p, double s)
 {
-    double k0, k1;
+    T k0, k1;
     if (kernel == GPX_KERNEL_GAUSSIAN) {
-        const double c1 = -0.5 / (p[1] * p[1]), c2 = 0.5 * sqrt(2.0 / M_PI) * p[0] * p[0] / p[1];   // gaussian_c.pyx:27-28
-        k0 = c2; k1 = c2 * exp(c1);
+        const T c1 = (T)(-0.5 / (p[1] * p[1])), c2 = (T)(0.5 * sqrt(2.0 / M_PI) * p[0] * p[0] / p[1]);   // gaussian_c.pyx:27-28
+        k0 = c2; k1 = c2 * (T)exp((double)c1);
     } else {
         const double sn = sin(0.5 / p[2]);                                                            // periodic_c.pyx:27-29
-        k0 = p[0] * p[0]; k1 = p[0] * p[0] * exp(-2.0 * sn * sn / (p[1] * p[1]));
+        k0 = (T)(p[0] * p[0]); k1 = k0 * (T)exp(-2.0 * sn * sn / (p[1] * p[1]));
     }
-    return std::isfinite(k0 + s * s) && std::isfinite(k1);
+    const T diag = k0 + (T)(s * s);
+    return std::isfinite(diag) && std::isfinite(k1);
+}
+bool kernel_values_finite(int kernel, const double *p, double s, int dtype)
+{
+    return dtype == GPX_F32 ? kernel_values_finite_t<float>(kernel, p, s) : kernel_values_finite_t<double>(kernel, p, s);
 }
 
 static const char *NONFINITE_MSG = "array must not contain infs or NaNs";      // scipy's text (gp/gp.py:294, 332-334)
@@ -305,7 +313,7 @@ int gpx_gp_fit(gpx_gp_t *g, int *info)
             "set_data and set_params (or set_K) must be called before fit");
     // scipy.linalg.cholesky(Kxx, check_finite=True), gp/gp.py:294: a kernel matrix with NaN / inf entries is a
     // ValueError, not "not positive definite".  K is finite iff x, the kernel's constants and s^2 are.
-    if (!g->have_K && (!g->x_finite || !kernel_values_finite(g->kernel, g->params, g->s))) {
+    if (!g->have_K && (!g->x_finite || !kernel_values_finite(g->kernel, g->params, g->s, g->dtype))) {
         set_error("%s (%s)", NONFINITE_MSG, g->x_finite ? "kernel parameters or s" : "x");
         return GPX_ERR_ARG;
     }
@@ -357,7 +365,7 @@ int gpx_gp_fit(gpx_gp_t *g, int *info)
         GPX_HIP(hipStreamWaitEvent(g->st_ops, g->ev_ops, 0));
         potrf_set_hook(&hook);
     }
-    const int prc = potrf(g->dtype, g->A, g->n, g->lda, info_dev, st, nullptr, ride ? 1 : 0);
+    const int prc = potrf(g->dtype, g->A, g->n, g->lda, info_dev, st, nullptr, ride ? 1 : 0, /*may_block=*/true);
     potrf_set_hook(nullptr);
     GPX_TRY(prc);
     if (ahead) {
@@ -822,7 +830,7 @@ int gpx_cholesky(double *L, const double *A, int64_t n, int *info)
     GPX_TRY(a.alloc((size_t)n * lda * 8));
     GPX_TRY(inf.alloc(sizeof(int)));
     GPX_HIP(hipMemcpy2D(a.p, (size_t)lda * 8, A, (size_t)n * 8, (size_t)n * 8, (size_t)n, hipMemcpyHostToDevice));
-    GPX_TRY(potrf(GPX_F64, a.p, n, lda, (int *)inf.p, nullptr));
+    GPX_TRY(potrf(GPX_F64, a.p, n, lda, (int *)inf.p, nullptr, nullptr, 0, /*may_block=*/true));
     GPX_TRY(tril(GPX_F64, a.p, n, lda, nullptr));
     GPX_HIP(hipMemcpy(info, inf.p, sizeof(int), hipMemcpyDeviceToHost));
     GPX_TRY(check_internal_info(*info));

@@ -14,6 +14,8 @@
 #include <stdio.h>
 #include <string>
 #include <unistd.h>
+#include <fcntl.h>
+#include <stdlib.h>
 #include <sys/stat.h>
 #include <cmath>
 #include <vector>
@@ -144,11 +146,16 @@ int gpx_gp_save(gpx_gp_t *g, const char *path)
     hd.s = g->s; hd.logdet = h4[0]; hd.yta = h4[1];
     // written under a temporary name and renamed when complete: a failure never leaves a truncated checkpoint
     // under the final name
-    const std::string tmp_path = std::string(path) + ".tmp";
+    // (a UNIQUE temporary in the target's directory -- mkstemp -- so that two saves to the same path, e.g. every rank of
+    //  a multi-rank job checkpointing, never write or unlink each other's file; the last rename wins, each is complete)
+    std::string tmp_path = std::string(path) + ".XXXXXX";
+    const int tfd = mkstemp(&tmp_path[0]);
+    if (tfd < 0) { set_error("gpx_gp_save: cannot create a temporary file beside %s", path); return GPX_ERR_ARG; }
     struct Unlink { const std::string &p; bool armed = true; ~Unlink() { if (armed) (void)unlink(p.c_str()); } } cleanup{tmp_path};
     File fp;
-    fp.f = fopen(tmp_path.c_str(), "wb");
-    if (!fp.f) { set_error("gpx_gp_save: cannot open %s for writing", tmp_path.c_str()); cleanup.armed = false; return GPX_ERR_ARG; }
+    fp.f = fdopen(tfd, "wb");
+    if (!fp.f) { (void)close(tfd); set_error("gpx_gp_save: cannot open %s for writing", tmp_path.c_str()); return GPX_ERR_ARG; }
+    (void)fchmod(tfd, 0644);                                        // mkstemp creates 0600; a checkpoint is an ordinary file
     bool ok = fwrite(&hd, sizeof(hd), 1, fp.f) == 1;
     std::vector<double> v;
     GPX_TRY(vec_d2h_f64(g, g->x, n * g->d, v)); ok = ok && fwrite(v.data(), 8, v.size(), fp.f) == v.size();
@@ -183,9 +190,20 @@ int gpx_gp_save(gpx_gp_t *g, const char *path)
     (void)hipStreamSynchronize(g->st);
     if (rc != GPX_OK) return rc;
     if (!ok || fflush(fp.f) != 0 || fsync(fileno(fp.f)) != 0) { set_error("gpx_gp_save: short write to %s", tmp_path.c_str()); return GPX_ERR_ARG; }
-    fclose(fp.f); fp.f = nullptr;
+    {
+        FILE *f = fp.f; fp.f = nullptr;
+        if (fclose(f) != 0) { set_error("gpx_gp_save: closing %s failed", tmp_path.c_str()); return GPX_ERR_ARG; }
+    }
     if (rename(tmp_path.c_str(), path) != 0) { set_error("gpx_gp_save: cannot rename %s to %s", tmp_path.c_str(), path); return GPX_ERR_ARG; }
     cleanup.armed = false;
+    // the rename itself is only durable once the directory entry is: fsync the directory (best effort)
+    {
+        std::string dir(path);
+        const size_t slash = dir.find_last_of('/');
+        dir = slash == std::string::npos ? std::string(".") : (slash == 0 ? std::string("/") : dir.substr(0, slash));
+        const int dfd = open(dir.c_str(), O_RDONLY | O_DIRECTORY);
+        if (dfd >= 0) { (void)fsync(dfd); (void)close(dfd); }
+    }
     return GPX_OK;
 }
 

@@ -198,6 +198,7 @@ struct gpx_mg {
     double *scal = nullptr;                       // scal: [0] logdet block [1] y^T alpha [2] logdet acc [3] spare
     int *info = nullptr;                          // [0] info [1] reduction key
     hipStream_t S = nullptr, Q = nullptr, B = nullptr;   // main (updates, solves) / panel (factor, pack) / panel broadcasts
+    hipStream_t O = nullptr;                      // lowest priority: the diagonal blocks' solve operators, off the panel chain
     std::vector<hipEvent_t> ev;                   // sync events (no timing), reused round-robin per fit
     size_t ev_next = 0;
     std::vector<hipEvent_t> tev;                  // timing events (pairs)
@@ -303,11 +304,34 @@ static int mg_allreduce(gpx_mg *g, void *dev_ptr, size_t count, int dtype, int o
 // The callback back-end (tests: several ranks on one GPU) emulates the two phases with the broadcast callback: in
 // phase 1 piece i is received into its place only by rank i (the others drop it into a scratch block), in phase 2
 // piece i is re-broadcast by rank i, so a wrong piece map or a missing piece shows in the result.
+// The arithmetic of the two splits a panel broadcast goes through, as pure functions (also behind gpx_debug_mg_plan, so
+// that alignment and coverage can be checked at N = 65536, P = 8 without a GPU-sized run):
+//   pieces of one broadcast (scatter + all-gather): P - 1 pieces of mg_piece() elements, the last one takes the rest
+static size_t mg_piece(size_t count, int P) { return count / (size_t)P / 32 * 32; }   // 32 elements = 128 / 256 bytes
+static bool mg_piece_sag_ok(size_t count, int P) { return P > 2 && mg_piece(count, P) >= 1024; }
+//   row chunks of one panel (each its own broadcast + event): ends[c] = first row AFTER chunk c, relative to the panel's
+//   first row; the first chunk covers at least the next block column's diagonal rows (its B-operand rows)
+static void mg_chunk_plan(int64_t rows, int64_t nb, int nch_req, std::vector<int64_t> *ends)
+{
+    ends->clear();
+    int nch = std::max(1, nch_req);
+    const int64_t min_rows = std::min(rows, std::max<int64_t>(2 * nb, 1024));
+    if (rows < 4 * min_rows) nch = 1;
+    int64_t done = 0;
+    for (int c = 0; c < nch; ++c) {
+        int64_t end = (c + 1 == nch) ? rows : std::max(min_rows, (rows * (c + 1) / nch) / 128 * 128);
+        end = std::min(end, rows);
+        if (end <= done) continue;
+        ends->push_back(end);
+        done = end;
+    }
+}
+
 static int mg_bcast_panel(gpx_mg *g, void *dev_ptr, size_t count, int root, hipStream_t st)
 {
     const int P = g->world, me = g->rank;
-    const size_t piece = count / (size_t)P / 32 * 32;             // 32-element (128- / 256-byte) aligned pieces; the last one takes the rest
-    const bool sag = g->bcast_sag && P > 2 && piece >= 1024 && (g->cb_bcast || g->comm);
+    const size_t piece = mg_piece(count, P);                      // 32-element (128- / 256-byte) aligned pieces; the last one takes the rest
+    const bool sag = g->bcast_sag && mg_piece_sag_ok(count, P) && (g->cb_bcast || g->comm);
     if (!sag) { route_hit(RT_MG_BCAST_ONE); return mg_bcast(g, dev_ptr, count, root, st); }
     route_hit(RT_MG_BCAST_SAG);
     auto off = [&](int i) { return (size_t)i * piece; };
@@ -383,22 +407,20 @@ static int mg_factor_and_bcast(gpx_mg *g, int64_t j, void *buf, hipEvent_t buf_f
         if (buf_free) GPX_HIP(hipStreamWaitEvent(Q, buf_free, 0));
         { MgTimer t(g, T_PACK, Q); GPX_TRY(mg_pack(g, r0, cl, rows, kb, buf, Q)); }
         GPX_TRY(mg_order(g, Q, B));
-        // the inverse of this diagonal block for the backward solve, built here, off everybody's critical path (the
-        // broadcast is already ordered behind the pack; this rank's next panel is `world` steps away)
-        GPX_TRY(trsv_ops_build(g->dtype, g->Aat(r0, cl), kb, g->ld, &g->ops[(size_t)(j / g->world)], Q));
+        // the inverse of this diagonal block for the backward solve: ~11 small launches, on a low-priority stream of
+        // their own ordered after the pack (round 4; they used to sit on Q, where with world <= 2 the owner's next panel
+        // queued right behind them; their buffers come from mg_alloc, nothing is allocated inside this loop)
+        GPX_TRY(mg_order(g, Q, g->O));
+        GPX_TRY(trsv_ops_build(g->dtype, g->Aat(r0, cl), kb, g->ld, &g->ops[(size_t)(j / g->world)], g->O));
     } else if (buf_free) {
         GPX_HIP(hipStreamWaitEvent(B, buf_free, 0));
     }
-    // row chunks: the first one covers at least the next block column's diagonal rows (its B-operand rows)
-    int nch = (chunk_ev && g->world > 1) ? g->bcast_chunks : 1;
-    const int64_t min_rows = std::min(rows, std::max<int64_t>(2 * g->nb, 1024));
-    if (rows < 4 * min_rows) nch = 1;
+    // row chunks (mg_chunk_plan)
+    std::vector<int64_t> ends;
+    mg_chunk_plan(rows, g->nb, (chunk_ev && g->world > 1) ? g->bcast_chunks : 1, &ends);
     MgTimer t(g, T_BCAST, B);
     int64_t done = 0;
-    for (int c = 0; c < nch; ++c) {
-        int64_t end = (c + 1 == nch) ? rows : std::max(min_rows, (rows * (c + 1) / nch) / 128 * 128);
-        end = std::min(end, rows);
-        if (end <= done) continue;
+    for (const int64_t end : ends) {
         GPX_TRY(mg_bcast_panel(g, (char *)buf + (size_t)done * g->nb * g->es, (size_t)(end - done) * g->nb, (int)g->owner(j), B));
         done = end;
         if (chunk_ev) {
@@ -481,6 +503,7 @@ static int mg_factor(gpx_mg *g)
     }
     GPX_TRY(mg_order(g, Q, S));
     GPX_TRY(mg_order(g, g->B, S));
+    GPX_TRY(mg_order(g, g->O, S));                                // the solve reads the operators
     if (g->debug_info != 0) {                                     // test hook: as if a resident panel launch had failed
         GPX_HIP(hipMemcpyAsync(g->info, &g->debug_info, sizeof(int), hipMemcpyHostToDevice, S));
         GPX_HIP(hipStreamSynchronize(S));
@@ -551,6 +574,7 @@ static int mg_reduce(gpx_mg *g)
     GPX_HIP(hipStreamSynchronize(S));
     GPX_HIP(hipStreamSynchronize(g->Q));
     GPX_HIP(hipStreamSynchronize(g->B));
+    GPX_HIP(hipStreamSynchronize(g->O));
     g->logdet = h[2]; g->yta = h[1];
     g->info_host = hi[1] == 0 ? 0 : (hi[1] == INT_MAX ? -7 : (1 << 30) - hi[1]);
     return GPX_OK;
@@ -577,6 +601,16 @@ static int mg_alloc(gpx_mg *g)
     GPX_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
     GPX_HIP(hipStreamCreateWithPriority(&g->Q, hipStreamNonBlocking, greatest));   // the panel chain: critical path
     GPX_HIP(hipStreamCreateWithPriority(&g->B, hipStreamNonBlocking, greatest));   // the panel broadcasts
+    GPX_HIP(hipStreamCreateWithPriority(&g->O, hipStreamNonBlocking, least));      // the solve operators
+    // the operator blocks of every owned diagonal block, here and not on first use inside the factorisation's loop
+    // (~21 MB per 1024-wide fp64 block: 1.3 GB at N = 65536 on one rank -- part of this handle's HBM budget)
+    for (size_t jl = 0; jl < g->my_blocks.size(); ++jl) {
+        const int64_t kb = g->kb(g->my_blocks[jl]);
+        if (kb < 512 || kb % 512 != 0) continue;                  // (the step route: trsv_ops_build declines these)
+        const size_t need = trsv_ops_bytes(g->dtype, kb);
+        GPX_HIP(hipMalloc(&g->ops[jl].buf, need));
+        g->ops[jl].bytes = need;
+    }
     return GPX_OK;
 }
 
@@ -634,6 +668,7 @@ int gpx_mg_destroy(gpx_mg_t *g)
     if (g->S) (void)hipStreamSynchronize(g->S);
     if (g->Q) (void)hipStreamSynchronize(g->Q);
     if (g->B) (void)hipStreamSynchronize(g->B);
+    if (g->O) (void)hipStreamSynchronize(g->O);
     if (g->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(g->comm);
     void *bufs[] = {g->A, g->pbuf[0], g->pbuf[1], g->x, g->y, g->alpha, g->tmp, g->scal, g->info, g->sag_tmp};
     for (void *b : bufs) if (b) (void)hipFree(b);
@@ -643,6 +678,7 @@ int gpx_mg_destroy(gpx_mg_t *g)
     if (g->S) (void)hipStreamDestroy(g->S);
     if (g->Q) (void)hipStreamDestroy(g->Q);
     if (g->B) (void)hipStreamDestroy(g->B);
+    if (g->O) (void)hipStreamDestroy(g->O);
     delete g;
     return GPX_OK;
 }
@@ -717,6 +753,28 @@ int gpx_debug_mg_inject_info(gpx_mg_t *g, int value)
     return GPX_OK;
 }
 
+int gpx_debug_mg_plan(int64_t n, int64_t nb, int world, int chunks, int64_t j, int64_t *out, int cap)
+{
+    // host arithmetic only (no device is touched): the row chunks of panel j and the pieces of each chunk's broadcast
+    GPX_ARG(n >= 1 && nb >= 64 && world >= 1 && chunks >= 1 && j >= 0 && j * nb < n && out && cap >= 0, "bad arguments");
+    const int64_t rows = (n + 1) - j * nb;                        // (the rider row travels with every panel)
+    std::vector<int64_t> ends;
+    mg_chunk_plan(rows, nb, world > 1 ? chunks : 1, &ends);
+    int64_t done = 0;
+    int k = 0;
+    for (const int64_t end : ends) {
+        if ((k + 1) * 6 > cap) { set_error("gpx_debug_mg_plan: out holds %d values, more are needed", cap); return GPX_ERR_ARG; }
+        const size_t count = (size_t)(end - done) * (size_t)nb;
+        const size_t piece = mg_piece(count, world);
+        int64_t *o = out + (size_t)k * 6;
+        o[0] = done; o[1] = end; o[2] = (int64_t)count; o[3] = (int64_t)piece;
+        o[4] = (int64_t)(count - (size_t)(world - 1) * piece);    // the last piece
+        o[5] = mg_piece_sag_ok(count, world) ? 1 : 0;
+        done = end; ++k;
+    }
+    return k;                                                     // >= 0: number of chunks written
+}
+
 int gpx_mg_create_cb(gpx_mg_t **out, int dtype, int kernel, int64_t n, int d, int64_t nb, int world, int rank,
                      gpx_mg_bcast_fn bcast, gpx_mg_allreduce_fn allreduce, void *user)
 {
@@ -761,7 +819,7 @@ int gpx_mg_fit(gpx_mg_t *g, const double *params, double s, double *log_lh, int 
     MG_ENTER(g);
     GPX_ARG(g->have_data && params, "set_data must be called before fit");
     GPX_ARG(!(s < 0), "invalid value for s");
-    if (!kernel_values_finite(g->kernel, params, s)) { set_error("array must not contain infs or NaNs"); return GPX_ERR_ARG; }
+    if (!kernel_values_finite(g->kernel, params, s, g->dtype)) { set_error("array must not contain infs or NaNs"); return GPX_ERR_ARG; }
     g->fitted = false;
     g->ev_next = 0; g->tev_next = 0;
     GPX_HIP(hipMemsetAsync(g->info, 0, 4 * sizeof(int), g->S));

@@ -57,16 +57,28 @@ template <typename T> __device__ __forceinline__ T pub_load(const T *p)
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// all of this workgroup's published stores are on their way: drain them, meet, raise the flag
-__device__ __forceinline__ void res_raise(int *flag, int serial)
+// all of this workgroup's published stores are on their way: drain them, meet, raise the flag.
+// Ordering.  Every published element and every flag is an AGENT-scope atomic access (sc1: write-through stores, loads
+// that do not hit in a non-coherent L2), so the hardware half of a release is exactly the drain below -- on gfx9 stores
+// count in vmcnt, and the count only drops when the write is acknowledged at the coherence point -- followed by the
+// workgroup barrier, and the hardware half of an acquire is "the flag load has returned before the payload loads
+// issue" (the poll loop consumes the value; the barrier follows).  What a formal release / acquire pair adds on
+// gfx942 / gfx950 is buffer_wbl2 sc1 / buffer_inv sc1 -- write back and invalidate this XCD's whole L2 for the sake of
+// NON-atomic data, of which the hand-off has none; the first version of the kernel paid that next to a trailing
+// update with gigabytes of dirty tiles.  `strict` (GPX_RES_STRICT=1) issues the formal pair anyway: the soak test
+// (tests/test_gpu_round4.py) runs both forms and compares them bit for bit.
+__device__ __forceinline__ void res_raise(int *flag, int serial, int strict)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(flag, serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) {
+        if (strict) __hip_atomic_store(flag, serial, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        else __hip_atomic_store(flag, serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // one lane polls; everybody learns the outcome through LDS (the caller's next barrier orders the payload loads)
-__device__ __forceinline__ void res_wait(const int *flag, int serial, int *s_ok, int naps)
+__device__ __forceinline__ void res_wait(const int *flag, int serial, int *s_ok, int naps, int strict)
 {
     if (threadIdx.x == 0) {
         int spins = 0;
@@ -76,6 +88,7 @@ __device__ __forceinline__ void res_wait(const int *flag, int serial, int *s_ok,
             ++spins;
         }
         if (spins >= RES_SPIN) *s_ok = 0;
+        if (strict) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("" ::: "memory");
     }
 }
@@ -203,7 +216,7 @@ template <typename T, bool LEAF_MFMA>
 __global__ __launch_bounds__(256, 2) void panel_res_kernel(T *__restrict__ A, int64_t lda, int64_t n, int64_t r0, int64_t c0,
                                                            int nsteps, int *__restrict__ info, T *__restrict__ pub,
                                                            int *__restrict__ flags, int serial, int64_t sM, int kpre,
-                                                           unsigned long long *__restrict__ stamps, int w0)
+                                                           unsigned long long *__restrict__ stamps, int w0, int strict)
 {
     typedef PM<T> M;
     typedef typename M::v4 v4;
@@ -329,7 +342,7 @@ __global__ __launch_bounds__(256, 2) void panel_res_kernel(T *__restrict__ A, in
                     }
                 }
             }
-            res_raise(flags + j, serial);
+            res_raise(flags + j, serial, strict);
             if (own_a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
@@ -344,7 +357,7 @@ __global__ __launch_bounds__(256, 2) void panel_res_kernel(T *__restrict__ A, in
         }
         }
         // ---- rows below the diagonal block ----
-        res_wait(flags + j, serial, &s_ok, !future_diag);
+        res_wait(flags + j, serial, &s_ok, !future_diag, strict);
         __syncthreads();
         if (w == j + 1) stamp(8);
         if (!s_ok) {
@@ -384,7 +397,7 @@ __global__ __launch_bounds__(256, 2) void panel_res_kernel(T *__restrict__ A, in
             for (int c = 1; c < RES_MAXSTEPS; ++c)
                 if (c == w) res_prod<T, PT, true>(sA, sA, acc[c], wave, li, lq);
             if (w == j + 1) stamp(11);
-            res_raise(flags + res_xslot(w, j), serial);
+            res_raise(flags + res_xslot(w, j), serial, strict);
             if (w == j + 1) stamp(12);
         }
 #pragma unroll
@@ -397,7 +410,7 @@ __global__ __launch_bounds__(256, 2) void panel_res_kernel(T *__restrict__ A, in
 #pragma unroll
         for (int c = j + 1; c < RES_MAXSTEPS; ++c) {
             if (c >= nsteps || (future_diag && c >= w)) break;
-            res_wait(flags + res_xslot(c, j), serial, &s_ok, 1);
+            res_wait(flags + res_xslot(c, j), serial, &s_ok, 1, strict);
             __syncthreads();                                    // also: the previous block's sB has been consumed
             if (!s_ok) {
                 if (tid == 0) atomicCAS(info, 0, -7);
@@ -426,7 +439,7 @@ __global__ __launch_bounds__(256, 2) void panel_res_kernel(T *__restrict__ A, in
                 const int row = 16 * wave + M::row(lane, r), col = 16 * jj + li;
                 if (jj <= wave) pub_store(W + row * IB + col, (col <= row) ? xw[jj][r] : (T)0);   // (tiles above: zero since the clear)
             }
-        res_raise(flags + j, serial);
+        res_raise(flags + j, serial, strict);
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
@@ -527,6 +540,7 @@ static int panel_res_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int
     unsigned long long *stamps = (g_res_stamps && g_res_stamp_at-- == 0) ? g_res_stamps : (unsigned long long *)nullptr;
     const int serial = ++scr->serial;
     const int nsteps = (int)(kb / IB);
+    const int strict = env_i64("GPX_RES_STRICT", 0) != 0 ? 1 : 0;   // formal release / acquire hand-offs (see res_raise)
     // TALL panels go out as TWO launches on the same stream: first the diagonal workgroups alone (the chain of leaves),
     // then all the rows below.  In one launch the row workgroups sit on their CUs for the whole chain -- ~230 us at
     // 32768 rows, of which they compute for ~30 -- and each of them keeps a trailing-update workgroup of the other
@@ -552,19 +566,19 @@ static int panel_res_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int
         const bool mfma_chain = F64 || env_i64("GPX_LEAF_MFMA_F32_ROWS", 16384) > 0;
         if (mfma_chain)
             hipLaunchKernelGGL((panel_res_kernel<T, true>), dim3((unsigned)nsteps, grid.y), dim3(256), 0, st, A, lda, n, r0, c0, nsteps,
-                               info_dev, (T *)pub, flags, serial, bt ? bt->sA : (int64_t)0, (int)(kpre / IB), stamps, 0);
+                               info_dev, (T *)pub, flags, serial, bt ? bt->sA : (int64_t)0, (int)(kpre / IB), stamps, 0, strict);
         else
             hipLaunchKernelGGL((panel_res_kernel<T, F64>), dim3((unsigned)nsteps, grid.y), dim3(256), 0, st, A, lda, n, r0, c0, nsteps,
-                               info_dev, (T *)pub, flags, serial, bt ? bt->sA : (int64_t)0, (int)(kpre / IB), stamps, 0);
+                               info_dev, (T *)pub, flags, serial, bt ? bt->sA : (int64_t)0, (int)(kpre / IB), stamps, 0, strict);
         // (the rows never run a leaf: the lean instantiation)
         hipLaunchKernelGGL((panel_res_kernel<T, F64>), dim3(grid.x - (unsigned)nsteps, grid.y), dim3(256), 0, st, A, lda, n, r0, c0, nsteps,
-                           info_dev, (T *)pub, flags, serial, bt ? bt->sA : (int64_t)0, (int)(kpre / IB), stamps, nsteps);
+                           info_dev, (T *)pub, flags, serial, bt ? bt->sA : (int64_t)0, (int)(kpre / IB), stamps, nsteps, strict);
     } else if (mfma_single) {
         hipLaunchKernelGGL((panel_res_kernel<T, true>), grid, dim3(256), 0, st, A, lda, n, r0, c0, nsteps, info_dev, (T *)pub,
-                           flags, serial, bt ? bt->sA : (int64_t)0, (int)(kpre / IB), stamps, 0);
+                           flags, serial, bt ? bt->sA : (int64_t)0, (int)(kpre / IB), stamps, 0, strict);
     } else {
         hipLaunchKernelGGL((panel_res_kernel<T, F64>), grid, dim3(256), 0, st, A, lda, n, r0, c0, nsteps, info_dev, (T *)pub,
-                           flags, serial, bt ? bt->sA : (int64_t)0, (int)(kpre / IB), stamps, 0);
+                           flags, serial, bt ? bt->sA : (int64_t)0, (int)(kpre / IB), stamps, 0, strict);
     }
     GPX_LAUNCH_CHECK();
     if (record_after) GPX_HIP(hipEventRecord(record_after, st));

@@ -491,7 +491,7 @@ static int reserve_cus_batch(int64_t n, int count)
 // factors panel k + 1 (whose block column was updated first).
 // bt != null: bt->count matrices sA elements apart are factored in lock-step (every launch covers all of
 // them; info_dev then holds one word per matrix).
-int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t st, const Batch *bt, int64_t xrows)
+int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t st, const Batch *bt, int64_t xrows, bool may_block)
 {
     // xrows extra rows below the n x n matrix take part in every panel and update as rows, never as columns: on
     // return row n + i holds L^-1 applied to what was stored there (a right-hand side rides along: gpx_gp_fit)
@@ -549,7 +549,14 @@ int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t
     GPX_TRY(g_la.get(&ep));
     GPX_TRY(potrf_panel(dtype, A, lda, N, 0, 0, kb, info_dev, q, bt, 0, ep));
     hipEvent_t e_rest = nullptr;                                // fires when the trailing update of the step before is done
-    const bool host_paced = !bt && n <= env_i64("GPX_POTRF_HOST_PACED", 16384);
+    // host pacing blocks the calling thread inside the loop: only where the caller said it may (the handle's gpx_gp_fit,
+    // documented in include/gpx.h; gpx_d_potrf stays a pure enqueue) and never while the stream is being captured
+    bool host_paced = may_block && !bt && n <= env_i64("GPX_POTRF_HOST_PACED", 16384);
+    if (host_paced) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(user, &cs) != hipSuccess) (void)hipGetLastError();
+        else if (cs != hipStreamCaptureStatusNone) host_paced = false;
+    }
     while (true) {
         const int64_t r = k0 + kb;
         if (masked && n - r <= reserve_below) GPX_TRY(switch_to(masked));

@@ -1,43 +1,34 @@
 """Drop-in for the reference's Cython module gp/ext/gp_c.pyx.
 
-In the reference this module is glue: every function is a loop of np.dot /
-np.trace / np.linalg.slogdet calls on dense (n, n) matrices (gp_c.pyx:17-131).
-Here the same formulas run with their matrix products on the fp64 matrix cores
-(gpx_gemm_nt_host -> csrc/gpx_gemm.hip); traces and the final scalar
-combinations (O(n) or O(n_params^2) work) stay on the host.
+Same function names and argument lists as the reference (gp_c.pyx:17, :34, :52,
+:70, :114): float64 C-contiguous numpy arrays in, results written into the
+caller's output array.  In the reference every function is a loop of dense
+(n, n) products; here each call is ONE entry of libgpx.so (include/gpx.h,
+``gpx_gp_c_*``): the host matrices are uploaded once, the arithmetic is
+re-expressed on the device as matrix-vector work, transposed-tile trace
+reductions and one GEMM per kernel parameter (csrc/gpx_deriv.hip, "Glue"), and
+only the output scalars come back.
 
-`log_lh(y, K, Kiy)` keeps the reference's signature; the second argument may be
-either the kernel matrix K (reference semantics: it is factored on the device,
-replacing the LU-based slogdet of gp_c.pyx:21) or, via `log_lh_chol`, its
-Cholesky factor.
+`gp.GP` takes this route for plugin kernels only (kernels without a native id);
+the built-in kernels never materialise a Jacobian or an inverse at all
+(`gpx_gp_dloglh_dtheta`, `gpx_gp_dlh_d2lh`, `gpx_gp_dm_dtheta`).
+
+`log_lh(y, K, Kiy)` keeps the reference's signature; the second argument is the
+kernel matrix K (it is factored on the device, replacing the LU-based slogdet of
+gp_c.pyx:21); `log_lh_chol` takes its Cholesky factor instead.
 """
 import ctypes
 
 import numpy as np
 
 from .. import _lib
-from ._buffers import as_buffer
+from ._buffers import as_buffer, check_out
 
 __all__ = ["log_lh", "log_lh_chol", "dloglh_dtheta", "dlh_dtheta", "d2lh_dtheta2", "dm_dtheta",
            "MIN"]
 
 DTYPE = np.float64
 MIN = _lib.MIN_LOG   # gp_c.pyx:14
-
-
-def _mm(A, B):
-    """np.dot(A, B) for 2-D float64 operands, on the device (C = A (B^T)^T)."""
-    A = np.ascontiguousarray(A, dtype=DTYPE)
-    Bt = np.ascontiguousarray(np.asarray(B, dtype=DTYPE).T)
-    C = np.empty((A.shape[0], Bt.shape[0]), dtype=DTYPE)
-    _lib.check(_lib.load().gpx_gemm_nt_host(_lib.dptr(C), _lib.dptr(A), _lib.dptr(Bt),
-                                            A.shape[0], Bt.shape[0], A.shape[1]))
-    return C
-
-
-def _mv(A, v):
-    """np.dot(A, v) for a matrix and a vector, on the device."""
-    return _mm(A, np.asarray(v, dtype=DTYPE).reshape(-1, 1)).ravel()
 
 
 def log_lh_chol(y, L, Kiy):
@@ -64,60 +55,61 @@ def log_lh(y, K, Kiy):                 # gp_c.pyx:17-31
     return log_lh_chol(y, L, Kiy)
 
 
-def _dK(Kj, i, m, s):
-    # gp_c.pyx:42-46: the last "parameter" is the noise s, dK/ds = 2 s I
-    return Kj[i] if i < Kj.shape[0] else np.eye(m) * 2 * s
+def _common(y, Ki, Kj, Kiy=None):
+    """Validated views of the arguments every derivative function shares, and (n, n_kernel_params)."""
+    y = as_buffer(y, 1, "y")
+    Ki = as_buffer(Ki, 2, "Ki")
+    Kj = as_buffer(Kj, 3, "Kj")
+    n = y.size
+    npar = Kj.shape[0]
+    if Ki.shape != (n, n) or Kj.shape[1:] != (n, n):
+        raise ValueError("Ki / Kj do not match y: %s, %s, n = %d" % (Ki.shape, Kj.shape, n))
+    if Kiy is not None:
+        Kiy = as_buffer(Kiy, 1, "Kiy")
+        if Kiy.size != n:
+            raise ValueError("Kiy has %d entries, expected %d" % (Kiy.size, n))
+    return y, Ki, Kj, Kiy, n, npar
 
 
 def dloglh_dtheta(y, Ki, Kj, Kiy, s, dloglh):      # gp_c.pyx:34-49
-    n, m = Kj.shape[0], Kj.shape[1]
-    for i in range(n + 1):
-        k = _mm(Ki, _dK(Kj, i, m, s))
-        t0 = 0.5 * np.dot(y, _mv(k, Kiy))
-        t1 = -0.5 * np.trace(k)
-        dloglh[i] = t0 + t1
+    y, Ki, Kj, Kiy, n, npar = _common(y, Ki, Kj, Kiy)
+    dloglh = as_buffer(dloglh, 1, "dloglh")
+    check_out(dloglh, (npar + 1,))
+    _lib.check(_lib.load().gpx_gp_c_dloglh_dtheta(_lib.dptr(y), _lib.dptr(Ki), _lib.dptr(Kj), _lib.dptr(Kiy),
+                                                  float(s), n, npar, _lib.dptr(dloglh)))
 
 
 def dlh_dtheta(y, Ki, Kj, Kiy, s, lh, dlh):        # gp_c.pyx:52-67
-    n, m = Kj.shape[0], Kj.shape[1]
-    for i in range(n + 1):
-        k = _mm(Ki, _dK(Kj, i, m, s))
-        t0 = np.dot(y, _mv(k, Kiy))
-        t1 = np.trace(k)
-        dlh[i] = 0.5 * lh * (t0 - t1)
+    y, Ki, Kj, Kiy, n, npar = _common(y, Ki, Kj, Kiy)
+    dlh = as_buffer(dlh, 1, "dlh")
+    check_out(dlh, (npar + 1,))
+    _lib.check(_lib.load().gpx_gp_c_dlh_dtheta(_lib.dptr(y), _lib.dptr(Ki), _lib.dptr(Kj), _lib.dptr(Kiy),
+                                               float(s), float(lh), n, npar, _lib.dptr(dlh)))
 
 
 def d2lh_dtheta2(y, Ki, Kj, Kh, Kiy, s, lh, dlh, d2lh):   # gp_c.pyx:70-111
-    n, m = Kj.shape[0], Kj.shape[1]
-    dK = [_dK(Kj, i, m, s) for i in range(n + 1)]
-    dKi = [_mm(-Ki, _mm(dK[i], Ki)) for i in range(n + 1)]
-    for i in range(n + 1):
-        KidK_i = _mm(Ki, dK[i])
-        ydKi_iy = np.dot(y, _mv(KidK_i, Kiy))
-        ydKi_iy_tr = ydKi_iy - np.trace(KidK_i)
-        for j in range(n + 1):
-            if j < n and i < n:
-                d2k = Kh[i, j]
-            elif j == n and i == n:
-                d2k = np.eye(m) * 2
-            else:
-                d2k = np.zeros((m, m))
-            dKi_jdK_i = _mm(dKi[j], dK[i])
-            t0 = dlh[j] * ydKi_iy_tr
-            t1a = np.dot(y, _mv(dKi_jdK_i, Kiy))
-            t1b = np.dot(Kiy, _mv(d2k, Kiy))
-            t1c = np.dot(Kiy, _mv(dK[i], _mv(dKi[j], y)))
-            t1 = lh * (t1a + t1b + t1c - np.trace(dKi_jdK_i + _mm(Ki, d2k)))
-            d2lh[i, j] = 0.5 * (t0 + t1)
+    y, Ki, Kj, Kiy, n, npar = _common(y, Ki, Kj, Kiy)
+    Kh = as_buffer(Kh, 4, "Kh")
+    if Kh.shape != (npar, npar, n, n):
+        raise ValueError("Kh has shape %s, expected %s" % (Kh.shape, (npar, npar, n, n)))
+    dlh = as_buffer(dlh, 1, "dlh")
+    if dlh.size != npar + 1:
+        raise ValueError("dlh has %d entries, expected %d" % (dlh.size, npar + 1))
+    d2lh = as_buffer(d2lh, 2, "d2lh")
+    check_out(d2lh, (npar + 1, npar + 1))
+    _lib.check(_lib.load().gpx_gp_c_d2lh_dtheta2(_lib.dptr(y), _lib.dptr(Ki), _lib.dptr(Kj), _lib.dptr(Kh),
+                                                 _lib.dptr(Kiy), float(s), float(lh), _lib.dptr(dlh), n, npar,
+                                                 _lib.dptr(d2lh)))
 
 
 def dm_dtheta(y, Ki, Kj, Kjxo, Kxox, s, dm):       # gp_c.pyx:114-131
-    n, m = Kj.shape[0], Kj.shape[1]
-    Kiy = _mv(Ki, y)
-    for i in range(n + 1):
-        if i < n:
-            dKxox, dKxx = Kjxo[i], Kj[i]
-        else:
-            dKxox, dKxx = np.zeros_like(Kxox), np.eye(m) * 2 * s
-        dm[i] = _mv(dKxox, Kiy)
-        dm[i] -= _mv(Kxox, _mv(_mm(Ki, _mm(dKxx, Ki)), y))
+    y, Ki, Kj, _, n, npar = _common(y, Ki, Kj)
+    Kjxo = as_buffer(Kjxo, 3, "Kjxo")
+    Kxox = as_buffer(Kxox, 2, "Kxox")
+    m = Kxox.shape[0]
+    if Kxox.shape != (m, n) or Kjxo.shape != (npar, m, n):
+        raise ValueError("Kjxo / Kxox do not match: %s, %s" % (Kjxo.shape, Kxox.shape))
+    dm = as_buffer(dm, 2, "dm")
+    check_out(dm, (npar + 1, m))
+    _lib.check(_lib.load().gpx_gp_c_dm_dtheta(_lib.dptr(y), _lib.dptr(Ki), _lib.dptr(Kj), _lib.dptr(Kjxo),
+                                              _lib.dptr(Kxox), float(s), n, npar, m, _lib.dptr(dm)))

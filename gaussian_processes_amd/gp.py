@@ -387,7 +387,7 @@ class GP(object):
             return out
         out, Ki = self._nan_or(npar)
         if Ki is not None:
-            gp_c.dloglh_dtheta(self._y, Ki, self.Kxx_J, self.inv_Kxx_y, self._s, out)
+            gp_c.dloglh_dtheta(_c(self._y), Ki, _c(self.Kxx_J), self.inv_Kxx_y, self._s, out)
         return out
 
     def _native_derivs(self):
@@ -403,7 +403,7 @@ class GP(object):
             return np.asarray(self.lh * self.dloglh_dtheta, dtype=DTYPE)
         out, Ki = self._nan_or(len(self.params))
         if Ki is not None:
-            gp_c.dlh_dtheta(self._y, Ki, self.Kxx_J, self.inv_Kxx_y, self._s, self.lh, out)
+            gp_c.dlh_dtheta(_c(self._y), Ki, _c(self.Kxx_J), self.inv_Kxx_y, self._s, self.lh, out)
         return out
 
     @memoprop
@@ -421,8 +421,8 @@ class GP(object):
         npar = len(self.params)
         out, Ki = self._nan_or((npar, npar))
         if Ki is not None:
-            gp_c.d2lh_dtheta2(self._y, Ki, self.Kxx_J, self.Kxx_H, self.inv_Kxx_y, self._s,
-                              self.lh, self.dlh_dtheta, out)
+            gp_c.d2lh_dtheta2(_c(self._y), Ki, _c(self.Kxx_J), _c(self.Kxx_H), self.inv_Kxx_y, self._s,
+                              self.lh, _c(self.dlh_dtheta), out)
         return out
 
     @memoprop
@@ -500,11 +500,11 @@ class GP(object):
             _lib.check(_lib.load().gpx_gp_dm_dtheta(st.handle, _lib.dptr(xo), m, _lib.dptr(dm)))
             return dm
         Ki = self.inv_Kxx
-        Kj = self.Kxx_J
-        Kjxo = self.K.jacobian(xo, self._x)
-        Kxox = self.Kxox(xo)
-        dm = np.empty((len(self.params), xo.shape[0]))
-        gp_c.dm_dtheta(self._y, Ki, Kj, Kjxo, Kxox, self._s, dm)
+        Kj = _c(self.Kxx_J)
+        Kjxo = _c(self.K.jacobian(xo, self._x))
+        Kxox = _c(self.Kxox(xo))
+        dm = np.empty((len(self.params), Kxox.shape[0]))
+        gp_c.dm_dtheta(_c(self._y), Ki, Kj, Kjxo, Kxox, self._s, dm)
         return dm
 
     # ---- persistence of the DEVICE state (extension; the reference pickles host arrays, gp/gp.py:78-92) ----
@@ -575,6 +575,11 @@ class GP(object):
         ax.plot(X, mean, lw=2, color=color)
         ax.plot(x, y, "o", ms=5, color=markercolor)
         ax.set_xlim(*xlim)
+
+
+def _c(a):
+    """float64 C-contiguous view / copy (what the ext modules' buffer arguments require)."""
+    return np.ascontiguousarray(a, dtype=DTYPE)
 
 
 def _check_finite(a):

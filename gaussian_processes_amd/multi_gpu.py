@@ -84,7 +84,9 @@ class GlooCallbacks(object):
 
     def __init__(self, dist):
         import torch
+        from .mlii import _cpu_group
         self.torch, self.dist = torch, dist
+        self.group = _cpu_group(dist)          # host buffers: never over an nccl default group
         self.rank = dist.get_rank()
         self.lib = _lib.load()
         self.error = None
@@ -97,7 +99,7 @@ class GlooCallbacks(object):
             _lib.check(self.lib.gpx_stream_sync(stream))
             if self.rank == root:
                 _lib.check(self.lib.gpx_memcpy_d2h(buf.ctypes.data_as(ctypes.c_void_p), dev_ptr, nbytes, stream))
-            self.dist.broadcast(self.torch.from_numpy(buf), src=root)
+            self.dist.broadcast(self.torch.from_numpy(buf), src=root, group=self.group)
             if self.rank != root:
                 _lib.check(self.lib.gpx_memcpy_h2d(dev_ptr, buf.ctypes.data_as(ctypes.c_void_p), nbytes, stream))
             return 0
@@ -111,7 +113,7 @@ class GlooCallbacks(object):
             _lib.check(self.lib.gpx_stream_sync(stream))
             _lib.check(self.lib.gpx_memcpy_d2h(buf.ctypes.data_as(ctypes.c_void_p), dev_ptr, buf.nbytes, stream))
             self.dist.all_reduce(self.torch.from_numpy(buf),
-                                 op=self.dist.ReduceOp.SUM if op == 0 else self.dist.ReduceOp.MAX)
+                                 op=self.dist.ReduceOp.SUM if op == 0 else self.dist.ReduceOp.MAX, group=self.group)
             _lib.check(self.lib.gpx_memcpy_h2d(dev_ptr, buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes, stream))
             return 0
         except Exception as exc:
@@ -129,10 +131,16 @@ class NativeDistributedGP(object):
                    "chain_update")
 
     def __init__(self, n, d, dtype_id=_lib.F64, kernel_id=_lib.KERNEL_GAUSSIAN, nb=None, dist=None,
-                 backend="rccl", device=0):
+                 backend="rccl", device=0, callbacks=None):
+        """`callbacks` (backend="callbacks" only): an object with ctypes function pointers `.bcast` / `.allreduce`
+        (gpx_mg_bcast_fn / gpx_mg_allreduce_fn of include/gpx.h), an `.error` slot and `.rank` / `.world` -- any
+        transport for the host-callback data plane; default: `GlooCallbacks(dist)`."""
         self.lib = _lib.load()
         self.n, self.d = int(n), int(d)
-        self.rank, self.world = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
+        if callbacks is not None:
+            self.rank, self.world = int(callbacks.rank), int(callbacks.world)
+        else:
+            self.rank, self.world = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
         self.nb = int(nb or default_nb(n, self.world))
         _lib.check(self.lib.gpx_set_device(int(device)))
         self.h = ctypes.c_void_p()
@@ -149,13 +157,15 @@ class NativeDistributedGP(object):
                 err = _lib.last_error() if rc != 0 else ""
             if dist is not None and self.world > 1:
                 import torch
+                from .mlii import _cpu_group
+                cpu = _cpu_group(dist)           # CPU tensors: a gloo side group when the default group is nccl
                 ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32)
-                dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # over the CPU group
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=cpu)
                 if int(ok.item()) == 0:
                     self.close()
                     raise _lib.GpxError("multi-GPU set-up failed on %s before the communicator was created%s"
                                         % ("this rank" if rc != 0 else "another rank", (": " + err) if err else ""))
-                dist.broadcast(torch.from_numpy(ident), src=0)    # the ncclUniqueId travels out of band
+                dist.broadcast(torch.from_numpy(ident), src=0, group=cpu)    # the ncclUniqueId travels out of band
             else:
                 _lib.check(rc)
             try:
@@ -164,8 +174,8 @@ class NativeDistributedGP(object):
                 self.close()
                 raise
         elif backend == "callbacks":
-            if dist is not None and self.world > 1:
-                self._cb = GlooCallbacks(dist)
+            if self.world > 1:
+                self._cb = callbacks if callbacks is not None else GlooCallbacks(dist)
                 b = ctypes.cast(self._cb.bcast, ctypes.c_void_p)
                 a = ctypes.cast(self._cb.allreduce, ctypes.c_void_p)
             else:
@@ -245,6 +255,47 @@ class NativeDistributedGP(object):
 
 
 # ------------------------------------------------------------------ benchmark --
+WATCHDOG_EXIT = 86      # exit status of a rank whose watchdog fired (bench.py's launcher recognises it)
+
+
+class Watchdog(object):
+    """Wall-clock bound around a phase that can only hang, never fail -- ncclCommInitRank with a peer that never
+    arrives, the first collective over a link that is not there.  The guarded call sits in C with the GIL released,
+    so a timer thread still runs: on expiry it says which phase on stderr and ends THIS process with status
+    WATCHDOG_EXIT (os._exit: no unwinding through frames blocked in RCCL).  Every rank carries its own; peers of a
+    hung rank are stuck in the same collective and expire with it, so the whole job fails loudly within `seconds`
+    instead of holding its GPUs until the lease ends.  Nothing is re-executed in a process that touched the GPU."""
+
+    def __init__(self, seconds, what, rank=0, on_expire=None):
+        import threading
+        self.what, self.rank, self.seconds = what, rank, float(seconds)
+        self._on_expire = on_expire or (lambda: os._exit(WATCHDOG_EXIT))
+        self._timer = threading.Timer(self.seconds, self._fire) if self.seconds > 0 else None
+        if self._timer is not None:
+            self._timer.daemon = True
+            self._timer.start()
+
+    def _fire(self):
+        import sys
+        try:
+            sys.stderr.write("bench: WATCHDOG rank %d: '%s' did not finish within %.0f s -- exiting with status %d\n"
+                             % (self.rank, self.what, self.seconds, WATCHDOG_EXIT))
+            sys.stderr.flush()
+        finally:
+            self._on_expire()
+
+    def cancel(self):
+        if self._timer is not None:
+            self._timer.cancel()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.cancel()
+        return False
+
+
 def bench_distributed(args, X, y, Xo, params, s, dtype_id, residual_check=None):
     """bench.py's N > 1 leg: the same workload as N = 1 (strong scaling), one rank per GPU.  Control plane:
     a torch.distributed gloo group (rendezvous, barriers, the ncclUniqueId, the max-over-ranks clock); data
@@ -293,7 +344,10 @@ def bench_distributed(args, X, y, Xo, params, s, dtype_id, residual_check=None):
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
     try:
-        gp = NativeDistributedGP(N, d, dtype_id=dtype_id, dist=dist, backend=backend, device=local_rank)
+        # communicator set-up and the first fit (the first real collectives) under a watchdog: see Watchdog
+        wd_s = float(os.environ.get("GPX_BENCH_WATCHDOG_S", "300"))
+        with Watchdog(wd_s, "communicator set-up (%s, world %d)" % (backend, world), rank):
+            gp = NativeDistributedGP(N, d, dtype_id=dtype_id, dist=dist, backend=backend, device=local_rank)
         gp.set_data(X, y)
 
         def step():
@@ -301,7 +355,10 @@ def bench_distributed(args, X, y, Xo, params, s, dtype_id, residual_check=None):
             mean = gp.mean(params, Xo)
             return llh, mean
 
-        for _ in range(args.warmup):
+        with Watchdog(wd_s, "first fit + predict (N=%d, world %d)" % (N, world), rank):
+            first = step()
+            dist.barrier()
+        for _ in range(max(0, args.warmup - 1)):
             step()
         # what the communicator itself says (ncclCommCount / ncclCommUserRank / ncclCommCuDevice), from every rank:
         # evidence that the data plane really spans `world` GPUs (a silent fallback would show rccl_nranks = 0)
@@ -376,6 +433,8 @@ def bench_distributed(args, X, y, Xo, params, s, dtype_id, residual_check=None):
             "rccl_nranks": comm_infos[0]["rccl_nranks"],
             "comm_info_per_rank": comm_infos,
             "panel_bcast_autotune": bcast_tune,
+            "watchdog_s": wd_s,
+            "first_fit_log_lh": first[0],
             "panel_bcast": gp.comm_info()["panel_bcast"],
             "whole_step_tflops_n3_over_3": round(tfl, 3),
             "whole_step_frac_of_peak_all_gpus": round(tfl / (peak * world), 4),

@@ -218,10 +218,10 @@ int gpx_d_gemm_nt(int dtype, int64_t M, int64_t N, int64_t K, double alpha,
  * info_dev: DEVICE int; 0 on success, j (1-based) if the j-th leading minor is
  * not positive definite (pivot <= 0 or NaN), as LAPACK reports it; negative: an
  * internal failure (the host entry points turn that into GPX_ERR_INTERNAL).
- * For n <= 16384 the call paces its panel launches on the device's progress (it
- * waits on the host for the previous step's update instead of putting a barrier
- * packet in front of every panel): it returns when most of the factorisation
- * has run, not at once; the result is still only complete in stream order. */
+ * A pure enqueue at every size (round 4: the host-paced panel launches that made
+ * the call block for n <= 16384 are confined to the handle's gpx_gp_fit, which
+ * says so; nothing here waits on the host, so the call is legal under stream
+ * capture); the result is complete in stream order. */
 int gpx_d_potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev,
                 void *stream);
 
@@ -416,6 +416,12 @@ int gpx_mg_set_bcast(gpx_mg_t *mg, int sag);
 /* test hook: the next gpx_mg_fit of this rank behaves as if its factorisation had left `value` in the device
  * info word (value < 0: an internal failure, which every rank must then report as GPX_ERR_INTERNAL) */
 int gpx_debug_mg_inject_info(gpx_mg_t *mg, int value);
+/* test hook, host arithmetic only (no GPU needed): how panel j of an n x n problem with block width nb on `world`
+ * ranks travels -- per row chunk (each its own broadcast + event) six values: first row, end row (relative to the
+ * panel's first row; the panel has n + 1 - j nb rows, the rider row included), elements in the chunk, elements per
+ * scatter / all-gather piece, elements in the last piece, 1 if the scatter + all-gather form is eligible.
+ * Returns the number of chunks (>= 1) or a negative status. */
+int gpx_debug_mg_plan(int64_t n, int64_t nb, int world, int chunks, int64_t j, int64_t *out, int cap);
 int gpx_mg_create_cb(gpx_mg_t **mg, int dtype, int kernel, int64_t n, int d, int64_t nb, int world, int rank,
                      gpx_mg_bcast_fn bcast, gpx_mg_allreduce_fn allreduce, void *user);
 int gpx_mg_destroy(gpx_mg_t *mg);
@@ -468,6 +474,26 @@ int gpx_cho_solve(const double *L, int64_t n, double *b);
  * from diag(L) instead of the reference's second LU factorisation of K. */
 int gpx_gp_c_log_lh(const double *y, const double *L, const double *Kiy, int64_t n,
                     double *log_lh);
+/* The derivative glue of gp/ext/gp_c.pyx for PLUGIN kernels, with the reference's own
+ * arguments: every array HOST float64, C order; n = number of training points, np =
+ * number of KERNEL parameters (outputs have np + 1 entries: the noise s is last);
+ * Ki (n, n) = inv(Kxx), Kj (np, n, n) the kernel Jacobian, Kh (np, np, n, n) its
+ * Hessian, Kiy (n,) = Ki y.  Every matrix crosses PCIe once; quadratic forms run as
+ * matrix-vector work, traces of products as reductions, only the np products
+ * dK_i Ki of the second-derivative trace terms as GEMMs (csrc/gpx_deriv.hip, "Glue").
+ *   gpx_gp_c_dloglh_dtheta -- gp_c.pyx:34-49     dloglh (np + 1)
+ *   gpx_gp_c_dlh_dtheta    -- gp_c.pyx:52-67     dlh    (np + 1)
+ *   gpx_gp_c_d2lh_dtheta2  -- gp_c.pyx:70-111    d2lh   (np + 1, np + 1); dlh is an INPUT as there
+ *   gpx_gp_c_dm_dtheta     -- gp_c.pyx:114-131   dm     (np + 1, m); Kjxo (np, m, n), Kxox (m, n) */
+int gpx_gp_c_dloglh_dtheta(const double *y, const double *Ki, const double *Kj, const double *Kiy,
+                           double s, int64_t n, int np, double *dloglh);
+int gpx_gp_c_dlh_dtheta(const double *y, const double *Ki, const double *Kj, const double *Kiy,
+                        double s, double lh, int64_t n, int np, double *dlh);
+int gpx_gp_c_d2lh_dtheta2(const double *y, const double *Ki, const double *Kj, const double *Kh,
+                          const double *Kiy, double s, double lh, const double *dlh, int64_t n,
+                          int np, double *d2lh);
+int gpx_gp_c_dm_dtheta(const double *y, const double *Ki, const double *Kj, const double *Kjxo,
+                       const double *Kxox, double s, int64_t n, int np, int64_t m, double *dm);
 
 /* C (M, N) = A (M, K) * B (N, K)^T, all HOST float64 C-contiguous: the np.dot
  * calls of the derivative glue (gp/ext/gp_c.pyx:43-48,61-66,89-110,127-131) on
