@@ -675,7 +675,8 @@ static int glue_d2lh(const double *y, const double *Ki, const double *Kj, const 
         GPX_TRY(G.mv(dD[i].p, n, n, ld, dw.p, at(Pv, i)));
         GPX_TRY(G.mv(dKi.p, n, n, ld, at(Pv, i), at(Rv, i)));
         GPX_TRY(dN[i].alloc((size_t)n * ld * 8));
-        GPX_TRY(gemm_nt(GPX_F64, n, n, n, dD[i].p, ld, dKiT.p, ld, dN[i].p, ld, 1.0, GPX_FULL, 0, 0, G.st, 1));   // N_i = dK_i Ki
+        GPX_HIP(hipMemsetAsync(dN[i].p, 0, (size_t)n * ld * 8, G.st));                   // (beta = 0 exists on the aligned fast path only)
+        GPX_TRY(gemm_nt(GPX_F64, n, n, n, dD[i].p, ld, dKiT.p, ld, dN[i].p, ld, 1.0, GPX_FULL, 0, 0, G.st));      // N_i = dK_i Ki
     }
     // the noise: dK = 2 s I
     GPX_TRY(G.scale(dKiy.p, at(V, np), n, 2.0 * s));

@@ -212,7 +212,7 @@ __device__ __forceinline__ void res_prod(const T (*sa)[PT], const T (*sb)[PT], t
 // LEAF_MFMA: the diagonal block's leaf on the MFMA pipe (fp64: always; fp32: the short-panel instantiation -- the
 // unrolled MFMA sweep costs the fp32 kernel 58 VGPRs, i.e. a third workgroup per CU, which tall panels miss more than
 // they gain from the faster leaf)
-template <typename T, bool LEAF_MFMA>
+template <typename T, bool LEAF_MFMA, int LV = 1>
 __global__ __launch_bounds__(256, 2) void panel_res_kernel(T *__restrict__ A, int64_t lda, int64_t n, int64_t r0, int64_t c0,
                                                            int nsteps, int *__restrict__ info, T *__restrict__ pub,
                                                            int *__restrict__ flags, int serial, int64_t sM, int kpre,
@@ -430,7 +430,13 @@ __global__ __launch_bounds__(256, 2) void panel_res_kernel(T *__restrict__ A, in
         for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
             for (int r = 0; r < 4; ++r) xw[jj][r] = (16 * wave + M::row(lane, r) == 16 * jj + li) ? (T)1 : (T)0;
-        LeafMfma<T>::run(dg, xw, r0 + (int64_t)IB * j, info, wave, lane, (stamps && w == 0 && blockIdx.y == 0) ? stamps + 2040 * 16 : nullptr);
+        // LV = 2 (fp64): the leaf whose pivot lane runs ahead of the strip (gpx_leaf.h, factor64_mfma2)
+        if constexpr (LV == 3 && sizeof(T) == 8)
+            factor64_mfma3(dg, xw, r0 + (int64_t)IB * j, info, wave, lane, (stamps && w == 0 && blockIdx.y == 0) ? stamps + 2040 * 16 : nullptr);
+        else if constexpr (LV == 2 && sizeof(T) == 8)
+            factor64_mfma2(dg, xw, r0 + (int64_t)IB * j, info, wave, lane, (stamps && w == 0 && blockIdx.y == 0) ? stamps + 2040 * 16 : nullptr);
+        else
+            LeafMfma<T>::run(dg, xw, r0 + (int64_t)IB * j, info, wave, lane, (stamps && w == 0 && blockIdx.y == 0) ? stamps + 2040 * 16 : nullptr);
         T *W = pub + (int64_t)j * (IB * IB);
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
@@ -562,9 +568,19 @@ static int panel_res_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int
     // update of the step before (64 x n = 8192: 0.213 -> 0.199 s with two parts, 16 x: 55.0 -> 54.6 ms, 8 x: 29.4 -> 30.8)
     const int64_t nmat = bt ? bt->count : 1;
     const bool two_part = nmat > 1 ? rows * nmat > env_i64("GPX_POTRF_TWO_PART_BATCH", 98304) : rows > two_part_rows;
+    // fp64 leaf (gpx_leaf.h): GPX_LEAF = 3 (default) the rolled loop with the pivot lane ahead of the strip, 2 the same
+    // schedule fully unrolled, 1 the round-3 leaf
+    const int64_t leaf = F64 ? env_i64("GPX_LEAF", 3) : 1;
+    const bool v3 = leaf == 3, v2 = leaf == 2;
     if (two_part && (int64_t)grid.x > nsteps) {
         const bool mfma_chain = F64 || env_i64("GPX_LEAF_MFMA_F32_ROWS", 16384) > 0;
-        if (mfma_chain)
+        if (v3)
+            hipLaunchKernelGGL((panel_res_kernel<T, true, F64 ? 3 : 1>), dim3((unsigned)nsteps, grid.y), dim3(256), 0, st, A, lda, n, r0, c0, nsteps,
+                               info_dev, (T *)pub, flags, serial, bt ? bt->sA : (int64_t)0, (int)(kpre / IB), stamps, 0, strict);
+        else if (v2)
+            hipLaunchKernelGGL((panel_res_kernel<T, true, F64 ? 2 : 1>), dim3((unsigned)nsteps, grid.y), dim3(256), 0, st, A, lda, n, r0, c0, nsteps,
+                               info_dev, (T *)pub, flags, serial, bt ? bt->sA : (int64_t)0, (int)(kpre / IB), stamps, 0, strict);
+        else if (mfma_chain)
             hipLaunchKernelGGL((panel_res_kernel<T, true>), dim3((unsigned)nsteps, grid.y), dim3(256), 0, st, A, lda, n, r0, c0, nsteps,
                                info_dev, (T *)pub, flags, serial, bt ? bt->sA : (int64_t)0, (int)(kpre / IB), stamps, 0, strict);
         else
@@ -573,6 +589,12 @@ static int panel_res_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int
         // (the rows never run a leaf: the lean instantiation)
         hipLaunchKernelGGL((panel_res_kernel<T, F64>), dim3(grid.x - (unsigned)nsteps, grid.y), dim3(256), 0, st, A, lda, n, r0, c0, nsteps,
                            info_dev, (T *)pub, flags, serial, bt ? bt->sA : (int64_t)0, (int)(kpre / IB), stamps, nsteps, strict);
+    } else if (v3) {
+        hipLaunchKernelGGL((panel_res_kernel<T, true, F64 ? 3 : 1>), grid, dim3(256), 0, st, A, lda, n, r0, c0, nsteps, info_dev, (T *)pub,
+                           flags, serial, bt ? bt->sA : (int64_t)0, (int)(kpre / IB), stamps, 0, strict);
+    } else if (v2) {
+        hipLaunchKernelGGL((panel_res_kernel<T, true, F64 ? 2 : 1>), grid, dim3(256), 0, st, A, lda, n, r0, c0, nsteps, info_dev, (T *)pub,
+                           flags, serial, bt ? bt->sA : (int64_t)0, (int)(kpre / IB), stamps, 0, strict);
     } else if (mfma_single) {
         hipLaunchKernelGGL((panel_res_kernel<T, true>), grid, dim3(256), 0, st, A, lda, n, r0, c0, nsteps, info_dev, (T *)pub,
                            flags, serial, bt ? bt->sA : (int64_t)0, (int)(kpre / IB), stamps, 0, strict);

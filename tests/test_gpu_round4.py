@@ -159,6 +159,38 @@ def test_soak_repeat_fits_are_bitwise_identical(monkeypatch, n, dtype):
         assert _residual(X, y, a0, h, w, s, rows) < (1e-9 if f64 else 2e-3)
 
 
+# ------------------------------------------------- the round-4 leaf (pivot lane ahead) --
+@pytest.mark.parametrize("N", [64, 130, 700, 1990, 4171])
+def test_leaf_with_pivot_lane_ahead_vs_round3_leaf_and_oracle(monkeypatch, N):
+    """The fp64 resident panel kernel has three leaves (gpx_leaf.h): factor64_mfma3 (default: the pivot lane forms, factors
+    and inverts the NEXT 4 x 4 diagonal tile while the waves finish the current step -- two barriers a step -- as a ROLLED
+    loop of 16 steps that stays in the instruction cache), factor64_mfma2 (GPX_LEAF=2: the same schedule fully unrolled)
+    and the round-3 factor64_mfma (GPX_LEAF=1: three barriers, everybody waits for the pivot lane).  All against the
+    oracle's factor, log_lh, alpha and inverse; 3 and 2 run the same arithmetic in the same order (bitwise equal), 1 rounds
+    the pivot tile's strip rows differently (equal to ~1e-13)."""
+    d = 3
+    X, y, Xo = orc.synth_inputs(N, d, 16)
+    h, w, s = 1.0, 0.5 * np.sqrt(d), 0.9
+    o = orc.OracleGP("gaussian", (h, w), X, y, s)
+    out = {}
+    for label, env in (("v3", None), ("v2", "2"), ("v1", "1")):
+        if env is None:
+            monkeypatch.delenv("GPX_LEAF", raising=False)
+        else:
+            monkeypatch.setenv("GPX_LEAF", env)
+        g = gp.GP(gp.GaussianKernel(h, w), X, y, s=s)
+        out[label] = (float(g.log_lh), np.array(g.Lxx), np.array(g.inv_Kxx_y), np.array(g.inv_Kxx) if N <= 700 else None)
+        np.testing.assert_allclose(out[label][0], o.log_lh, rtol=1e-10, err_msg=label)
+        np.testing.assert_allclose(np.tril(out[label][1]), o.Lxx, rtol=1e-9, atol=1e-12, err_msg=label)
+        np.testing.assert_allclose(out[label][2], o.inv_Kxx_y, rtol=1e-8, atol=1e-11, err_msg=label)
+        if N <= 700:                                           # W = inv(L_jj) of the leaves feeds the explicit inverse
+            np.testing.assert_allclose(out[label][3], o.inv_Kxx, rtol=1e-7, atol=1e-10, err_msg=label)
+    monkeypatch.delenv("GPX_LEAF", raising=False)
+    assert out["v3"][0] == out["v2"][0]
+    assert np.array_equal(np.tril(out["v3"][1]), np.tril(out["v2"][1]))
+    np.testing.assert_allclose(np.tril(out["v3"][1]), np.tril(out["v1"][1]), rtol=1e-11, atol=1e-13)
+
+
 # ------------------------------------- the reference's property checks, seeded stream --
 DTHETA = 1e-5            # gp/tests/util.py:9 'dtheta'
 PFAIL = 5                # 'pct_allowed_failures'
