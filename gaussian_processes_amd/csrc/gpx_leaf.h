@@ -400,6 +400,7 @@ __device__ __forceinline__ void factor64_mfma(PM<double>::v4 (&a)[4], PM<double>
         }
         __syncthreads();
         if (stamps && jt == 9 && threadIdx.x == 0) stamps[0] = __builtin_amdgcn_s_memtime();
+        if (stamps && threadIdx.x == 0) { stamps[16 + jt] = __builtin_amdgcn_s_memrealtime(); stamps[32 + jt] = __builtin_amdgcn_s_memtime(); }
         // ---- S2 ----
         if (wave == pw && lane == 0) {
             double d[4][4], wi[4][4], rk[4];
@@ -520,67 +521,80 @@ __device__ __forceinline__ void factor64_mfma(PM<double>::v4 (&a)[4], PM<double>
 
 
 
-// ---- round 4: the same leaf with the pivot lane running AHEAD of the strip -------------------------------------------
-// factor64_mfma above spends 1220 of its 2200 cycles a step with 255 lanes waiting at a barrier for ONE lane: that lane
-// reads the step's 4 x 4 diagonal tile from LDS -- which exists only after the previous step's rank-4 update (S5) and
-// the strip hand-over (S1) -- factors it, inverts it, and only then can S3 start.  But the NEXT diagonal tile depends on
-// very little of step jt: with S = the raw strip rows c0+4 .. c0+7 (4 x 4), N = the raw next tile (4 x 4, as updated
-// through step jt - 1) and Wi = inv(L_dd) of step jt,
-//         D(jt + 1) = N - (S Wi^T)(S Wi^T)^T                                        80 fused multiply-adds,
-// all of whose inputs are in LDS at the START of step jt.  So the pivot lane forms D(jt + 1) itself, while the waves
-// do S3 / S4 of step jt, and factors + inverts it while they do S5 of step jt: inverse(jt + 1) is published before
-// step jt + 1 begins and nobody ever waits for the pivot chain -- a step costs max(pivot lane's loop, the waves'
-// S3 + S4 + S5) with TWO barriers instead of the SUM with three.
-//   [B1]  waves: S3 strip solve (1 MFMA), S4 strip -> LDS, X rows of the step before   |  pivot: S, N from LDS, D(jt+1)
-//   [B2]  waves: S5 rank-4 updates; raw strip jt+1 and raw tile jt+2 -> LDS            |  pivot: factor + invert D(jt+1), publish
-// The pivot lane's rows of the strip are computed twice (its own fmas for D(jt + 1); the S3 MFMA for the strip that is
-// stored and used by every update): two roundings of the same exact numbers, both backward stable; the factor L_dd the
-// pivot lane publishes is the one that is stored.  The pivot lane lives in wave 0, whose rows are final after four
-// steps.  Rank-4 updates of tiles ABOVE the diagonal (column tile > the wave's row tile) are skipped: nothing reads
-// them (only the lower triangle of the block is loaded, used and stored).
-__device__ __forceinline__ void factor64_mfma2(PM<double>::v4 (&a)[4], PM<double>::v4 (&x)[4], int64_t j0, int *__restrict__ info,
-                                               int wave, int lane, unsigned long long *stamps = nullptr)
+// ---- round 4: the leaf in ONE wave, without LDS and without barriers -----------------------------------------------------
+// Two variants of factor64_mfma were built first in round 4 and removed again (DESIGN section 3.2b keeps the measurements):
+// the pivot lane running AHEAD of the strip -- it forms D(jt + 1) = N - (S Wi^T)(S Wi^T)^T itself, 80 fmas, and factors it
+// while the waves finish step jt, two barriers a step instead of three -- fully unrolled (a 92 KB kernel) and as a rolled
+// 16-step loop (61 KB).  Per-step stamps (profiles/r04_leaf_steps_v1_v2_v3.log) showed why neither paid: a step takes
+// ~1.0 us while the diagonal workgroup has its CU to itself and 3.3 - 4.7 us while workgroups of the trailing update
+// share it, whatever the schedule inside the step.
+// This one touches LDS only to load the block and to store the results, and meets no barrier in between.  The idea:
+// factor the TRANSPOSE.  With
+// M = U^T U (U upper, L = U^T) held as accumulator tiles T(ti, tj), ti <= tj -- lane (li, lq), register r:
+// M[16 ti + lq + 4 r][16 tj + li] -- the four ROWS c0 .. c0 + 3 of a step are register q = (c0 / 4) % 4 of the tiles
+// of tile row jj0, and such a register is, untouched,
+//     as an MFMA B operand (4 x 16):  B[k][n] = U[c0 + k][16 tj + n]
+//     as an MFMA A operand (16 x 4):  A[i][k] = U[c0 + k][16 ti + i]
+// so the rank-4 update  T(ti, tj) -= U_strip(ti)^T U_strip(tj)  takes its operands straight from the accumulator
+// registers of the strip: no layout change, no LDS, no other wave.  The strip solve is one MFMA per tile whose A operand
+// is the 4 x 4 inverse (every lane computes it, from the diagonal tile gathered with v_readlane) and whose result lands
+// in the register it came from.  The same row operations applied to the identity give Y = U^-T = L^-1 = W, the inverse
+// the panel kernel publishes.  One wave does all of it (14 MFMAs a step on average, its SIMD's matrix pipe 40 % busy);
+// the other three waves of the workgroup wait at the barrier behind it.  16 steps, fully unrolled (static tile indices).
+__device__ __forceinline__ constexpr int w1_tix(int ti, int tj) { return ti * 4 - ti * (ti - 1) / 2 + (tj - ti); }   // ti <= tj
+__device__ __forceinline__ double w1_bcast(double v, int src)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, src);
+    hi = __builtin_amdgcn_readlane(hi, src);
+    return __hiloint2double(hi, lo);
+}
+
+// sM: the block, row-major, lower triangle valid (pitch PT).  On return sM holds L (lower; entries above the diagonal are
+// not written) and sW holds W = inv(L) (all 64 x 64, zeros above the diagonal).  One wave (64 lanes) calls this.
+template <int PT>
+__device__ __forceinline__ void factor64_wave(double (*sM)[PT], double (*sW)[PT], int64_t j0, int *__restrict__ info, int lane,
+                                              unsigned long long *stamps = nullptr)
 {
     typedef PM<double> M;
     typedef M::v4 v4;
-    __shared__ __attribute__((aligned(16))) double sS[IB][4];   // the step's raw column strip (rows of the block)
-    __shared__ __attribute__((aligned(16))) double sN[4][4];    // the NEXT step's raw diagonal tile
-    __shared__ double sLn[IB][4];         // the step's finished strip of L
-    __shared__ __attribute__((aligned(16))) double sWi[2][4][4];   // inv(L_dd) of the step (by parity), zero above the diagonal
-    __shared__ __attribute__((aligned(16))) double sDd[2][4][4];   // L_dd (by parity), zero above the diagonal
-    __shared__ double sXd[4][IB];         // four rows of X (of the step before: the X side runs one step behind)
     const int li = lane & 15, lq = lane >> 4;
     const v4 zero = {0.0, 0.0, 0.0, 0.0};
-    const bool pivot = wave == 0 && lane == 0;
-    if (threadIdx.x < 32) {
-        const int h = threadIdx.x >> 4, e = threadIdx.x & 15;
-        sWi[h][e >> 2][e & 3] = 0.0; sDd[h][e >> 2][e & 3] = 0.0;
-    }
-    // raw strip of step `jt` (columns 4 jt ..) and raw diagonal tile of step jt + 1, from the accumulator tiles
-    auto hand_over = [&](int jt) {
-        const int jj0 = jt >> 2, q = jt & 3;
-        if ((li >> 2) == q) {
+    v4 T[10], Y[10];                       // Y(ti, tj'), ti >= tj': stored at w1_tix(tj', ti)
+    // ---- load: T(ti, tj)[r] = M[16 ti + lq + 4 r][16 tj + li], taken from the lower triangle (symmetric) ----
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sS[16 * wave + lq + 4 * r][li & 3] = a[jj0][r];
-        }
-        if (jt + 1 < IB / 4) {
-            const int jjn = (jt + 1) >> 2, qn = (jt + 1) & 3;
-            if (wave == jjn && (li >> 2) == qn) {                 // rows 4 qn + lq of the wave's 16: register qn
+    for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)                        // (a loop with a constant test, not a[jjn][qn]: the direct form
-                    if (r == qn) sN[lq][li & 3] = a[jjn][r];       //  cost the kernel 340 bytes of scratch a lane)
+        for (int tj = ti; tj < 4; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * ti + lq + 4 * r, col = 16 * tj + li;
+                T[w1_tix(ti, tj)][r] = row <= col ? sM[col][row] : sM[row][col];
             }
-        }
-    };
-    // the pivot lane's state: the current tile's inverse (lower) and the next tile (lower)
-    double wi[4][4], dn[4][4];
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+        for (int tj = 0; tj <= ti; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Y[w1_tix(tj, ti)][r] = (ti == tj && lq + 4 * r == li) ? 1.0 : 0.0;
     int bad_at = 0;
-    auto factor_publish = [&](int jt, double (&d)[4][4]) {      // d: lower part of diagonal tile jt -> L_dd, inverse; publish both
-        double rk[4];
+#pragma unroll
+    for (int jt = 0; jt < IB / 4; ++jt) {
+        const int c0 = 4 * jt, jj0 = jt >> 2, q = jt & 3;
+        if (stamps && lane == 0) { stamps[16 + jt] = __builtin_amdgcn_s_memrealtime(); stamps[32 + jt] = __builtin_amdgcn_s_memtime(); }
+        // ---- the 4 x 4 diagonal tile to every lane: d[r][c] (r >= c) = M[c0 + c][c0 + r] ----
+        double d[4][4], wi[4][4], rk[4];
+        {
+            const double src = T[w1_tix(jj0, jj0)][q];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c <= r; ++c) d[r][c] = w1_bcast(src, 16 * c + 4 * q + r);
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const double piv = d[k][k];
-            if (bad_at == 0 && !(piv > 0.0)) bad_at = 4 * jt + k + 1;                // also catches NaN; reported at the end
+            if (bad_at == 0 && !(piv > 0.0)) bad_at = c0 + k + 1;                    // also catches NaN; reported at the end
             const double rinv = fast_rsqrt(piv);
             rk[k] = rinv;
             d[k][k] = piv * rinv;
@@ -591,6 +605,7 @@ __device__ __forceinline__ void factor64_mfma2(PM<double>::v4 (&a)[4], PM<double
 #pragma unroll
                 for (int r = c; r < 4; ++r) d[r][c] = fma(-d[r][k], d[c][k], d[r][c]);
         }
+        // inv(l), l = R^T lower: column by column
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
 #pragma unroll
@@ -603,370 +618,68 @@ __device__ __forceinline__ void factor64_mfma2(PM<double>::v4 (&a)[4], PM<double
                 wi[i][k] = -rk[i] * sacc;
             }
         }
-        struct alignas(16) D2 { double v[2]; };
+        // A operand of the strip solve: A[i][m] = inv(l)[i][m] at lane (li = i < 4, lq = m)
+        double aw = 0.0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int k = 0; k + 1 <= i; k += 2) {
-                *reinterpret_cast<D2 *>(&sWi[jt & 1][i][k]) = D2{{wi[i][k], wi[i][k + 1]}};
-                *reinterpret_cast<D2 *>(&sDd[jt & 1][i][k]) = D2{{d[i][k], (k + 1 <= i) ? d[i][k + 1] : 0.0}};
-            }
-            if ((i & 1) == 0) { sWi[jt & 1][i][i] = wi[i][i]; sDd[jt & 1][i][i] = d[i][i]; }
+            for (int m = 0; m <= i; ++m) aw = (li == i && lq == m) ? wi[i][m] : aw;
+        // ---- strip solve: rows c0 .. c0 + 3 of U (tiles of tile row jj0) and of Y ----
+#pragma unroll
+        for (int tj = jj0; tj < 4; ++tj) {
+            const v4 u = M::mfma(aw, T[w1_tix(jj0, tj)][q], zero);
+            T[w1_tix(jj0, tj)][q] = u[0];
         }
-    };
-    // ---- prologue: strip 0 and tile 1 to LDS; the pivot lane factors tile 0 ----
-    hand_over(0);
-    __syncthreads();
-    if (pivot) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            double row[4];
-            load_frag32<double>(&sS[i][0], row);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) dn[i][k] = (k <= i) ? row[k] : 0.0;
+        for (int tj = 0; tj <= jj0; ++tj) {
+            const v4 u = M::mfma(aw, Y[w1_tix(tj, jj0)][q], zero);
+            Y[w1_tix(tj, jj0)][q] = u[0];
         }
-        factor_publish(0, dn);
-    }
-    double al_prev = 0.0;
+        // ---- a block of four steps is complete: tile row jj0 of U and of Y is final -- to LDS now (L = U^T, lower part
+        // only; W = Y with zeros right of the diagonal tile), which ends the life of those registers ----
+        if (q == 3) {
 #pragma unroll
-    for (int jt = 0; jt < IB / 4; ++jt) {
-        const int c0 = 4 * jt, jj0 = jt >> 2, q = jt & 3;
-        const int jjp = (jt - 1) >> 2, qp = (jt - 1) & 3;        // the step before (jt > 0)
-        __syncthreads();                                          // B1: sS = raw strip jt, sN = raw tile jt + 1, inverse jt published
-        if (stamps && jt == 9 && threadIdx.x == 0) stamps[0] = __builtin_amdgcn_s_memtime();
-        if (stamps && jt == 10 && threadIdx.x == 0) stamps[7] = __builtin_amdgcn_s_memtime();
-        // ---- pivot lane: D(jt + 1) ----
-        if (pivot && jt + 1 < IB / 4) {
-            double S[4][4], ls[4][4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                load_frag32<double>(&sS[c0 + 4 + i][0], S[i]);
-                double row[4];
-                load_frag32<double>(&sN[i][0], row);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) dn[i][k] = (k <= i) ? row[k] : 0.0;
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    double v = S[r][0] * wi[c][0];
-#pragma unroll
-                    for (int k = 1; k <= c; ++k) v = fma(S[r][k], wi[c][k], v);
-                    ls[r][c] = v;
-                }
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int c = 0; c <= r; ++c) {
-                    double v = dn[r][c];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v = fma(-ls[r][k], ls[c][k], v);
-                    dn[r][c] = v;
-                }
-        }
-        if (stamps && jt == 9 && pivot) stamps[1] = __builtin_amdgcn_s_memtime();
-        // ---- waves: X rows of the step before (B operand in place in the registers) ----
-        if (jt > 0 && wave == jjp) {
-            const double wprev = (li < 4) ? sWi[(jt - 1) & 1][li][lq] : 0.0;
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                if (jj > jjp) continue;                         // X is lower triangular: nothing to the right of the step
-                const v4 u = M::mfma(wprev, x[jj][qp], zero);
-                x[jj][qp] = u[0];
-                sXd[lq][16 * jj + li] = u[0];
-            }
-        }
-        // ---- S3: new strip = strip . inv(L_dd)^T;  S4: to LDS (the diagonal rows take L_dd itself) ----
-        // (a wave whose 16 rows all lie above the step has nothing left to do but keep the barriers: wave w is active
-        //  while jt < 4 (w + 1); from step 4 on wave 0 is the pivot lane's alone)
-        const bool active = wave >= jj0;
-        if (active) {
-            const double winv = (li < 4) ? sWi[jt & 1][li][lq] : 0.0;   // B operand: B[k][n] = Winv[n][k]
-            const v4 t = M::mfma(sS[16 * wave + li][lq], winv, zero);
-            if (li < 4) {
+            for (int tj = jj0; tj < 4; ++tj)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * wave + lq + 4 * r;
-                    sLn[row][li] = (row >= c0 && row < c0 + 4) ? sDd[jt & 1][row - c0][li] : t[r];
-                }
-            }
-        }
-        if (stamps && jt == 9 && threadIdx.x == 192) stamps[2] = __builtin_amdgcn_s_memtime();
-        __syncthreads();                                          // B2: sLn, sXd are in
-        if (stamps && jt == 9 && threadIdx.x == 0) stamps[3] = __builtin_amdgcn_s_memtime();
-        // ---- pivot lane: factor + invert tile jt + 1, publish (read at the next B1) ----
-        if (pivot && jt + 1 < IB / 4) factor_publish(jt + 1, dn);
-        if (stamps && jt == 9 && pivot) stamps[4] = __builtin_amdgcn_s_memtime();
-        // ---- S5 ----
-        double al = 0.0;
-        if (active) {
-            if ((li >> 2) == q) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) a[jj0][r] = sLn[16 * wave + lq + 4 * r][li & 3];
-            }
-            const int arow = 16 * wave + li;
-            al = (arow > c0 + 3) ? -sLn[arow][lq] : 0.0;          // rows at or above the step: no update
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                // the tile that holds the NEXT step's strip first
-                const int tj = (jj + ((jt + 1) >> 2)) & 3;
-                if (tj >= jj0 && tj <= wave) {                      // (tiles above the diagonal: never read)
-                    const int bcol = 16 * tj + li;
-                    const double bl = (bcol > c0 + 3) ? sLn[bcol][lq] : 0.0;      // columns up to the step are final
-                    a[tj] = M::mfma(al, bl, a[tj]);
-                }
-            }
-        }
-        if (jt + 1 < IB / 4 && wave >= ((jt + 1) >> 2)) hand_over(jt + 1);   // raw strip jt + 1 (and raw tile jt + 2) for the next step
-        if (jt > 0 && wave >= jjp) {                              // (al_prev is zero for a wave above step jt - 1)
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-                if (jj <= jjp) x[jj] = M::mfma(al_prev, sXd[lq][16 * jj + li], x[jj]);
-        }
-        al_prev = al;
-        if (stamps && jt == 9 && threadIdx.x == 192) stamps[5] = __builtin_amdgcn_s_memtime();
-        if (stamps && jt == 10 && threadIdx.x == 0) stamps[6] = __builtin_amdgcn_s_memtime();
-    }
-    if (pivot && bad_at != 0) atomicCAS(info, 0, (int)(j0 + bad_at));        // first failure wins
-    // the last step's X rows (its rank-4 update has no rows below it)
-    if (wave == 3) {
-        const double wprev = (li < 4) ? sWi[1][li][lq] : 0.0;
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const v4 u = M::mfma(wprev, x[jj][3], zero);
-            x[jj][3] = u[0];
-        }
-    }
-}
-
-
-
-// ---- round 4, second step: the same leaf as a ROLLED loop ------------------------------------------------------------
-// Both leaves above are fully unrolled -- 16 steps of straight-line code that each run exactly once -- because the tile
-// (jt >> 2) and the register (jt & 3) a step touches had to be compile-time constants.  That made the fp64 panel kernel
-// 79 - 92 KB of code against a 64 KB instruction cache (shared by two CUs, and with the trailing update's kernel): every
-// step fetches its instructions cold, ~12 cycles an instruction instead of the 4 - 7 the arithmetic needs (measured:
-// factor64_mfma2's pivot lane took 1228 cycles for 80 independent fmas; the whole step 2712 instead of ~900).
-// Here ONE step body runs 16 times:
-//   * the current column tile is always a[0]: when a block of four steps ends, a[0] -- final -- is copied into out[]
-//     by a select over the block index and the tiles shift left (24 register moves per block);
-//   * the register of a tile that holds the step's rows (jt & 3, dynamic now) is read / written through 4-way selects;
-//   * everything else that depended on jt is either an LDS address, a lane mask, or a wave-uniform branch.
-// Same two-barrier schedule, same arithmetic, same results as factor64_mfma2.
-__device__ __forceinline__ double sel4(const PM<double>::v4 &v, int k)
-{
-    return k == 0 ? v[0] : (k == 1 ? v[1] : (k == 2 ? v[2] : v[3]));
-}
-__device__ __forceinline__ void put4(PM<double>::v4 &v, int k, double val)
-{
-    v[0] = k == 0 ? val : v[0]; v[1] = k == 1 ? val : v[1]; v[2] = k == 2 ? val : v[2]; v[3] = k == 3 ? val : v[3];
-}
-
-__device__ __forceinline__ void factor64_mfma3(PM<double>::v4 (&a)[4], PM<double>::v4 (&x)[4], int64_t j0, int *__restrict__ info,
-                                               int wave, int lane, unsigned long long *stamps = nullptr)
-{
-    typedef PM<double> M;
-    typedef M::v4 v4;
-    __shared__ __attribute__((aligned(16))) double sS[IB][4];   // the step's raw column strip (rows of the block)
-    __shared__ __attribute__((aligned(16))) double sN[4][4];    // the NEXT step's raw diagonal tile
-    __shared__ double sLn[IB][4];         // the step's finished strip of L
-    __shared__ __attribute__((aligned(16))) double sWi[2][4][4];   // inv(L_dd) of the step (by parity), zero above the diagonal
-    __shared__ __attribute__((aligned(16))) double sDd[2][4][4];   // L_dd (by parity), zero above the diagonal
-    __shared__ double sXd[4][IB];         // four rows of X (of the step before: the X side runs one step behind)
-    const int li = lane & 15, lq = lane >> 4;
-    const v4 zero = {0.0, 0.0, 0.0, 0.0};
-    const bool pivot = wave == 0 && lane == 0;
-    if (threadIdx.x < 32) {
-        const int h = threadIdx.x >> 4, e = threadIdx.x & 15;
-        sWi[h][e >> 2][e & 3] = 0.0; sDd[h][e >> 2][e & 3] = 0.0;
-    }
-    v4 out[4] = {a[0], a[1], a[2], a[3]};             // finished tiles (by column tile); a[] becomes "current tile first"
-    // raw strip of step jt (columns 4 jt .., in the CURRENT tile a[0]) and raw diagonal tile of step jt + 1 (in a[0], or
-    // in a[1] when step jt + 1 opens the next block; always called with the tiles already shifted for step jt)
-    auto hand_over = [&](int jt) {
-        const int q = jt & 3;
-        if ((li >> 2) == q) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sS[16 * wave + lq + 4 * r][li & 3] = a[0][r];
-        }
-        if (jt + 1 < IB / 4) {
-            const int jjn = (jt + 1) >> 2, qn = (jt + 1) & 3;
-            if (wave == jjn && (li >> 2) == qn) sN[lq][li & 3] = qn == 0 ? a[1][0] : sel4(a[0], qn);   // (qn == 0: the next block's tile)
-        }
-    };
-    double wi[4][4], dn[4][4];
-    int bad_at = 0;
-    auto factor_publish = [&](int jt, double (&d)[4][4]) {      // d: lower part of diagonal tile jt -> L_dd, inverse; publish both
-        double rk[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const double piv = d[k][k];
-            if (bad_at == 0 && !(piv > 0.0)) bad_at = 4 * jt + k + 1;                // also catches NaN; reported at the end
-            const double rinv = fast_rsqrt(piv);
-            rk[k] = rinv;
-            d[k][k] = piv * rinv;
-#pragma unroll
-            for (int r = k + 1; r < 4; ++r) d[r][k] *= rinv;
-#pragma unroll
-            for (int c = k + 1; c < 4; ++c)
-#pragma unroll
-                for (int r = c; r < 4; ++r) d[r][c] = fma(-d[r][k], d[c][k], d[r][c]);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (i < k) { wi[i][k] = 0.0; continue; }
-                if (i == k) { wi[i][k] = rk[i]; continue; }
-                double sacc = 0.0;
-#pragma unroll
-                for (int m = k; m < i; ++m) sacc = fma(d[i][m], wi[m][k], sacc);
-                wi[i][k] = -rk[i] * sacc;
-            }
-        }
-        struct alignas(16) D2 { double v[2]; };
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int k = 0; k + 1 <= i; k += 2) {
-                *reinterpret_cast<D2 *>(&sWi[jt & 1][i][k]) = D2{{wi[i][k], wi[i][k + 1]}};
-                *reinterpret_cast<D2 *>(&sDd[jt & 1][i][k]) = D2{{d[i][k], (k + 1 <= i) ? d[i][k + 1] : 0.0}};
-            }
-            if ((i & 1) == 0) { sWi[jt & 1][i][i] = wi[i][i]; sDd[jt & 1][i][i] = d[i][i]; }
-        }
-    };
-    // ---- prologue: strip 0 and tile 1 to LDS; the pivot lane factors tile 0 ----
-    hand_over(0);
-    __syncthreads();
-    if (pivot) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            double row[4];
-            load_frag32<double>(&sS[i][0], row);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) dn[i][k] = (k <= i) ? row[k] : 0.0;
-        }
-        factor_publish(0, dn);
-    }
-    double al_prev = 0.0;
-#pragma unroll 1
-    for (int jt = 0; jt < IB / 4; ++jt) {
-        const int c0 = 4 * jt, jj0 = jt >> 2, q = jt & 3;
-        const int jjp = (jt - 1) >> 2, qp = (jt - 1) & 3;        // the step before (jt > 0)
-        __syncthreads();                                          // B1: sS = raw strip jt, sN = raw tile jt + 1, inverse jt published
-        if (stamps && jt == 9 && threadIdx.x == 0) stamps[0] = __builtin_amdgcn_s_memtime();
-        if (stamps && jt == 10 && threadIdx.x == 0) stamps[7] = __builtin_amdgcn_s_memtime();
-        // ---- pivot lane: D(jt + 1) = N - (S Wi^T)(S Wi^T)^T ----
-        if (pivot && jt + 1 < IB / 4) {
-            double S[4][4], ls[4][4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                load_frag32<double>(&sS[c0 + 4 + i][0], S[i]);
-                double row[4];
-                load_frag32<double>(&sN[i][0], row);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) dn[i][k] = (k <= i) ? row[k] : 0.0;
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    double v = S[r][0] * wi[c][0];
-#pragma unroll
-                    for (int k = 1; k <= c; ++k) v = fma(S[r][k], wi[c][k], v);
-                    ls[r][c] = v;
+                    const int row = 16 * jj0 + lq + 4 * r, col = 16 * tj + li;   // U[row][col] = L[col][row]
+                    if (row <= col) sM[col][row] = T[w1_tix(jj0, tj)][r];
                 }
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int c = 0; c <= r; ++c) {
-                    double v = dn[r][c];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v = fma(-ls[r][k], ls[c][k], v);
-                    dn[r][c] = v;
-                }
-        }
-        if (stamps && jt == 9 && pivot) stamps[1] = __builtin_amdgcn_s_memtime();
-        // ---- waves: X rows of the step before (B operand in place in the registers) ----
-        if (jt > 0 && wave == jjp) {
-            const double wprev = (li < 4) ? sWi[(jt - 1) & 1][li][lq] : 0.0;
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                if (jj > jjp) continue;                         // X is lower triangular: nothing to the right of the step
-                const v4 u = M::mfma(wprev, sel4(x[jj], qp), zero);
-                put4(x[jj], qp, u[0]);
-                sXd[lq][16 * jj + li] = u[0];
-            }
-        }
-        // ---- S3: new strip = strip . inv(L_dd)^T;  S4: to LDS (the diagonal rows take L_dd itself) ----
-        const bool active = wave >= jj0;                          // (a wave whose rows all lie above the step only keeps the barriers)
-        if (active) {
-            const double winv = (li < 4) ? sWi[jt & 1][li][lq] : 0.0;   // B operand: B[k][n] = Winv[n][k]
-            const v4 t = M::mfma(sS[16 * wave + li][lq], winv, zero);
-            if (li < 4) {
+            for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * wave + lq + 4 * r;
-                    const bool diag = row >= c0 && row < c0 + 4;
-                    const double ld = sDd[jt & 1][diag ? row - c0 : 0][li];
-                    sLn[row][li] = diag ? ld : t[r];
+                    const int row = 16 * jj0 + lq + 4 * r, col = 16 * tj + li;
+                    sW[row][col] = (tj <= jj0 && col <= row) ? Y[w1_tix(tj <= jj0 ? tj : jj0, jj0)][r] : 0.0;
                 }
-            }
         }
-        if (stamps && jt == 9 && threadIdx.x == 192) stamps[2] = __builtin_amdgcn_s_memtime();
-        __syncthreads();                                          // B2: sLn, sXd are in
-        if (stamps && jt == 9 && threadIdx.x == 0) stamps[3] = __builtin_amdgcn_s_memtime();
-        // ---- pivot lane: factor + invert tile jt + 1, publish (read at the next B1) ----
-        if (pivot && jt + 1 < IB / 4) factor_publish(jt + 1, dn);
-        if (stamps && jt == 9 && pivot) stamps[4] = __builtin_amdgcn_s_memtime();
-        // ---- S5 ----
-        double al = 0.0;
-        if (active) {
-            if ((li >> 2) == q) {
+        if (jt + 1 == IB / 4) break;
+        // ---- rank-4 updates: T(ti, tj) -= U_s(ti)^T U_s(tj),  Y(ti, tj') -= U_s(ti)^T Y_s(tj')  (rows right of the strip only) ----
+        double au[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) a[0][r] = sLn[16 * wave + lq + 4 * r][li & 3];
-            }
-            const int arow = 16 * wave + li;
-            al = (arow > c0 + 3) ? -sLn[arow][lq] : 0.0;          // rows at or above the step: no update
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {                          // a[t]: column tile jj0 + t
-                if (jj0 + t <= wave) {                              // (tiles above the diagonal: never read)
-                    const int bcol = 16 * (jj0 + t) + li;
-                    const double bl = (bcol > c0 + 3) ? sLn[bcol][lq] : 0.0;      // columns up to the step are final
-                    a[t] = M::mfma(al, bl, a[t]);
-                }
-            }
-            if (q == 3) {                                           // the block's tile is final: keep it, shift the tiles left
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) out[t][r] = (t == jj0) ? a[0][r] : out[t][r];
-                }
-                a[0] = a[1]; a[1] = a[2]; a[2] = a[3];
-            }
+        for (int ti = jj0; ti < 4; ++ti) {
+            const double v = T[w1_tix(jj0, ti)][q];
+            au[ti] = (16 * ti + li > c0 + 3) ? -v : 0.0;           // A[i][k] = -U[c0 + k][16 ti + i]; columns up to the strip: final
         }
-        if (jt + 1 < IB / 4 && wave >= ((jt + 1) >> 2)) hand_over(jt + 1);   // raw strip jt + 1 (and raw tile jt + 2) for the next step
-        if (jt > 0 && wave >= jjp) {                              // (al_prev is zero for a wave above step jt - 1)
+        // (the tile that holds the next diagonal 4 x 4 first: the next step's pivots depend on it alone)
+        const int jn = (jt + 1) >> 2;
+        T[w1_tix(jn, jn)] = M::mfma(au[jn], T[w1_tix(jj0, jn)][q], T[w1_tix(jn, jn)]);
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-                if (jj <= jjp) x[jj] = M::mfma(al_prev, sXd[lq][16 * jj + li], x[jj]);
-        }
-        al_prev = al;
-        if (stamps && jt == 9 && threadIdx.x == 192) stamps[5] = __builtin_amdgcn_s_memtime();
+        for (int ti = jj0; ti < 4; ++ti)
+#pragma unroll
+            for (int tj = ti; tj < 4; ++tj) {
+                if (ti == jn && tj == jn) continue;
+                if (16 * ti + 15 <= c0 + 3) continue;              // (never: ti >= jj0)
+                T[w1_tix(ti, tj)] = M::mfma(au[ti], T[w1_tix(jj0, tj)][q], T[w1_tix(ti, tj)]);
+            }
+#pragma unroll
+        for (int ti = jj0; ti < 4; ++ti)
+#pragma unroll
+            for (int tj = 0; tj <= jj0; ++tj)
+                Y[w1_tix(tj, ti)] = M::mfma(au[ti], Y[w1_tix(tj, jj0)][q], Y[w1_tix(tj, ti)]);
     }
-    if (pivot && bad_at != 0) atomicCAS(info, 0, (int)(j0 + bad_at));        // first failure wins
-#pragma unroll
-    for (int t = 0; t < 4; ++t) a[t] = out[t];
-    // the last step's X rows (its rank-4 update has no rows below it)
-    if (wave == 3) {
-        const double wprev = (li < 4) ? sWi[1][li][lq] : 0.0;
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const v4 u = M::mfma(wprev, x[jj][3], zero);
-            x[jj][3] = u[0];
-        }
-    }
+    if (stamps && lane == 0) { stamps[16 + 16] = __builtin_amdgcn_s_memrealtime(); stamps[32 + 16] = __builtin_amdgcn_s_memtime(); }
+    if (lane == 0 && bad_at != 0) atomicCAS(info, 0, (int)(j0 + bad_at));          // first failure wins
 }
 
 

@@ -170,6 +170,34 @@ __device__ __forceinline__ void res_stage(const T *__restrict__ src, T (*dst)[PT
     }
 }
 
+// the same in two halves -- global -> registers, registers -> LDS -- so that the next block's loads can be in flight under
+// the current block's products (the one-wave-leaf instantiation has the registers for it)
+template <typename T> struct StageRegs {
+    static constexpr int E = 16 / (int)sizeof(T), RPW = 256 / (IB / E), PER = IB / RPW;
+    typedef uint4v Q;                                           // (a vector type, not a struct of words: stays in registers)
+    Q q[PER];
+};
+template <typename T>
+__device__ __forceinline__ void res_stage_rows_load(const T *__restrict__ src, int lda, int nvalid, StageRegs<T> &rg)
+{
+    typedef StageRegs<T> S;
+    const int row0 = threadIdx.x / (IB / S::E), col = (threadIdx.x % (IB / S::E)) * S::E;
+#pragma unroll
+    for (int i = 0; i < S::PER; ++i) {
+        const int row = row0 + S::RPW * i;
+        const int rr = row < nvalid ? row : nvalid - 1;
+        rg.q[i] = *reinterpret_cast<const typename S::Q *>(src + (unsigned)(rr * lda + col));
+    }
+}
+template <typename T, int PT>
+__device__ __forceinline__ void res_stage_rows_store(const StageRegs<T> &rg, T (*dst)[PT])
+{
+    typedef StageRegs<T> S;
+    const int row0 = threadIdx.x / (IB / S::E), col = (threadIdx.x % (IB / S::E)) * S::E;
+#pragma unroll
+    for (int i = 0; i < S::PER; ++i) *reinterpret_cast<typename S::Q *>(&dst[row0 + S::RPW * i][col]) = rg.q[i];
+}
+
 // stage 64 rows x 64 columns of the matrix (rows lda apart, 16-byte aligned; rows >= nvalid repeat the last valid one)
 // into LDS.  Offsets inside the block fit 32 bits whatever the matrix size.
 template <typename T, int PT>
@@ -213,7 +241,7 @@ __device__ __forceinline__ void res_prod(const T (*sa)[PT], const T (*sb)[PT], t
 // unrolled MFMA sweep costs the fp32 kernel 58 VGPRs, i.e. a third workgroup per CU, which tall panels miss more than
 // they gain from the faster leaf)
 template <typename T, bool LEAF_MFMA, int LV = 1>
-__global__ __launch_bounds__(256, 2) void panel_res_kernel(T *__restrict__ A, int64_t lda, int64_t n, int64_t r0, int64_t c0,
+__global__ __launch_bounds__(256, LV == 4 ? 1 : 2) void panel_res_kernel(T *__restrict__ A, int64_t lda, int64_t n, int64_t r0, int64_t c0,
                                                            int nsteps, int *__restrict__ info, T *__restrict__ pub,
                                                            int *__restrict__ flags, int serial, int64_t sM, int kpre,
                                                            unsigned long long *__restrict__ stamps, int w0, int strict)
@@ -268,10 +296,20 @@ __global__ __launch_bounds__(256, 2) void panel_res_kernel(T *__restrict__ A, in
     if (kpre > 0) {
         const int nvalid = (int)(n - (r0 + (int64_t)w * IB) < IB ? n - (r0 + (int64_t)w * IB) : IB);
         const T *mine = A + (r0 + (int64_t)w * IB) * lda;      // my 64 rows, column 0
+        // (LV == 4: the loads of my rows' NEXT 64 columns are issued before this block's products and land under them:
+        //  workgroup 0's four short products then follow each other at the matrix pipe's pace -- they are the start of the chain)
+        constexpr bool PREFETCH = LV == 4;
+        StageRegs<T> nxt;
+        if constexpr (PREFETCH) res_stage_rows_load<T>(mine + (c0 - (int64_t)IB * kpre), (int)lda, nvalid, nxt);
         for (int kc = 0; kc < kpre; ++kc) {
             const int64_t pc = c0 - (int64_t)IB * (kpre - kc);
             __syncthreads();
-            res_stage_rows<T, PT>(mine + pc, (int)lda, nvalid, sA);
+            if constexpr (PREFETCH) {
+                res_stage_rows_store<T, PT>(nxt, sA);
+                if (kc + 1 < kpre) res_stage_rows_load<T>(mine + pc + IB, (int)lda, nvalid, nxt);
+            } else {
+                res_stage_rows<T, PT>(mine + pc, (int)lda, nvalid, sA);
+            }
 #pragma unroll
             for (int c = 0; c < RES_MAXSTEPS; ++c) {
                 if (c >= nsteps || (future_diag && c > w)) break;
@@ -422,6 +460,36 @@ __global__ __launch_bounds__(256, 2) void panel_res_kernel(T *__restrict__ A, in
             res_prod<T, PT, true>(sA, sB, acc[c], wave, li, lq);
         }
     }
+    if constexpr (LEAF_MFMA && LV == 4 && sizeof(T) == 8) {
+        if (dg_step >= 0) {
+            // ---- the diagonal block: the ONE-WAVE leaf (gpx_leaf.h, factor64_wave): the block is in sA by rows; wave 0
+            // factors it without touching LDS or a barrier, leaves L in sA and W = inv(L) in sB ----
+            const int j = dg_step;
+            __syncthreads();                                      // sA is complete
+            if (wave == 0)
+                factor64_wave<PT>(sA, sB, r0 + (int64_t)IB * j, info, lane, (stamps && w == 0 && blockIdx.y == 0) ? stamps + 2040 * 16 : nullptr);
+            __syncthreads();
+            // publish W: its 10 lower 16 x 16 tiles, 16-byte agent-scope stores (what res_stage_w loads)
+            T *W = pub + (int64_t)j * (IB * IB);
+            constexpr int UPT = 16 * 8, TOTAL = 10 * UPT;           // 16-byte units per tile (16 rows x 8), lower tiles
+#pragma unroll
+            for (int i = 0; i < (TOTAL + 255) / 256; ++i) {
+                const int u = tid + 256 * i;
+                if (u < TOTAL) {
+                    const int tile = u / UPT, wq = u % UPT;
+                    const int ti = tile < 1 ? 0 : tile < 3 ? 1 : tile < 6 ? 2 : 3, tj = tile - ti * (ti + 1) / 2;
+                    const int row = 16 * ti + wq / 8, col = 16 * tj + (wq % 8) * 2;
+                    pub_store16(W + row * IB + col, *reinterpret_cast<const uint4v *>(&sB[row][col]));
+                }
+            }
+            res_raise(flags + j, serial, strict);
+#pragma unroll
+            for (int i = 0; i < IB * IB / 256; ++i) {
+                const int idx = tid + 256 * i, row = idx / IB, col = idx % IB;
+                if (col <= row) A[(r0 + (int64_t)IB * j + row) * lda + c0 + IB * j + col] = sA[row][col];
+            }
+        }
+    } else
     if constexpr (LEAF_MFMA) if (dg_step >= 0) {
         // ---- the diagonal block: the leaf on the MFMA pipe (gpx_leaf.h), in place in the accumulator tiles ----
         const int j = dg_step;
@@ -430,12 +498,6 @@ __global__ __launch_bounds__(256, 2) void panel_res_kernel(T *__restrict__ A, in
         for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
             for (int r = 0; r < 4; ++r) xw[jj][r] = (16 * wave + M::row(lane, r) == 16 * jj + li) ? (T)1 : (T)0;
-        // LV = 2 (fp64): the leaf whose pivot lane runs ahead of the strip (gpx_leaf.h, factor64_mfma2)
-        if constexpr (LV == 3 && sizeof(T) == 8)
-            factor64_mfma3(dg, xw, r0 + (int64_t)IB * j, info, wave, lane, (stamps && w == 0 && blockIdx.y == 0) ? stamps + 2040 * 16 : nullptr);
-        else if constexpr (LV == 2 && sizeof(T) == 8)
-            factor64_mfma2(dg, xw, r0 + (int64_t)IB * j, info, wave, lane, (stamps && w == 0 && blockIdx.y == 0) ? stamps + 2040 * 16 : nullptr);
-        else
             LeafMfma<T>::run(dg, xw, r0 + (int64_t)IB * j, info, wave, lane, (stamps && w == 0 && blockIdx.y == 0) ? stamps + 2040 * 16 : nullptr);
         T *W = pub + (int64_t)j * (IB * IB);
 #pragma unroll
@@ -568,40 +630,40 @@ static int panel_res_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int
     // update of the step before (64 x n = 8192: 0.213 -> 0.199 s with two parts, 16 x: 55.0 -> 54.6 ms, 8 x: 29.4 -> 30.8)
     const int64_t nmat = bt ? bt->count : 1;
     const bool two_part = nmat > 1 ? rows * nmat > env_i64("GPX_POTRF_TWO_PART_BATCH", 98304) : rows > two_part_rows;
-    // fp64 leaf (gpx_leaf.h): GPX_LEAF = 3 (default) the rolled loop with the pivot lane ahead of the strip, 2 the same
-    // schedule fully unrolled, 1 the round-3 leaf
-    const int64_t leaf = F64 ? env_i64("GPX_LEAF", 3) : 1;
-    const bool v3 = leaf == 3, v2 = leaf == 2;
+    // fp64 leaf (gpx_leaf.h): GPX_LEAF = 4 the one-wave leaf (default for single matrices), 1 the round-3 leaf on four waves.
+    // (The one-wave leaf's instantiation runs ONE workgroup per CU -- 355 registers a lane: its 20 accumulator tiles -- which a
+    //  single matrix's panels never notice (at most 256 workgroups per launch) but a lock-step batch's would: batches keep 1.)
+    const int64_t excl_rows = env_i64("GPX_PANEL_EXCL_ROWS", 0);
+    const bool v4 = F64 && env_i64("GPX_LEAF", (!bt && rows <= excl_rows) ? 4 : 1) == 4;
+    // A CU of its own for every workgroup of a SHORT panel (one-wave-leaf instantiation, single matrix).  Per-step stamps
+    // of every leaf variant say the same thing: ~0.9 us a step while the workgroup has its CU to itself, 3 - 4.5 us while
+    // workgroups of the trailing update share it (matrix pipe, issue slots).  The instantiation already holds 355 registers
+    // a lane, which keeps the 128 x 128 update kernel (234) off its CUs; GPX_PANEL_PAD_LDS bytes of unused dynamic LDS on
+    // top of its 74 KB keep the 128 x 64 one (49 KB of the CU's 160) off too.  Worth it only while the panel has few
+    // workgroups -- each takes a whole CU from the update for as long as the chain runs.
+    size_t pad_lds = 0;
+    if (v4 && !bt && rows <= excl_rows) {
+        pad_lds = (size_t)env_i64("GPX_PANEL_PAD_LDS", 38 * 1024);
+        GPX_TRY(set_max_lds((const void *)panel_res_kernel<T, true, F64 ? 4 : 1>, (int)pad_lds));
+    }
+#define GPX_PANEL_LAUNCH(KERNEL, GRID, W0)                                                                                      \
+    hipLaunchKernelGGL((KERNEL), GRID, dim3(256), pad_lds, st, A, lda, n, r0, c0, nsteps, info_dev, (T *)pub, flags, serial,   \
+                       bt ? bt->sA : (int64_t)0, (int)(kpre / IB), stamps, W0, strict)
     if (two_part && (int64_t)grid.x > nsteps) {
         const bool mfma_chain = F64 || env_i64("GPX_LEAF_MFMA_F32_ROWS", 16384) > 0;
-        if (v3)
-            hipLaunchKernelGGL((panel_res_kernel<T, true, F64 ? 3 : 1>), dim3((unsigned)nsteps, grid.y), dim3(256), 0, st, A, lda, n, r0, c0, nsteps,
-                               info_dev, (T *)pub, flags, serial, bt ? bt->sA : (int64_t)0, (int)(kpre / IB), stamps, 0, strict);
-        else if (v2)
-            hipLaunchKernelGGL((panel_res_kernel<T, true, F64 ? 2 : 1>), dim3((unsigned)nsteps, grid.y), dim3(256), 0, st, A, lda, n, r0, c0, nsteps,
-                               info_dev, (T *)pub, flags, serial, bt ? bt->sA : (int64_t)0, (int)(kpre / IB), stamps, 0, strict);
-        else if (mfma_chain)
-            hipLaunchKernelGGL((panel_res_kernel<T, true>), dim3((unsigned)nsteps, grid.y), dim3(256), 0, st, A, lda, n, r0, c0, nsteps,
-                               info_dev, (T *)pub, flags, serial, bt ? bt->sA : (int64_t)0, (int)(kpre / IB), stamps, 0, strict);
-        else
-            hipLaunchKernelGGL((panel_res_kernel<T, F64>), dim3((unsigned)nsteps, grid.y), dim3(256), 0, st, A, lda, n, r0, c0, nsteps,
-                               info_dev, (T *)pub, flags, serial, bt ? bt->sA : (int64_t)0, (int)(kpre / IB), stamps, 0, strict);
-        // (the rows never run a leaf: the lean instantiation)
-        hipLaunchKernelGGL((panel_res_kernel<T, F64>), dim3(grid.x - (unsigned)nsteps, grid.y), dim3(256), 0, st, A, lda, n, r0, c0, nsteps,
-                           info_dev, (T *)pub, flags, serial, bt ? bt->sA : (int64_t)0, (int)(kpre / IB), stamps, nsteps, strict);
-    } else if (v3) {
-        hipLaunchKernelGGL((panel_res_kernel<T, true, F64 ? 3 : 1>), grid, dim3(256), 0, st, A, lda, n, r0, c0, nsteps, info_dev, (T *)pub,
-                           flags, serial, bt ? bt->sA : (int64_t)0, (int)(kpre / IB), stamps, 0, strict);
-    } else if (v2) {
-        hipLaunchKernelGGL((panel_res_kernel<T, true, F64 ? 2 : 1>), grid, dim3(256), 0, st, A, lda, n, r0, c0, nsteps, info_dev, (T *)pub,
-                           flags, serial, bt ? bt->sA : (int64_t)0, (int)(kpre / IB), stamps, 0, strict);
+        const dim3 gdiag((unsigned)nsteps, grid.y), grows(grid.x - (unsigned)nsteps, grid.y);
+        if (v4) GPX_PANEL_LAUNCH((panel_res_kernel<T, true, F64 ? 4 : 1>), gdiag, 0);
+        else if (mfma_chain) GPX_PANEL_LAUNCH((panel_res_kernel<T, true>), gdiag, 0);
+        else GPX_PANEL_LAUNCH((panel_res_kernel<T, F64>), gdiag, 0);
+        GPX_PANEL_LAUNCH((panel_res_kernel<T, F64>), grows, nsteps);          // (the rows never run a leaf: the lean instantiation)
+    } else if (v4) {
+        GPX_PANEL_LAUNCH((panel_res_kernel<T, true, F64 ? 4 : 1>), grid, 0);
     } else if (mfma_single) {
-        hipLaunchKernelGGL((panel_res_kernel<T, true>), grid, dim3(256), 0, st, A, lda, n, r0, c0, nsteps, info_dev, (T *)pub,
-                           flags, serial, bt ? bt->sA : (int64_t)0, (int)(kpre / IB), stamps, 0, strict);
+        GPX_PANEL_LAUNCH((panel_res_kernel<T, true>), grid, 0);
     } else {
-        hipLaunchKernelGGL((panel_res_kernel<T, F64>), grid, dim3(256), 0, st, A, lda, n, r0, c0, nsteps, info_dev, (T *)pub,
-                           flags, serial, bt ? bt->sA : (int64_t)0, (int)(kpre / IB), stamps, 0, strict);
+        GPX_PANEL_LAUNCH((panel_res_kernel<T, F64>), grid, 0);
     }
+#undef GPX_PANEL_LAUNCH
     GPX_LAUNCH_CHECK();
     if (record_after) GPX_HIP(hipEventRecord(record_after, st));
     scr->last = st; scr->have_last = true; scr->last_on_side = (side != nullptr && st == side);

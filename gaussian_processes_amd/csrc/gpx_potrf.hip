@@ -286,6 +286,11 @@ static int leaf_scratch(size_t bytes, void **out)
 // Three further panel routes were built, measured slower and removed again in round 3 (DESIGN section 3.2 keeps the
 // measurements): "tall" (diagonal block first, inv(L11) by recursive doubling, one product for all rows below),
 // "fused" (one launch per 64 columns, left-looking) and "lean" (leaf + one row kernel per 64 columns).
+// the wide panel as a blocked factorisation of its own (defined below, after the look-ahead state it uses)
+static bool panel_nested_ok(int64_t rows, int64_t r0, int64_t c0, int64_t kb, int64_t kpre, size_t es, int64_t lda, const void *base);
+static int potrf_panel_nested(int dtype, void *A, int64_t lda, int64_t n, int64_t r0, int64_t kb, int *info_dev, hipStream_t q,
+                              const Batch *bt, hipEvent_t done);
+
 template <typename T>
 static int potrf_panel_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int64_t kb, int *info_dev,
                          hipStream_t st, int dtype, const Batch *bt, int64_t kpre = 0, hipEvent_t done = nullptr)
@@ -351,6 +356,11 @@ static int potrf_panel_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, i
         if (done) GPX_HIP(hipEventRecord(done, st));
         return GPX_OK;
     }
+    // wide panels of short matrices: a blocked factorisation of their own, with its own look-ahead (round 4)
+    if (panel_nested_ok(n - r0, r0, c0, kb, kpre, sizeof(T), lda, A)) {
+        route_hit(RT_PANEL_NESTED);
+        return potrf_panel_nested(dtype, A, lda, n, r0, kb, info_dev, st, bt, done);
+    }
     const int64_t h = ((kb / IB + 1) / 2) * IB;          // left half, a multiple of 64
     GPX_TRY(potrf_panel_t<T>(A, lda, n, r0, c0, h, info_dev, st, dtype, bt));
     T *R = A + (r0 + h) * lda + c0;                       // rows below the left half's diagonal block
@@ -373,6 +383,7 @@ int potrf_panel(int dtype, void *A, int64_t lda, int64_t n, int64_t r0, int64_t 
 struct LookAhead {
     int device = -1;
     hipStream_t q = nullptr;
+    hipStream_t u = nullptr;        // the in-panel updates of a nested wide panel (potrf_panel_nested), created on first use
     // trailing-update streams that leave `reserved` CUs to the panel stream, one per reservation ever asked for.
     // They live until the owning thread ends: pooled events keep referring to the stream they were last recorded
     // on, and a factorisation that alternates between reservations (single fits: 32, small lock-step batches: 16)
@@ -421,7 +432,7 @@ static int lookahead_setup()
     GPX_HIP(hipGetDevice(&dev));
     if (g_la.device != dev) {
         g_la.drop_streams();
-        g_la.q = nullptr; g_la.ev.clear();
+        g_la.q = nullptr; g_la.u = nullptr; g_la.ev.clear();
         g_la.device = dev;
         // the panel is on the critical path of the NEXT step: give its stream the highest
         // priority so that its workgroups get the CUs that trailing-update workgroups free up
@@ -430,6 +441,71 @@ static int lookahead_setup()
         GPX_HIP(hipStreamCreateWithPriority(&g_la.q, hipStreamNonBlocking, greatest));
     }
     g_la.next = 0;
+    return GPX_OK;
+}
+
+// ---- the wide panel as a blocked factorisation of its own ------------------------------------------------------------
+// A panel of 768 / 1024 columns used to halve recursively: left half, ONE product, right half -- a chain without any
+// overlap inside the panel, which is why a wide outer block only paid above 12288 rows.  Here the wide panel (rows
+// [r0, n) x columns [r0, r0 + kb), sub-panels of `sub` = 256 columns) runs the factorisation's own schedule one level
+// down:
+//     sub-panel j on the panel stream q: ONE resident launch that first applies sub-panel j - 1 to its own columns (kpre)
+//     in-panel update U(j) on stream u:  sub-panel j applied to the panel's columns BEYOND sub-panel j + 1, K = 256
+//     sub-panel j + 1 waits for sub-panel j (stream order) and for U(j - 1) (event), U(j) for sub-panel j and U(j - 1)
+// -- the resident kernels of consecutive sub-panels follow each other directly, the small in-panel products run beside them.
+// With it the OUTER block can be 1024 wide while many rows are left, so that the bulk of the trailing update runs at
+// K = 1024 (the MFMA kernel: 62 - 64 TF/s) instead of K = 256 (37 - 55 TF/s: C re-read and re-written every 256
+// columns, a tile as long as its own prologue + epilogue) -- the two-level scheme: near updates per sub-panel inside the
+// 1024-column window, the far trailing matrix once per four sub-panels.  The outer loop of potrf() needs no change: its
+// one-panel look-ahead already updates the NEXT block column first (the far update's first 1024 columns), starts this
+// panel, and applies the rest underneath it.
+static thread_local bool g_in_potrf = false;    // potrf() is running on this thread: its look-ahead state (streams, event pool) is set up
+static bool panel_nested_ok(int64_t rows, int64_t r0, int64_t c0, int64_t kb, int64_t kpre, size_t es, int64_t lda, const void *base)
+{
+    const int64_t sub = panel_res_max();
+    if (!g_in_potrf || env_i64("GPX_POTRF_NESTED", 0) == 0) return false;
+    // (r0 != c0: a rank's local block column of the multi-GPU schedule -- the in-panel updates' tile map assumes global columns)
+    return r0 == c0 && kpre == 0 && sub == 256 && kb % sub == 0 && kb / sub >= 3 && rows <= env_i64("GPX_POTRF_NESTED_ROWS", 16384) &&
+           panel_res_fold(rows, sub, sub, es, lda, base);
+}
+
+static int potrf_panel_nested(int dtype, void *A, int64_t lda, int64_t n, int64_t r0, int64_t kb, int *info_dev, hipStream_t q,
+                              const Batch *bt, hipEvent_t done)
+{
+    const int64_t sub = panel_res_max(), ns = kb / sub, cend = r0 + kb;
+    const size_t es = esize(dtype);
+    auto at = [&](int64_t r, int64_t c) { return (char *)A + (r * lda + c) * es; };
+    if (!g_la.u) {
+        int least = 0, greatest = 0;
+        GPX_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        GPX_HIP(hipStreamCreateWithPriority(&g_la.u, hipStreamNonBlocking, greatest));
+    }
+    hipStream_t u = g_la.u;
+    hipEvent_t eu_prev = nullptr;                                 // U(j - 1) done
+    for (int64_t j = 0; j < ns; ++j) {
+        const int64_t rj = r0 + j * sub;
+        // sub-panel j: needs sub-panel j - 1 (stream order; its update of these columns is folded into this launch) and
+        // U(j - 2) -- the last in-panel update that touched these columns (U(j - 1) starts beyond them)
+        hipEvent_t ep;
+        GPX_TRY(g_la.get(&ep));
+        GPX_TRY(potrf_panel_res(dtype, A, lda, n, rj, rj, sub, info_dev, q, bt, j > 0 ? sub : 0, j + 1 == ns ? done : ep));
+        route_hit(RT_PANEL_RES);
+        if (j + 1 == ns) break;
+        // U(j): columns [rj + 2 sub, cend), rows from rj + sub
+        if (rj + 2 * sub < cend) {
+            GPX_HIP(hipStreamWaitEvent(u, ep, 0));
+            GPX_TRY(syrk_bc(dtype, n, rj + sub, A, lda, rj + 2 * sub, cend, at(rj, rj), lda, rj, sub, sub, 1, 0, u, info_dev, bt));
+            hipEvent_t eu;
+            GPX_TRY(g_la.get(&eu));
+            GPX_HIP(hipEventRecord(eu, u));
+            // sub-panel j + 2 is the first to need U(j); sub-panel j + 1 needs U(j - 1)
+            if (eu_prev) GPX_HIP(hipStreamWaitEvent(q, eu_prev, 0));
+            eu_prev = eu;
+        } else if (eu_prev) {
+            GPX_HIP(hipStreamWaitEvent(q, eu_prev, 0));
+            eu_prev = nullptr;
+        }
+    }
     return GPX_OK;
 }
 
@@ -513,6 +589,7 @@ int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t
         return GPX_OK;
     }
     GPX_TRY(lookahead_setup());
+    struct InPotrf { InPotrf() { g_in_potrf = true; } ~InPotrf() { g_in_potrf = false; } } in_potrf__;
     hipStream_t q = g_la.q;
     hipEvent_t e, ep;
     GPX_TRY(g_la.get(&e));

@@ -161,19 +161,19 @@ def test_soak_repeat_fits_are_bitwise_identical(monkeypatch, n, dtype):
 
 # ------------------------------------------------- the round-4 leaf (pivot lane ahead) --
 @pytest.mark.parametrize("N", [64, 130, 700, 1990, 4171])
-def test_leaf_with_pivot_lane_ahead_vs_round3_leaf_and_oracle(monkeypatch, N):
-    """The fp64 resident panel kernel has three leaves (gpx_leaf.h): factor64_mfma3 (default: the pivot lane forms, factors
-    and inverts the NEXT 4 x 4 diagonal tile while the waves finish the current step -- two barriers a step -- as a ROLLED
-    loop of 16 steps that stays in the instruction cache), factor64_mfma2 (GPX_LEAF=2: the same schedule fully unrolled)
-    and the round-3 factor64_mfma (GPX_LEAF=1: three barriers, everybody waits for the pivot lane).  All against the
-    oracle's factor, log_lh, alpha and inverse; 3 and 2 run the same arithmetic in the same order (bitwise equal), 1 rounds
-    the pivot tile's strip rows differently (equal to ~1e-13)."""
+def test_fp64_leaves_vs_oracle_and_each_other(monkeypatch, N):
+    """The fp64 resident panel kernel has two leaves for the 64 x 64 diagonal block (gpx_leaf.h, GPX_LEAF):
+      4 (default for single matrices)  factor64_wave: ONE wave factors the TRANSPOSE held in accumulator tiles -- a strip's
+                   registers serve as MFMA A and B operands as they are -- without LDS or barriers inside its 16 steps;
+      1            factor64_mfma (round 3; lock-step batches): four waves, three barriers and five LDS round trips a step.
+    Both against the oracle's factor, log_lh, alpha and explicit inverse (W = inv(L_jj) of every leaf feeds it), and against
+    each other (they differ in rounding only)."""
     d = 3
     X, y, Xo = orc.synth_inputs(N, d, 16)
     h, w, s = 1.0, 0.5 * np.sqrt(d), 0.9
     o = orc.OracleGP("gaussian", (h, w), X, y, s)
     out = {}
-    for label, env in (("v3", None), ("v2", "2"), ("v1", "1")):
+    for label, env in (("one_wave", None), ("four_waves", "1")):
         if env is None:
             monkeypatch.delenv("GPX_LEAF", raising=False)
         else:
@@ -183,12 +183,57 @@ def test_leaf_with_pivot_lane_ahead_vs_round3_leaf_and_oracle(monkeypatch, N):
         np.testing.assert_allclose(out[label][0], o.log_lh, rtol=1e-10, err_msg=label)
         np.testing.assert_allclose(np.tril(out[label][1]), o.Lxx, rtol=1e-9, atol=1e-12, err_msg=label)
         np.testing.assert_allclose(out[label][2], o.inv_Kxx_y, rtol=1e-8, atol=1e-11, err_msg=label)
-        if N <= 700:                                           # W = inv(L_jj) of the leaves feeds the explicit inverse
+        if N <= 700:
             np.testing.assert_allclose(out[label][3], o.inv_Kxx, rtol=1e-7, atol=1e-10, err_msg=label)
     monkeypatch.delenv("GPX_LEAF", raising=False)
-    assert out["v3"][0] == out["v2"][0]
-    assert np.array_equal(np.tril(out["v3"][1]), np.tril(out["v2"][1]))
-    np.testing.assert_allclose(np.tril(out["v3"][1]), np.tril(out["v1"][1]), rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(np.tril(out["one_wave"][1]), np.tril(out["four_waves"][1]), rtol=1e-11, atol=1e-13)
+    # a lock-step batch may take the one-wave leaf too (GPX_LEAF=4 forces it): same values
+    from gaussian_processes_amd import mlii
+    thetas = np.array([[h, w, s], [0.8, 1.1, 1.2]])
+    b1 = mlii.log_lh_batch(X, y, thetas)
+    monkeypatch.setenv("GPX_LEAF", "4")
+    b4 = mlii.log_lh_batch(X, y, thetas)
+    monkeypatch.delenv("GPX_LEAF", raising=False)
+    np.testing.assert_allclose(b1[0], o.log_lh, rtol=1e-10)
+    np.testing.assert_allclose(b4, b1, rtol=1e-12)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("N,nb", [(4700, "1024"), (3072, "1024"), (2400, "768"), (5120 + 37, "1024")])
+def test_nested_wide_panel_vs_recursive_halving_and_oracle(monkeypatch, dtype, N, nb):
+    """A 768 / 1024-wide panel is a blocked factorisation of its own (potrf_panel_nested: sub-panels of 256 in resident
+    launches that follow each other on the panel stream, in-panel updates beside them on a stream of their own) instead of
+    halving recursively (GPX_POTRF_NESTED=0).  Both against the oracle and each other: ragged last block (takes the
+    halving route), three and four sub-panels, the rider row, a lock-step batch."""
+    from gaussian_processes_amd import mlii
+    d = 3
+    X, y, Xo = orc.synth_inputs(N, d, 16)
+    h, w, s = 1.0, 0.5 * np.sqrt(d), 0.9
+    o = orc.OracleGP("gaussian", (h, w), X, y, s)
+    monkeypatch.setenv("GPX_POTRF_NB", nb)
+    thetas = np.array([[h, w, s], [0.8, 1.1, 1.2]])
+    out = {}
+    for label, env in (("nested", None), ("halving", "0")):
+        if env is None:
+            monkeypatch.delenv("GPX_POTRF_NESTED", raising=False)
+        else:
+            monkeypatch.setenv("GPX_POTRF_NESTED", env)
+        _lib.route_reset()
+        g = gp.GP(gp.GaussianKernel(h, w), X, y, s=s, dtype=dtype)
+        llh = float(g.log_lh)
+        nn = _lib.route_count(_lib.ROUTE_PANEL_NESTED)
+        assert (nn > 0) if env is None else (nn == 0), (label, nn)
+        out[label] = (llh, np.array(g.Lxx, dtype=np.float64), np.array(g.inv_Kxx_y, dtype=np.float64),
+                      mlii.log_lh_batch(X, y, thetas, dtype=dtype) if N <= 4700 else None)
+    f64 = dtype == "float64"
+    for label, (llh, L, alpha, batch) in out.items():
+        np.testing.assert_allclose(llh, o.log_lh, rtol=1e-10 if f64 else 1e-4, err_msg=label)
+        np.testing.assert_allclose(np.tril(L), o.Lxx, err_msg=label, **(dict(rtol=1e-9, atol=1e-12) if f64 else dict(rtol=2e-3, atol=2e-4)))
+        np.testing.assert_allclose(alpha, o.inv_Kxx_y, err_msg=label, **(dict(rtol=1e-8, atol=1e-11) if f64 else dict(rtol=2e-3, atol=2e-4)))
+        if batch is not None:
+            np.testing.assert_allclose(batch[0], o.log_lh, rtol=1e-10 if f64 else 1e-4, err_msg=label)
+    np.testing.assert_allclose(np.tril(out["nested"][1]), np.tril(out["halving"][1]),
+                               **(dict(rtol=1e-10, atol=1e-13) if f64 else dict(rtol=1e-3, atol=1e-4)))
 
 
 # ------------------------------------- the reference's property checks, seeded stream --

@@ -34,14 +34,21 @@ for w in live[:4]:
     r = s[w]
     if r[8]: print("  wg %d: %s" % (w, "  ".join("%7.1f" % ((r[k] - t0) / 100.0) for k in range(8, 13))))
 ls = st.to_host().reshape(-1, 16).astype(np.int64)[2040]
-if ls[0] and os.environ.get("GPX_LEAF", "3") == "1":
+if ls[0] and os.environ.get("GPX_LEAF", "4") == "1":
     print("MFMA leaf, step 9 of workgroup 0 (s_memtime cycles): S2 pivot %d, wait %d, S3+S4 %d, wait %d, S5 %d; whole step %d"
           % (ls[1] - ls[0], ls[2] - ls[1], ls[3] - ls[2], ls[4] - ls[3], ls[5] - ls[4], ls[6] - ls[5]))
-elif ls[0]:
+elif ls[0] and os.environ.get("GPX_LEAF", "4") in ("2", "3"):
     # factor64_mfma2: [0] B1 passed, [1] pivot lane has D(jt+1), [2] wave 3 done with S3 + S4, [3] B2 passed, [4] pivot lane has
     # published the next inverse, [5] wave 3 done with S5 + hand-over, [6] the same point one step later (thread 0)
     print("MFMA leaf v2, step 9 of workgroup 0 (s_memtime cycles after B1): pivot D(jt+1) %d | wave 3 S3+S4 %d | B2 %d | pivot factor+publish %d "
           "(+%d after B2) | wave 3 S5+hand-over %d (+%d after B2) | whole step %d"
           % (ls[1] - ls[0], ls[2] - ls[0], ls[3] - ls[0], ls[4] - ls[0], ls[4] - ls[3], ls[5] - ls[0], ls[5] - ls[3], ls[7] - ls[0]))
+lsx = st.to_host().reshape(-1, 16).astype(np.int64)[2040:2048].ravel()
+if lsx[16]:
+    rt, ct = lsx[16:32], lsx[32:48]
+    print("leaf of workgroup 0, per step (first barrier to first barrier): us " + " ".join("%.2f" % ((rt[i + 1] - rt[i]) / 100.0) for i in range(15)))
+    print("                                                     core cycles " + " ".join("%d" % (ct[i + 1] - ct[i]) for i in range(15)))
+    print("   16 steps: %.2f us from the first barrier of step 0 to that of step 15; clock %.2f GHz" % (
+        (rt[15] - rt[0]) / 100.0, (ct[15] - ct[0]) / ((rt[15] - rt[0]) * 10.0)))
 ends = (s[live, 6] - t0) / 100.0; starts = (s[live, 0] - t0) / 100.0
 print("last start %.1f us, last end %.1f us (workgroup %d)" % (starts.max(), ends.max(), live[ends.argmax()]))
