@@ -633,17 +633,22 @@ static int panel_res_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int
     // fp64 leaf (gpx_leaf.h): GPX_LEAF = 4 the one-wave leaf (default for single matrices), 1 the round-3 leaf on four waves.
     // (The one-wave leaf's instantiation runs ONE workgroup per CU -- 355 registers a lane: its 20 accumulator tiles -- which a
     //  single matrix's panels never notice (at most 256 workgroups per launch) but a lock-step batch's would: batches keep 1.)
-    const int64_t excl_rows = env_i64("GPX_PANEL_EXCL_ROWS", 0);
+    const int64_t excl_rows = env_i64("GPX_PANEL_EXCL_ROWS", 5120);
     const bool v4 = F64 && env_i64("GPX_LEAF", (!bt && rows <= excl_rows) ? 4 : 1) == 4;
-    // A CU of its own for every workgroup of a SHORT panel (one-wave-leaf instantiation, single matrix).  Per-step stamps
-    // of every leaf variant say the same thing: ~0.9 us a step while the workgroup has its CU to itself, 3 - 4.5 us while
-    // workgroups of the trailing update share it (matrix pipe, issue slots).  The instantiation already holds 355 registers
-    // a lane, which keeps the 128 x 128 update kernel (234) off its CUs; GPX_PANEL_PAD_LDS bytes of unused dynamic LDS on
-    // top of its 74 KB keep the 128 x 64 one (49 KB of the CU's 160) off too.  Worth it only while the panel has few
-    // workgroups -- each takes a whole CU from the update for as long as the chain runs.
+    // A CU of its own for every workgroup of a SHORT panel (single matrix, rows <= GPX_PANEL_EXCL_ROWS).  Per-step stamps
+    // of every leaf variant say the same thing (profiles/r04_leaf_steps_*.log): ~1.0 us a step while the diagonal workgroup
+    // has its CU to itself, 3 - 4.5 us while workgroups of the trailing update share it (matrix pipe, issue slots) -- a
+    // panel took 120 us alone and 140 - 230 us beside an update.  The dispatcher cannot be told to keep a CU free, but it
+    // cannot place what does not fit: the one-wave-leaf instantiation holds 355 registers a lane, which keeps the 128 x 128
+    // update kernel (234) off its CUs, and GPX_PANEL_PAD_LDS = 48 KB of unused dynamic LDS on top of its 66 KB leave less
+    // than the 128 x 64 update kernel's 48 KB of the CU's 160.  Panels start on an idle chip, a few us before the update
+    // they run beside (potrf()'s launch order), so they get their CUs and keep them: 115 us a panel in EVERY phase
+    // (profiles/r04_timeline_n8192_excl8192.txt).  Each workgroup takes a whole CU from the update for as long as the
+    // chain runs, so it pays only while the panel is short: n = 8192 potrf 5.75 -> 5.57 ms with 5120 rows, 5.68 with all
+    // (profiles/r04_ab_exclusive_cus.log).
     size_t pad_lds = 0;
     if (v4 && !bt && rows <= excl_rows) {
-        pad_lds = (size_t)env_i64("GPX_PANEL_PAD_LDS", 38 * 1024);
+        pad_lds = (size_t)env_i64("GPX_PANEL_PAD_LDS", 48 * 1024);
         GPX_TRY(set_max_lds((const void *)panel_res_kernel<T, true, F64 ? 4 : 1>, (int)pad_lds));
     }
 #define GPX_PANEL_LAUNCH(KERNEL, GRID, W0)                                                                                      \

@@ -660,7 +660,11 @@ int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t
             // step k - 1 is done well before panel k ends, so the HOST waits for it here -- the stream wait below then costs
             // nothing and panel k + 1 queues directly behind panel k.  n = 8192: potrf 6.33 -> 6.09 ms, n = 4096: 2.19 ->
             // 2.09, n = 2048: 0.99 -> 0.96 (tools/r3_ab.sh).  The call is then no longer a pure enqueue (include/gpx.h).
-            if (host_paced) GPX_HIP(hipEventSynchronize(e_rest));
+            // (Round 4 tried leaving these waits to the command processor while many rows are left -- the panel's stream waits
+            //  for the update's event, an event behind that wait gates the next update -- so that the host runs ahead: the
+            //  update-to-update gap went from ~30 to ~22 us and the factorisation did not get faster: n = 8192 5.63 vs
+            //  5.62 - 5.72 ms over four thresholds, 5.85 with every step device-paced; profiles/r04_ab_dev_paced.log.)
+            if (host_paced) GPX_HIP(hipEventSynchronize(e_rest));   // (polling hipEventQuery instead: no faster, r04_ab_*_host_spin.log)
             GPX_HIP(hipStreamWaitEvent(q, e_rest, 0));
         }
         GPX_TRY(g_la.get(&ep));

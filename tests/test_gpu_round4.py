@@ -201,10 +201,11 @@ def test_fp64_leaves_vs_oracle_and_each_other(monkeypatch, N):
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 @pytest.mark.parametrize("N,nb", [(4700, "1024"), (3072, "1024"), (2400, "768"), (5120 + 37, "1024")])
 def test_nested_wide_panel_vs_recursive_halving_and_oracle(monkeypatch, dtype, N, nb):
-    """A 768 / 1024-wide panel is a blocked factorisation of its own (potrf_panel_nested: sub-panels of 256 in resident
-    launches that follow each other on the panel stream, in-panel updates beside them on a stream of their own) instead of
-    halving recursively (GPX_POTRF_NESTED=0).  Both against the oracle and each other: ragged last block (takes the
-    halving route), three and four sub-panels, the rider row, a lock-step batch."""
+    """A 768 / 1024-wide panel as a blocked factorisation of its own (GPX_POTRF_NESTED=1, potrf_panel_nested: sub-panels of
+    256 in resident launches that follow each other on the panel stream, in-panel updates beside them on a stream of their
+    own) instead of halving recursively (the default: the nested route measured no faster anywhere).  Both
+    against the oracle and each other: ragged last block (takes the halving route), three and four sub-panels, the rider
+    row, a lock-step batch."""
     from gaussian_processes_amd import mlii
     d = 3
     X, y, Xo = orc.synth_inputs(N, d, 16)
@@ -213,16 +214,16 @@ def test_nested_wide_panel_vs_recursive_halving_and_oracle(monkeypatch, dtype, N
     monkeypatch.setenv("GPX_POTRF_NB", nb)
     thetas = np.array([[h, w, s], [0.8, 1.1, 1.2]])
     out = {}
-    for label, env in (("nested", None), ("halving", "0")):
+    for label, env in (("nested", "1"), ("halving", None)):
         if env is None:
-            monkeypatch.delenv("GPX_POTRF_NESTED", raising=False)
+            monkeypatch.delenv("GPX_POTRF_NESTED", raising=False)       # the default: halving (the nested route is opt-in)
         else:
             monkeypatch.setenv("GPX_POTRF_NESTED", env)
         _lib.route_reset()
         g = gp.GP(gp.GaussianKernel(h, w), X, y, s=s, dtype=dtype)
         llh = float(g.log_lh)
         nn = _lib.route_count(_lib.ROUTE_PANEL_NESTED)
-        assert (nn > 0) if env is None else (nn == 0), (label, nn)
+        assert (nn > 0) if env is not None else (nn == 0), (label, nn)
         out[label] = (llh, np.array(g.Lxx, dtype=np.float64), np.array(g.inv_Kxx_y, dtype=np.float64),
                       mlii.log_lh_batch(X, y, thetas, dtype=dtype) if N <= 4700 else None)
     f64 = dtype == "float64"
