@@ -140,6 +140,8 @@ int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t
 int potrf_panel_res(int dtype, void *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int64_t kb, int *info_dev,
                     hipStream_t st, const Batch *bt = nullptr, int64_t kpre = 0, hipEvent_t done = nullptr);
 int64_t panel_res_max();
+// set by potrf()'s loop for the one panel launch that will find the chip idle; reading it clears it (gpx_potrf.hip)
+bool potrf_take_idle_chip_hint();
 // this host thread's look-ahead stream of the blocked factorisation on the current device (nullptr before the first
 // one): it lives as long as the thread, so an event may be recorded on it at any time
 hipStream_t potrf_side_stream();

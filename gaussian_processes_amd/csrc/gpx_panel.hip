@@ -634,7 +634,9 @@ static int panel_res_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int
     // (The one-wave leaf's instantiation runs ONE workgroup per CU -- 355 registers a lane: its 20 accumulator tiles -- which a
     //  single matrix's panels never notice (at most 256 workgroups per launch) but a lock-step batch's would: batches keep 1.)
     const int64_t excl_rows = env_i64("GPX_PANEL_EXCL_ROWS", 5120);
-    const bool v4 = F64 && env_i64("GPX_LEAF", (!bt && rows <= excl_rows) ? 4 : 1) == 4;
+    const bool idle_chip = potrf_take_idle_chip_hint();        // (always taken: a hint is for ONE launch)
+    const bool excl = F64 && !bt && idle_chip && rows <= excl_rows;
+    const bool v4 = F64 && env_i64("GPX_LEAF", excl ? 4 : 1) == 4;
     // A CU of its own for every workgroup of a SHORT panel (single matrix, rows <= GPX_PANEL_EXCL_ROWS).  Per-step stamps
     // of every leaf variant say the same thing (profiles/r04_leaf_steps_*.log): ~1.0 us a step while the diagonal workgroup
     // has its CU to itself, 3 - 4.5 us while workgroups of the trailing update share it (matrix pipe, issue slots) -- a
@@ -647,28 +649,30 @@ static int panel_res_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int
     // chain runs, so it pays only while the panel is short: n = 8192 potrf 5.75 -> 5.57 ms with 5120 rows, 5.68 with all
     // (profiles/r04_ab_exclusive_cus.log).
     size_t pad_lds = 0;
-    if (v4 && !bt && rows <= excl_rows) {
+    if (v4 && excl) {
         pad_lds = (size_t)env_i64("GPX_PANEL_PAD_LDS", 48 * 1024);
         GPX_TRY(set_max_lds((const void *)panel_res_kernel<T, true, F64 ? 4 : 1>, (int)pad_lds));
     }
-#define GPX_PANEL_LAUNCH(KERNEL, GRID, W0)                                                                                      \
-    hipLaunchKernelGGL((KERNEL), GRID, dim3(256), pad_lds, st, A, lda, n, r0, c0, nsteps, info_dev, (T *)pub, flags, serial,   \
+#define GPX_PANEL_LAUNCH_LDS(KERNEL, GRID, W0, DYN)                                                                             \
+    hipLaunchKernelGGL((KERNEL), GRID, dim3(256), DYN, st, A, lda, n, r0, c0, nsteps, info_dev, (T *)pub, flags, serial,       \
                        bt ? bt->sA : (int64_t)0, (int)(kpre / IB), stamps, W0, strict)
+#define GPX_PANEL_LAUNCH(KERNEL, GRID, W0) GPX_PANEL_LAUNCH_LDS(KERNEL, GRID, W0, 0)
     if (two_part && (int64_t)grid.x > nsteps) {
         const bool mfma_chain = F64 || env_i64("GPX_LEAF_MFMA_F32_ROWS", 16384) > 0;
         const dim3 gdiag((unsigned)nsteps, grid.y), grows(grid.x - (unsigned)nsteps, grid.y);
-        if (v4) GPX_PANEL_LAUNCH((panel_res_kernel<T, true, F64 ? 4 : 1>), gdiag, 0);
+        if (v4) GPX_PANEL_LAUNCH_LDS((panel_res_kernel<T, true, F64 ? 4 : 1>), gdiag, 0, pad_lds);
         else if (mfma_chain) GPX_PANEL_LAUNCH((panel_res_kernel<T, true>), gdiag, 0);
         else GPX_PANEL_LAUNCH((panel_res_kernel<T, F64>), gdiag, 0);
         GPX_PANEL_LAUNCH((panel_res_kernel<T, F64>), grows, nsteps);          // (the rows never run a leaf: the lean instantiation)
     } else if (v4) {
-        GPX_PANEL_LAUNCH((panel_res_kernel<T, true, F64 ? 4 : 1>), grid, 0);
+        GPX_PANEL_LAUNCH_LDS((panel_res_kernel<T, true, F64 ? 4 : 1>), grid, 0, pad_lds);
     } else if (mfma_single) {
         GPX_PANEL_LAUNCH((panel_res_kernel<T, true>), grid, 0);
     } else {
         GPX_PANEL_LAUNCH((panel_res_kernel<T, F64>), grid, 0);
     }
 #undef GPX_PANEL_LAUNCH
+#undef GPX_PANEL_LAUNCH_LDS
     GPX_LAUNCH_CHECK();
     if (record_after) GPX_HIP(hipEventRecord(record_after, st));
     scr->last = st; scr->have_last = true; scr->last_on_side = (side != nullptr && st == side);

@@ -460,6 +460,12 @@ static int lookahead_setup()
 // one-panel look-ahead already updates the NEXT block column first (the far update's first 1024 columns), starts this
 // panel, and applies the rest underneath it.
 static thread_local bool g_in_potrf = false;    // potrf() is running on this thread: its look-ahead state (streams, event pool) is set up
+// potrf()'s loop sets this right before a panel whose FIRST launch will find the chip idle (it is ordered behind the update
+// before it and ahead of the one that runs beside it); the resident panel launch that takes the hint may claim whole CUs
+// (gpx_panel.hip, GPX_PANEL_EXCL_ROWS).  Later launches of the same panel (the right half of a wide one) start on a chip that
+// the update has filled meanwhile: they must not wait for empty CUs.
+static thread_local bool g_idle_chip = false;
+bool potrf_take_idle_chip_hint() { const bool v = g_idle_chip; g_idle_chip = false; return v; }
 static bool panel_nested_ok(int64_t rows, int64_t r0, int64_t c0, int64_t kb, int64_t kpre, size_t es, int64_t lda, const void *base)
 {
     const int64_t sub = panel_res_max();
@@ -622,9 +628,17 @@ int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t
     // forced GPX_POTRF_NB keep one width.
     const bool taper = env_i64("GPX_POTRF_TAPER", 1) != 0 && !env_set("GPX_POTRF_NB");
     auto nominal = [&](int64_t k0) -> int64_t { return (taper && !bt) ? std::min(nb, outer_block(n - k0)) : nb; };
+    // (Round 4 also built a "pair phase" here -- while many rows are left, the far trailing matrix updated once per TWO 256-wide
+    //  panels with one K = 512 product, the panels in between applying their predecessors themselves, 512 / 256 columns deep --
+    //  correct, and no faster: n = 8192 5.67 - 5.97 ms against 5.58 (profiles/r04_ab_pair_phase_dropped.log).  The K = 512 update
+    //  does run at 60 TF/s, but the second panel of every pair starts on a chip the update has filled and takes 280 - 470 us
+    //  instead of 115 (profiles/r04_timeline_n8192_pair_phase_dropped.txt): one panel per update, dispatched ahead of it, is
+    //  the schedule this machine rewards.  Removed again.)
     int64_t k0 = 0, kb = std::min(nominal(0), n);
     GPX_TRY(g_la.get(&ep));
+    g_idle_chip = !bt;
     GPX_TRY(potrf_panel(dtype, A, lda, N, 0, 0, kb, info_dev, q, bt, 0, ep));
+    g_idle_chip = false;
     hipEvent_t e_rest = nullptr;                                // fires when the trailing update of the step before is done
     // host pacing blocks the calling thread inside the loop: only where the caller said it may (the handle's gpx_gp_fit,
     // documented in include/gpx.h; gpx_d_potrf stays a pure enqueue) and never while the stream is being captured
@@ -647,11 +661,21 @@ int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t
         // block column k + 1 first, so that its panel can start ... (small n: the panel kernel applies panel k to its
         // own columns itself -- it then only waits for the trailing update of step k - 1, not for this stream's turn)
         const bool fold = panel_res_fold(N - r, kb, kb1, es, lda, A);
+        hipEvent_t e_gate = nullptr;
         if (!fold) {
             GPX_TRY(syrk_bc(dtype, N, r, A, lda, r, r + kb1, at(k0, k0), lda, k0, kb, w1, 1, 0, st, info_dev, bt));
             GPX_TRY(g_la.get(&e));
             GPX_HIP(hipEventRecord(e, st));
             GPX_HIP(hipStreamWaitEvent(q, e, 0));
+            // The panel has to get onto the chip BEFORE the rest of the update: that one follows the block-column update
+            // directly in its stream, while the panel sits behind a cross-stream wait -- it used to start ~6 us late, found
+            // every CU slot taken and ran for as long as the update did (n = 8192 with 512-wide blocks: the left half 504 us
+            // beside a 441 us update, the right half 107 us after it; profiles/r04_timeline_n8192_nb512_before_gate.txt).
+            // An event recorded on the panel's stream right behind its wait gates the rest of the update.
+            if ((bt ? env_i64("GPX_POTRF_GATE_BATCH", 0) != 0 : true) && N - r <= env_i64("GPX_POTRF_GATE_ROWS", 16384)) {
+                GPX_TRY(g_la.get(&e_gate));
+                GPX_HIP(hipEventRecord(e_gate, q));
+            }
         } else if (e_rest) {
             // Host-paced panels (single matrices, n <= 16384: the sizes whose panels take the update to their left themselves).  A wait on an
             // event of another stream that is still pending at ENQUEUE time becomes a barrier packet in front of the panel;
@@ -668,10 +692,14 @@ int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t
             GPX_HIP(hipStreamWaitEvent(q, e_rest, 0));
         }
         GPX_TRY(g_la.get(&ep));
+        g_idle_chip = !bt && (e_gate != nullptr || (fold && (host_paced || !e_rest)));
         GPX_TRY(potrf_panel(dtype, A, lda, N, r, r, kb1, info_dev, q, bt, fold ? kb : 0, ep));
+        g_idle_chip = false;
         // ... while the rest of the trailing matrix is updated underneath it
-        if (r + kb1 < n)
+        if (r + kb1 < n) {
+            if (e_gate) GPX_HIP(hipStreamWaitEvent(st, e_gate, 0));
             GPX_TRY(syrk_bc(dtype, N, r, A, lda, r + kb1, n, at(k0, k0), lda, k0, kb, w1, 1, 0, st, info_dev, bt));
+        }
         GPX_TRY(g_la.get(&e_rest));
         GPX_HIP(hipEventRecord(e_rest, st));
         // (after the next panel and this step's update are on their way: the hook's launches never delay the chain)

@@ -109,10 +109,13 @@ def test_soak_repeat_fits_are_bitwise_identical(monkeypatch, n, dtype):
         fit.close()
     for k in ("GPX_POTRF_HOST_PACED", "GPX_RES_STRICT"):
         monkeypatch.delenv(k, raising=False)
-    # the three routes run the same arithmetic in the same order
-    for route in ("not_host_paced", "strict"):
-        assert first[route][0] == first["default"][0], route
-        assert np.array_equal(first[route][1], first["default"][1]), route
+    # default and strict run the same kernels in the same order: bitwise equal.  Without host pacing a panel may not claim
+    # whole CUs (it does not start on an idle chip), so fp64 panels of up to 5120 rows take the four-wave leaf instead of the
+    # one-wave one there: the same factorisation, different rounding inside the 64 x 64 leaves
+    assert first["strict"][0] == first["default"][0]
+    assert np.array_equal(first["strict"][1], first["default"][1])
+    np.testing.assert_allclose(first["not_host_paced"][0], first["default"][0], rtol=1e-12 if f64 else 1e-6)
+    np.testing.assert_allclose(first["not_host_paced"][1], first["default"][1], rtol=1e-9 if f64 else 1e-3, atol=1e-11 if f64 else 1e-4)
     # a neighbour: another handle (other size) factoring in a loop on a second host thread (its own look-ahead stream,
     # its own published blocks), while this thread repeats the fit
     stop = threading.Event()
