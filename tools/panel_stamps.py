@@ -47,8 +47,8 @@ lsx = st.to_host().reshape(-1, 16).astype(np.int64)[2040:2048].ravel()
 if lsx[16]:
     rt, ct = lsx[16:32], lsx[32:48]
     print("leaf of workgroup 0, per step (first barrier to first barrier): us " + " ".join("%.2f" % ((rt[i + 1] - rt[i]) / 100.0) for i in range(15)))
-    print("                                                     core cycles " + " ".join("%d" % (ct[i + 1] - ct[i]) for i in range(15)))
+    print("                                          core cycles (from step 1) " + " ".join("%d" % (ct[i + 1] - ct[i]) for i in range(1, 15)))
     print("   16 steps: %.2f us from the first barrier of step 0 to that of step 15; clock %.2f GHz" % (
-        (rt[15] - rt[0]) / 100.0, (ct[15] - ct[0]) / ((rt[15] - rt[0]) * 10.0)))
+        (rt[15] - rt[0]) / 100.0, (ct[15] - ct[1]) / ((rt[15] - rt[1]) * 10.0)))
 ends = (s[live, 6] - t0) / 100.0; starts = (s[live, 0] - t0) / 100.0
 print("last start %.1f us, last end %.1f us (workgroup %d)" % (starts.max(), ends.max(), live[ends.argmax()]))
