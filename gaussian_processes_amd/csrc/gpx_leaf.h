@@ -2,6 +2,8 @@
 // batched inverses of the triangular solves (gpx_solve.hip).
 #pragma once
 #include "gpx_common.h"
+#include <utility>
+#include <type_traits>
 
 namespace gpx {
 
@@ -550,18 +552,127 @@ __device__ __forceinline__ double w1_bcast(double v, int src)
     return __hiloint2double(hi, lo);
 }
 
+template <typename F, int... Is>
+__device__ __forceinline__ void w1_steps(F &f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+
+// The leaf issues its MFMAs from VOLATILE asm: volatile asm statements keep their source order in the instruction stream,
+// which is the whole point (see "Schedule" below) -- hipcc's schedulers otherwise gather a step's MFMAs into one run and the
+// step's pivot arithmetic into another (sched_barrier fences do not hold pure VALU code in place, sched_group_barrier
+// pipelines were not followed; both tried).  What hipcc's hazard recogniser would do for MFMAs it knows about is settled by
+// measurement instead (tools/mfma_hazard_probe_gen.py: full-mantissa operands, every result compared bit for bit with the same
+// sequence given 40 wait states, one wave alone and 3 x 16384 waves contending for the matrix pipes; profiles/r04_mfma_hazard_probe.txt).
+// v_mfma_f64_16x16x4_f64 on gfx950:
+//   * registers 0 - 2 of the result (rows 0 .. 11 of the tile) are interlocked for every reader but LDS: VALU, v_readlane,
+//     v_accvgpr_read, a following MFMA's srcA / srcB / srcC -- right with ZERO wait states;
+//   * register 3 (rows 12 .. 15) is NOT: a reader inside 17 wait states gets a value of about single precision (the double
+//     product is built up over the passes); 18 wait states, or one more MFMA issued in between (it waits for the pipe), are enough;
+//   * an LDS store of a result needs 4 wait states for register 0 and 17 for register 3;
+//   * an MFMA whose source register (VGPR or AGPR, srcA or srcB) a VALU instruction wrote 0 - 1 wait states earlier reads the
+//     old value (2 and more: right) -- hipcc puts such copies in front of an asm operand as it likes, so every asm MFMA
+//     starts with an s_nop 2 (3 wait states);
+//   * a VALU write into the destination of an MFMA in flight, or over its sources, is held back correctly (but costs the
+//     writer the MFMA's whole duration: the strip MFMAs' destinations stay allocated for that reason);
+//   * back-to-back accumulation into one tile is right.
+// The leaf uses register 0 of the strip MFMAs only, reads other registers of a tile only at the places marked "register 3"
+// below, and keeps every read of a tile behind an anchor that follows its last writer by an MFMA or by 18 wait states.
+typedef double w1_v4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void w1_mfma_acc(w1_v4 &c, double a, double b)             // c += a (16 x 4) . b (4 x 16), accumulators in AGPRs
+{ asm volatile("s_nop 2\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b)); }
+__device__ __forceinline__ w1_v4 w1_mfma_strip(double a, double b)                     // a . b (rows 0 .. 3 = register 0 are what is wanted), b an accumulator register
+{ w1_v4 d; asm volatile("s_nop 2\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(b)); return d; }
+// ---- the leaf itself: TWO waves of the diagonal workgroup ----
 // sM: the block, row-major, lower triangle valid (pitch PT).  On return sM holds L (lower; entries above the diagonal are
-// not written) and sW holds W = inv(L) (all 64 x 64, zeros above the diagonal).  One wave (64 lanes) calls this.
-template <int PT>
-__device__ __forceinline__ void factor64_wave(double (*sM)[PT], double (*sW)[PT], int64_t j0, int *__restrict__ info, int lane,
-                                              unsigned long long *stamps = nullptr)
+// not written) and sW holds W = inv(L) (all 64 x 64, zeros above the diagonal).  Waves 0 and 1 of the workgroup call this
+// (role = wave); a workgroup barrier must follow before anybody reads sM / sW.
+//
+// Schedule (second version, round 4).  The first version issued a step's MFMAs in one run behind its pivots -- v_mfma_f64_16x16x4
+// holds the matrix pipe for 64 cycles on gfx950 and a wave issues in order, so a step cost (its 14 MFMAs) + (the pivot chain)
+// ~ 2300 cycles with the two never overlapping.  Now
+//   * the row operations on the identity (Y = inv) are NOT on the chain of the factorisation at all: wave 1 does them, on its
+//     own SIMD's matrix pipe, one step or more behind wave 0, from the operands wave 0 leaves in LDS (per step and lane: the
+//     strip solve's A operand and the rank-4 update's A operands, W1_SLOTS doubles; a step counter in LDS says how far wave 0
+//     is -- LDS executes one wave's instructions in order, so the counter is simply written behind the data);
+//   * wave 0's step is split into the CRITICAL pair -- the strip solve of the tile that holds the next diagonal 4 x 4 and that
+//     tile's rank-4 update -- and everything else, DEFERRED: the deferred MFMAs of step jt are issued one at a time BETWEEN the
+//     stages of step jt + 1's pivot arithmetic (gather | four pivots, each with its row of the inverse), which depends on the
+//     critical pair alone: the VALU chain runs in the shadow of the matrix pipe.  Empty volatile asm statements carrying a
+//     stage's values ("anchors") pin each stage between two MFMAs;
+//   * the open part of the block is held NEGATED (S = -M, Z = -Y): the rank-4 update is then a plain accumulate whose A and
+//     B operands are the strip registers as they stand; the strip solve uses -inv(l); the gather and the pivots work on -M;
+//   * only the tile row of the strip needs a mask on its A operand (rows already final), one select;
+//   * finished strips go to LDS at once from the registers the MFMA left them in (nothing is copied back into the tiles).
+constexpr int W1_SLOTS = 5;                                        // per step and lane: aw, then the update operands of tile rows jn .. 3
+constexpr int W1_BUF_DOUBLES = (IB / 4) * W1_SLOTS * 64;          // 40 KB
+
+__device__ __forceinline__ unsigned w1_lds_addr(const void *p)
 {
-    typedef PM<double> M;
-    typedef M::v4 v4;
+    return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void *)p;
+}
+
+template <int PT, int STAMP_STEP = -1>
+__device__ __forceinline__ void factor64_wave(double (*sM)[PT], double (*sW)[PT], double *sBuf, int *sStep, int role, int64_t j0,
+                                              int *__restrict__ info, int lane, unsigned long long *stamps = nullptr)
+{
+    typedef w1_v4 v4;
     const int li = lane & 15, lq = lane >> 4;
-    const v4 zero = {0.0, 0.0, 0.0, 0.0};
-    v4 T[10], Y[10];                       // Y(ti, tj'), ti >= tj': stored at w1_tix(tj', ti)
-    // ---- load: T(ti, tj)[r] = M[16 ti + lq + 4 r][16 tj + li], taken from the lower triangle (symmetric) ----
+    double (*buf)[W1_SLOTS][64] = reinterpret_cast<double (*)[W1_SLOTS][64]>(sBuf);
+    unsigned step_addr = w1_lds_addr(sStep);          // (not const: the step lambdas capture it)
+    if (role == 1) {
+        // ================= wave 1: Y = U^-T = L^-1 by the same row operations, from wave 0's operands =================
+        v4 Y[10];                          // -Y tiles: Y(ti, tj'), ti >= tj', stored at w1_tix(tj', ti)
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+            for (int tj = 0; tj <= ti; ++tj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Y[w1_tix(tj, ti)][r] = (ti == tj && lq + 4 * r == li) ? -1.0 : 0.0;
+        auto ystep = [&](auto jtc) {
+            constexpr int jt = decltype(jtc)::value;
+            constexpr int c0 = 4 * jt, jj0 = jt >> 2, q = jt & 3;
+            constexpr bool last = jt + 1 == IB / 4;
+            constexpr int jn = last ? 4 : (jt + 1) >> 2;          // the first tile row still open after this step (none after the last)
+            int seen;
+            do {
+                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen) : "v"(step_addr) : "memory");
+            } while (seen <= jt);
+            const double aw = buf[jt][0][lane];
+            double au[4];
+#pragma unroll
+            for (int ti = jn; ti < 4; ++ti) au[ti] = buf[jt][1 + ti - jn][lane];
+            // (register 3: the tiles of row jj0 were last written by the previous step's updates, possibly by its very last
+            //  MFMA; the poll and the loads above are two LDS round trips, the 18 wait states are on top for q == 3)
+            if constexpr (q == 3) {
+                if constexpr (jj0 == 0) asm volatile("s_nop 15\n\ts_nop 1" : "+a"(Y[w1_tix(0, 0)]));
+                if constexpr (jj0 == 1) asm volatile("s_nop 15\n\ts_nop 1" : "+a"(Y[w1_tix(0, 1)]), "+a"(Y[w1_tix(1, 1)]));
+                if constexpr (jj0 == 2) asm volatile("s_nop 15\n\ts_nop 1" : "+a"(Y[w1_tix(0, 2)]), "+a"(Y[w1_tix(1, 2)]), "+a"(Y[w1_tix(2, 2)]));
+                if constexpr (jj0 == 3) asm volatile("s_nop 15\n\ts_nop 1" : "+a"(Y[w1_tix(0, 3)]), "+a"(Y[w1_tix(1, 3)]), "+a"(Y[w1_tix(2, 3)]), "+a"(Y[w1_tix(3, 3)]));
+            }
+            v4 ys[4];
+#pragma unroll
+            for (int tj = 0; tj <= jj0; ++tj) ys[tj] = w1_mfma_strip(aw, Y[w1_tix(tj, jj0)][q]);
+#pragma unroll
+            for (int ti = jn; ti < 4; ++ti)
+#pragma unroll
+                for (int tj = 0; tj <= jj0; ++tj) w1_mfma_acc(Y[w1_tix(tj, ti)], au[ti], ys[tj][0]);
+            // (an LDS store of register 0 needs 4 wait states behind the MFMA; the anchor provides 8)
+            if constexpr (jj0 == 0) asm volatile("s_nop 7" : "+v"(ys[0]));
+            if constexpr (jj0 == 1) asm volatile("s_nop 7" : "+v"(ys[0]), "+v"(ys[1]));
+            if constexpr (jj0 == 2) asm volatile("s_nop 7" : "+v"(ys[0]), "+v"(ys[1]), "+v"(ys[2]));
+            if constexpr (jj0 == 3) asm volatile("s_nop 7" : "+v"(ys[0]), "+v"(ys[1]), "+v"(ys[2]), "+v"(ys[3]));
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj) {
+                const int row = c0 + lq, col = 16 * tj + li;      // W = Y with zeros right of the diagonal
+                sW[row][col] = (tj <= jj0 && col <= row) ? ys[tj <= jj0 ? tj : 0][0] : 0.0;
+            }
+        };
+        w1_steps(ystep, std::make_integer_sequence<int, IB / 4>{});
+        return;
+    }
+    // ================= wave 0: the factorisation =================
+    unsigned long long tm[12] = {};                                // STAMP_STEP >= 0 (tools/leaf_probe.hip): issue times inside that step
+    v4 T[10];                              // -M tiles (ti <= tj)
+    if (stamps && lane == 0) { stamps[16] = __builtin_amdgcn_s_memrealtime(); stamps[32] = __builtin_amdgcn_s_memtime(); }
+    // ---- load: T(ti, tj)[r] = -M[16 ti + lq + 4 r][16 tj + li], taken from the lower triangle (symmetric) ----
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
@@ -569,116 +680,166 @@ __device__ __forceinline__ void factor64_wave(double (*sM)[PT], double (*sW)[PT]
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * ti + lq + 4 * r, col = 16 * tj + li;
-                T[w1_tix(ti, tj)][r] = row <= col ? sM[col][row] : sM[row][col];
+                T[w1_tix(ti, tj)][r] = -(row <= col ? sM[col][row] : sM[row][col]);
             }
-#pragma unroll
-    for (int ti = 0; ti < 4; ++ti)
-#pragma unroll
-        for (int tj = 0; tj <= ti; ++tj)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Y[w1_tix(tj, ti)][r] = (ti == tj && lq + 4 * r == li) ? 1.0 : 0.0;
     int bad_at = 0;
+    double d[4][4], wi[4][4], aw = 0.0, aw_next = 0.0;
+    // the 4 x 4 diagonal tile of step jt to every lane, as it stands in the tile (negated): d[r][c] (r >= c) = -M[c0 + c][c0 + r]
+    // (20 v_readlane; a negation here would be 10 SALU operations each waiting for a VALU-written SGPR)
+    auto gather = [&](int jt) {
+        const double src = T[w1_tix(jt >> 2, jt >> 2)][jt & 3];
 #pragma unroll
-    for (int jt = 0; jt < IB / 4; ++jt) {
-        const int c0 = 4 * jt, jj0 = jt >> 2, q = jt & 3;
-        if (stamps && lane == 0) { stamps[16 + jt] = __builtin_amdgcn_s_memrealtime(); stamps[32 + jt] = __builtin_amdgcn_s_memtime(); }
-        // ---- the 4 x 4 diagonal tile to every lane: d[r][c] (r >= c) = M[c0 + c][c0 + r] ----
-        double d[4][4], wi[4][4], rk[4];
-        {
-            const double src = T[w1_tix(jj0, jj0)][q];
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int c = 0; c <= r; ++c) d[r][c] = w1_bcast(src, 16 * c + 4 * (jt & 3) + r);
+    };
+    // pivot k of the tile: on entry d[r][c], c >= k, hold the NEGATED open part; column k becomes l = R^T (final), the columns
+    // right of it are updated (still negated: e += l l^T).  Then row k of inv(l) -- it needs nothing later than this pivot --
+    // and its entries of the strip solve's A operand: A[i][m] = -inv(l)[i][m] at lane (li = i < 4, lq = m)
+    auto pivot = [&](int jt, int k) {
+        const double npiv = d[k][k];
+        if (bad_at == 0 && !(npiv < 0.0)) bad_at = 4 * jt + k + 1;                   // also catches NaN; reported at the end
+        const double rinv = fast_rsqrt(-npiv);
+        d[k][k] = -npiv * rinv;
 #pragma unroll
-                for (int c = 0; c <= r; ++c) d[r][c] = w1_bcast(src, 16 * c + 4 * q + r);
+        for (int r = k + 1; r < 4; ++r) d[r][k] = -d[r][k] * rinv;
+#pragma unroll
+        for (int c = k + 1; c < 4; ++c)
+#pragma unroll
+            for (int r = c; r < 4; ++r) d[r][c] = fma(d[r][k], d[c][k], d[r][c]);
+        wi[k][k] = rinv;
+#pragma unroll
+        for (int c = 0; c < k; ++c) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int m = c; m < k; ++m) sacc = fma(d[k][m], wi[m][c], sacc);
+            wi[k][c] = -rinv * sacc;
         }
+        if (k == 0) aw_next = 0.0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const double piv = d[k][k];
-            if (bad_at == 0 && !(piv > 0.0)) bad_at = c0 + k + 1;                    // also catches NaN; reported at the end
-            const double rinv = fast_rsqrt(piv);
-            rk[k] = rinv;
-            d[k][k] = piv * rinv;
+        for (int c = 0; c <= k; ++c) aw_next = (li == k && lq == c) ? -wi[k][c] : aw_next;
+    };
+    // anchors: the values a stage hands to the next one pass through an empty volatile asm, which sits in the MFMAs' order
+    auto anchor_tile = [&](v4 &t) { asm volatile("" : "+a"(t)); };
+    auto anchor_d = [&]() {
+        asm volatile("" : "+s"(d[0][0]), "+s"(d[1][0]), "+s"(d[2][0]), "+s"(d[3][0]), "+s"(d[1][1]), "+s"(d[2][1]), "+s"(d[3][1]),
+                          "+s"(d[2][2]), "+s"(d[3][2]), "+s"(d[3][3]));
+    };
+    auto anchor_p = [&](int k) {
+        if (k == 0) asm volatile("" : "+v"(d[1][0]), "+v"(d[2][0]), "+v"(d[3][0]), "+v"(d[1][1]), "+v"(d[2][1]), "+v"(d[3][1]),
+                                      "+v"(d[2][2]), "+v"(d[3][2]), "+v"(d[3][3]), "+v"(wi[0][0]), "+v"(aw_next));
+        if (k == 1) asm volatile("" : "+v"(d[2][1]), "+v"(d[3][1]), "+v"(d[2][2]), "+v"(d[3][2]), "+v"(d[3][3]), "+v"(wi[1][0]), "+v"(wi[1][1]), "+v"(aw_next));
+        if (k == 2) asm volatile("" : "+v"(d[3][2]), "+v"(d[3][3]), "+v"(wi[2][0]), "+v"(wi[2][1]), "+v"(wi[2][2]), "+v"(aw_next));
+        if (k == 3) asm volatile("" : "+v"(aw_next));
+    };
+    gather(0);
 #pragma unroll
-            for (int r = k + 1; r < 4; ++r) d[r][k] *= rinv;
+    for (int k = 0; k < 4; ++k) pivot(0, k);
+    aw = aw_next;
+    auto step = [&](auto jtc) {                                   // (a step per instantiation: every tile index below is static)
+        constexpr int jt = decltype(jtc)::value;
+        constexpr int c0 = 4 * jt, jj0 = jt >> 2, q = jt & 3;
+        constexpr bool last = jt + 1 == IB / 4;
+        constexpr int jn = last ? 3 : (jt + 1) >> 2;              // the tile row of the next step = the first still open after this one
+        constexpr int ct = (q == 3 && !last) ? jn : jj0;          // the tile of the critical strip
+        // the step's finished strips: rows c0 .. c0 + 3 of U = register 0 of these (the strip MFMA's whole destination stays
+        // allocated to the end of the step: hipcc would otherwise hand the three registers nobody reads to the next value it
+        // computes while the MFMA is still to write them, and the hardware holds that instruction back until it has)
+        v4 us[4];
+        double am = 0.0;
+        auto mark = [&](int i) { if constexpr (jt == STAMP_STEP) tm[i] = __builtin_amdgcn_s_memtime(); };
+        // (register 3: the strips read register q of the tiles of row jj0; their last writers are the previous step's critical
+        //  update and the first of its deferred updates, each followed by another MFMA or by the whole pivot chain -- the anchor
+        //  keeps hipcc's copies of those registers from moving up behind the writer)
+        if constexpr (jj0 == 0) asm volatile("" : "+a"(T[w1_tix(0, 0)]), "+a"(T[w1_tix(0, 1)]), "+a"(T[w1_tix(0, 2)]), "+a"(T[w1_tix(0, 3)]));
+        if constexpr (jj0 == 1) asm volatile("" : "+a"(T[w1_tix(1, 1)]), "+a"(T[w1_tix(1, 2)]), "+a"(T[w1_tix(1, 3)]));
+        if constexpr (jj0 == 2) asm volatile("" : "+a"(T[w1_tix(2, 2)]), "+a"(T[w1_tix(2, 3)]));
+        if constexpr (jj0 == 3) asm volatile("" : "+a"(T[w1_tix(3, 3)]));
+        // ---- critical pair ----
+        mark(0);
+        us[ct] = w1_mfma_strip(aw, T[w1_tix(jj0, ct)][q]);
+        if constexpr (q < 3) am = (li > 4 * q + 3) ? us[jj0][0] : 0.0;   // A operand for the strip's own tile row: rows up to the strip are final
+        if constexpr (!last) w1_mfma_acc(T[w1_tix(jn, jn)], jn == jj0 ? am : us[jn][0], us[jn][0]);
+        // ---- deferred: ordinals [from, to) of: the other strips, the updates (row-major: the next step's tile row first) ----
+        auto defer = [&](int from, int to) {
+            int k = 0;
 #pragma unroll
-            for (int c = k + 1; c < 4; ++c)
-#pragma unroll
-                for (int r = c; r < 4; ++r) d[r][c] = fma(-d[r][k], d[c][k], d[r][c]);
-        }
-        // inv(l), l = R^T lower: column by column
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (i < k) { wi[i][k] = 0.0; continue; }
-                if (i == k) { wi[i][k] = rk[i]; continue; }
-                double sacc = 0.0;
-#pragma unroll
-                for (int m = k; m < i; ++m) sacc = fma(d[i][m], wi[m][k], sacc);
-                wi[i][k] = -rk[i] * sacc;
+            for (int tj = jj0; tj < 4; ++tj) {
+                if (tj == ct) continue;
+                if (k >= from && k < to) us[tj] = w1_mfma_strip(aw, T[w1_tix(jj0, tj)][q]);
+                ++k;
             }
+            if constexpr (!last) {
+#pragma unroll
+                for (int ti = jn; ti < 4; ++ti)
+#pragma unroll
+                    for (int tj = ti; tj < 4; ++tj) {
+                        if (ti == jn && tj == jn) continue;
+                        if (k >= from && k < to) w1_mfma_acc(T[w1_tix(ti, tj)], ti == jj0 ? am : us[ti][0], us[tj][0]);
+                        ++k;
+                    }
+            }
+        };
+        constexpr int defer_count = (3 - jj0) + (last ? 0 : (4 - jn) * (5 - jn) / 2 - 1);     // strips besides the critical one + updates besides it
+        // wave 1's operands of this step: the strips are complete (issued at least three stages ago), 5 wait states for the stores
+        auto publish = [&](unsigned flag_addr) {
+            if constexpr (jj0 == 0) asm volatile("s_nop 4" : "+v"(us[0]), "+v"(us[1]), "+v"(us[2]), "+v"(us[3]));
+            if constexpr (jj0 == 1) asm volatile("s_nop 4" : "+v"(us[1]), "+v"(us[2]), "+v"(us[3]));
+            if constexpr (jj0 == 2) asm volatile("s_nop 4" : "+v"(us[2]), "+v"(us[3]));
+            if constexpr (jj0 == 3) asm volatile("s_nop 4" : "+v"(us[3]));
+            buf[jt][0][lane] = aw;
+            if constexpr (!last) {
+#pragma unroll
+                for (int ti = jn; ti < 4; ++ti) buf[jt][1 + ti - jn][lane] = (ti == jj0) ? am : us[ti][0];
+            }
+            asm volatile("ds_write_b32 %0, %1" : : "v"(flag_addr), "v"(jt + 1) : "memory");
+        };
+        if constexpr (!last) {
+            mark(1);
+            defer(0, 1);
+            mark(2);
+            // (register 3: the gather reads register (jt + 1) & 3 of the tile the critical update has just written; one deferred
+            //  MFMA in between is enough, the last steps have none)
+            if constexpr (((jt + 1) & 3) == 3 && defer_count == 0) asm volatile("s_nop 15\n\ts_nop 1" : "+a"(T[w1_tix(jn, jn)]));
+            else anchor_tile(T[w1_tix(jn, jn)]);
+            gather(jt + 1);
+            anchor_d();
+            mark(3);
+            defer(1, 2);
+            pivot(jt + 1, 0); anchor_p(0);
+            mark(4);
+            defer(2, 3);
+            pivot(jt + 1, 1); anchor_p(1);
+            mark(5);
+            defer(3, 4);
+            pivot(jt + 1, 2); anchor_p(2);
+            mark(6);
+            defer(4, 5);
+            pivot(jt + 1, 3); anchor_p(3);
+            mark(7);
+            publish(step_addr);
+            defer(5, 64);
+            mark(8);
+        } else {
+            defer(0, 64);
+            publish(step_addr);
         }
-        // A operand of the strip solve: A[i][m] = inv(l)[i][m] at lane (li = i < 4, lq = m)
-        double aw = 0.0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int m = 0; m <= i; ++m) aw = (li == i && lq == m) ? wi[i][m] : aw;
-        // ---- strip solve: rows c0 .. c0 + 3 of U (tiles of tile row jj0) and of Y ----
+        // ---- the step's finished rows to LDS: L = U^T (lower part only) ----
+        if constexpr (jj0 == 0) asm volatile("s_nop 7" : "+v"(us[0]), "+v"(us[1]), "+v"(us[2]), "+v"(us[3]));
+        if constexpr (jj0 == 1) asm volatile("s_nop 7" : "+v"(us[1]), "+v"(us[2]), "+v"(us[3]));
+        if constexpr (jj0 == 2) asm volatile("s_nop 7" : "+v"(us[2]), "+v"(us[3]));
+        if constexpr (jj0 == 3) asm volatile("s_nop 7" : "+v"(us[3]));
 #pragma unroll
         for (int tj = jj0; tj < 4; ++tj) {
-            const v4 u = M::mfma(aw, T[w1_tix(jj0, tj)][q], zero);
-            T[w1_tix(jj0, tj)][q] = u[0];
+            const int row = 16 * tj + li, col = c0 + lq;          // U[col][row] = L[row][col]
+            if (col <= row) sM[row][col] = us[tj][0];
         }
-#pragma unroll
-        for (int tj = 0; tj <= jj0; ++tj) {
-            const v4 u = M::mfma(aw, Y[w1_tix(tj, jj0)][q], zero);
-            Y[w1_tix(tj, jj0)][q] = u[0];
-        }
-        // ---- a block of four steps is complete: tile row jj0 of U and of Y is final -- to LDS now (L = U^T, lower part
-        // only; W = Y with zeros right of the diagonal tile), which ends the life of those registers ----
-        if (q == 3) {
-#pragma unroll
-            for (int tj = jj0; tj < 4; ++tj)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * jj0 + lq + 4 * r, col = 16 * tj + li;   // U[row][col] = L[col][row]
-                    if (row <= col) sM[col][row] = T[w1_tix(jj0, tj)][r];
-                }
-#pragma unroll
-            for (int tj = 0; tj < 4; ++tj)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * jj0 + lq + 4 * r, col = 16 * tj + li;
-                    sW[row][col] = (tj <= jj0 && col <= row) ? Y[w1_tix(tj <= jj0 ? tj : jj0, jj0)][r] : 0.0;
-                }
-        }
-        if (jt + 1 == IB / 4) break;
-        // ---- rank-4 updates: T(ti, tj) -= U_s(ti)^T U_s(tj),  Y(ti, tj') -= U_s(ti)^T Y_s(tj')  (rows right of the strip only) ----
-        double au[4];
-#pragma unroll
-        for (int ti = jj0; ti < 4; ++ti) {
-            const double v = T[w1_tix(jj0, ti)][q];
-            au[ti] = (16 * ti + li > c0 + 3) ? -v : 0.0;           // A[i][k] = -U[c0 + k][16 ti + i]; columns up to the strip: final
-        }
-        // (the tile that holds the next diagonal 4 x 4 first: the next step's pivots depend on it alone)
-        const int jn = (jt + 1) >> 2;
-        T[w1_tix(jn, jn)] = M::mfma(au[jn], T[w1_tix(jj0, jn)][q], T[w1_tix(jn, jn)]);
-#pragma unroll
-        for (int ti = jj0; ti < 4; ++ti)
-#pragma unroll
-            for (int tj = ti; tj < 4; ++tj) {
-                if (ti == jn && tj == jn) continue;
-                if (16 * ti + 15 <= c0 + 3) continue;              // (never: ti >= jj0)
-                T[w1_tix(ti, tj)] = M::mfma(au[ti], T[w1_tix(jj0, tj)][q], T[w1_tix(ti, tj)]);
-            }
-#pragma unroll
-        for (int ti = jj0; ti < 4; ++ti)
-#pragma unroll
-            for (int tj = 0; tj <= jj0; ++tj)
-                Y[w1_tix(tj, ti)] = M::mfma(au[ti], Y[w1_tix(tj, jj0)][q], Y[w1_tix(tj, ti)]);
-    }
-    if (stamps && lane == 0) { stamps[16 + 16] = __builtin_amdgcn_s_memrealtime(); stamps[32 + 16] = __builtin_amdgcn_s_memtime(); }
+        aw = aw_next;
+        mark(9);
+    };
+    w1_steps(step, std::make_integer_sequence<int, IB / 4>{});
+    if (stamps && lane == 0) { stamps[17] = __builtin_amdgcn_s_memrealtime(); stamps[33] = __builtin_amdgcn_s_memtime(); }
+    if constexpr (STAMP_STEP >= 0) if (stamps && lane == 0) for (int i = 0; i < 10; ++i) stamps[40 + i] = tm[i];
     if (lane == 0 && bad_at != 0) atomicCAS(info, 0, (int)(j0 + bad_at));          // first failure wins
 }
 

@@ -462,12 +462,16 @@ __global__ __launch_bounds__(256, LV == 4 ? 1 : 2) void panel_res_kernel(T *__re
     }
     if constexpr (LEAF_MFMA && LV == 4 && sizeof(T) == 8) {
         if (dg_step >= 0) {
-            // ---- the diagonal block: the ONE-WAVE leaf (gpx_leaf.h, factor64_wave): the block is in sA by rows; wave 0
-            // factors it without touching LDS or a barrier, leaves L in sA and W = inv(L) in sB ----
+            // ---- the diagonal block: the leaf of gpx_leaf.h (factor64_wave): the block is in sA by rows; wave 0 factors it
+            // without a barrier, wave 1 follows it with the inverse; L is left in sA and W = inv(L) in sB ----
+            __shared__ __attribute__((aligned(16))) double sLeaf[W1_BUF_DOUBLES];   // wave 0's per-step operands for wave 1 (40 KB)
+            __shared__ int sLeafStep;
             const int j = dg_step;
+            if (tid == 0) sLeafStep = 0;
             __syncthreads();                                      // sA is complete
-            if (wave == 0)
-                factor64_wave<PT>(sA, sB, r0 + (int64_t)IB * j, info, lane, (stamps && w == 0 && blockIdx.y == 0) ? stamps + 2040 * 16 : nullptr);
+            if (wave < 2)
+                factor64_wave<PT>(sA, sB, sLeaf, &sLeafStep, wave, r0 + (int64_t)IB * j, info, lane,
+                                  (stamps && w == 0 && blockIdx.y == 0) ? stamps + 2040 * 16 : nullptr);
             __syncthreads();
             // publish W: its 10 lower 16 x 16 tiles, 16-byte agent-scope stores (what res_stage_w loads)
             T *W = pub + (int64_t)j * (IB * IB);
@@ -630,27 +634,28 @@ static int panel_res_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int
     // update of the step before (64 x n = 8192: 0.213 -> 0.199 s with two parts, 16 x: 55.0 -> 54.6 ms, 8 x: 29.4 -> 30.8)
     const int64_t nmat = bt ? bt->count : 1;
     const bool two_part = nmat > 1 ? rows * nmat > env_i64("GPX_POTRF_TWO_PART_BATCH", 98304) : rows > two_part_rows;
-    // fp64 leaf (gpx_leaf.h): GPX_LEAF = 4 the one-wave leaf (default for single matrices), 1 the round-3 leaf on four waves.
-    // (The one-wave leaf's instantiation runs ONE workgroup per CU -- 355 registers a lane: its 20 accumulator tiles -- which a
-    //  single matrix's panels never notice (at most 256 workgroups per launch) but a lock-step batch's would: batches keep 1.)
+    // fp64 leaf (gpx_leaf.h): GPX_LEAF = 4 the two-wave leaf without barriers (default for single matrices' short panels), 1 the
+    // round-3 leaf on four waves.  (The LV = 4 instantiation runs ONE workgroup per CU -- its accumulator tiles and 107 KB of
+    // LDS -- which a single matrix's panels never notice (at most 256 workgroups per launch) but a lock-step batch's would:
+    // batches keep 1.)
     const int64_t excl_rows = env_i64("GPX_PANEL_EXCL_ROWS", 5120);
     const bool idle_chip = potrf_take_idle_chip_hint();        // (always taken: a hint is for ONE launch)
     const bool excl = F64 && !bt && idle_chip && rows <= excl_rows;
     const bool v4 = F64 && env_i64("GPX_LEAF", excl ? 4 : 1) == 4;
     // A CU of its own for every workgroup of a SHORT panel (single matrix, rows <= GPX_PANEL_EXCL_ROWS).  Per-step stamps
-    // of every leaf variant say the same thing (profiles/r04_leaf_steps_*.log): ~1.0 us a step while the diagonal workgroup
-    // has its CU to itself, 3 - 4.5 us while workgroups of the trailing update share it (matrix pipe, issue slots) -- a
-    // panel took 120 us alone and 140 - 230 us beside an update.  The dispatcher cannot be told to keep a CU free, but it
-    // cannot place what does not fit: the one-wave-leaf instantiation holds 355 registers a lane, which keeps the 128 x 128
-    // update kernel (234) off its CUs, and GPX_PANEL_PAD_LDS = 48 KB of unused dynamic LDS on top of its 66 KB leave less
-    // than the 128 x 64 update kernel's 48 KB of the CU's 160.  Panels start on an idle chip, a few us before the update
-    // they run beside (potrf()'s launch order), so they get their CUs and keep them: 115 us a panel in EVERY phase
+    // of every leaf variant say the same thing (profiles/r04_leaf_steps_*.log): a leaf step takes 3 - 4 times longer while
+    // workgroups of the trailing update share the CU (matrix pipe, issue slots) -- a panel took 120 us alone and 140 - 230 us
+    // beside an update.  The dispatcher cannot be told to keep a CU free, but it cannot place what does not fit: the LV = 4
+    // instantiation holds more registers a lane than leave room for the 128 x 128 update kernel (234), and its 107 KB of
+    // static LDS (panel blocks + the leaf's 40 KB of per-step operands) plus GPX_PANEL_PAD_LDS = 8 KB of unused dynamic LDS
+    // leave less than the 128 x 64 update kernel's 48 KB of the CU's 160.  Panels start on an idle chip, a few us before the
+    // update they run beside (potrf()'s launch order), so they get their CUs and keep them: the same panel time in EVERY phase
     // (profiles/r04_timeline_n8192_excl8192.txt).  Each workgroup takes a whole CU from the update for as long as the
     // chain runs, so it pays only while the panel is short: n = 8192 potrf 5.75 -> 5.57 ms with 5120 rows, 5.68 with all
-    // (profiles/r04_ab_exclusive_cus.log).
+    // (profiles/r04_ab_exclusive_cus.log, measured with the first one-wave leaf).
     size_t pad_lds = 0;
     if (v4 && excl) {
-        pad_lds = (size_t)env_i64("GPX_PANEL_PAD_LDS", 48 * 1024);
+        pad_lds = (size_t)env_i64("GPX_PANEL_PAD_LDS", 8 * 1024);
         GPX_TRY(set_max_lds((const void *)panel_res_kernel<T, true, F64 ? 4 : 1>, (int)pad_lds));
     }
 #define GPX_PANEL_LAUNCH_LDS(KERNEL, GRID, W0, DYN)                                                                             \

@@ -44,11 +44,10 @@ elif ls[0] and os.environ.get("GPX_LEAF", "4") in ("2", "3"):
           "(+%d after B2) | wave 3 S5+hand-over %d (+%d after B2) | whole step %d"
           % (ls[1] - ls[0], ls[2] - ls[0], ls[3] - ls[0], ls[4] - ls[0], ls[4] - ls[3], ls[5] - ls[0], ls[5] - ls[3], ls[7] - ls[0]))
 lsx = st.to_host().reshape(-1, 16).astype(np.int64)[2040:2048].ravel()
-if lsx[16]:
-    rt, ct = lsx[16:32], lsx[32:48]
-    print("leaf of workgroup 0, per step (first barrier to first barrier): us " + " ".join("%.2f" % ((rt[i + 1] - rt[i]) / 100.0) for i in range(15)))
-    print("                                          core cycles (from step 1) " + " ".join("%d" % (ct[i + 1] - ct[i]) for i in range(1, 15)))
-    print("   16 steps: %.2f us from the first barrier of step 0 to that of step 15; clock %.2f GHz" % (
-        (rt[15] - rt[0]) / 100.0, (ct[15] - ct[1]) / ((rt[15] - rt[1]) * 10.0)))
+if lsx[16] and lsx[17]:
+    # the one-wave leaf (factor64_wave): [16] / [17] = s_memrealtime (100 MHz) at its start / end, [32] / [33] = s_memtime (core clock)
+    us = (lsx[17] - lsx[16]) / 100.0
+    print("one-wave leaf of workgroup 0: %.2f us for 16 steps = %.2f us a step; %d core cycles a step; clock %.2f GHz" % (
+        us, us / 16, (lsx[33] - lsx[32]) // 16, (lsx[33] - lsx[32]) / (us * 1e3)))
 ends = (s[live, 6] - t0) / 100.0; starts = (s[live, 0] - t0) / 100.0
 print("last start %.1f us, last end %.1f us (workgroup %d)" % (starts.max(), ends.max(), live[ends.argmax()]))
