@@ -298,9 +298,20 @@ __global__ __launch_bounds__(256, LV == 4 ? 1 : 2) void panel_res_kernel(T *__re
         const T *mine = A + (r0 + (int64_t)w * IB) * lda;      // my 64 rows, column 0
         // (LV == 4: the loads of my rows' NEXT 64 columns are issued before this block's products and land under them:
         //  workgroup 0's four short products then follow each other at the matrix pipe's pace -- they are the start of the chain)
+        //  the rows of the diagonal blocks, the other operand, are fetched one block ahead in the same way: a workgroup's 4 x kpre
+        //  products then run at the matrix pipe's pace too -- the last diagonal workgroup's pre-update, 50 us with every
+        //  block's load latency in the open, is what the panel waited for once the leaf was fast)
         constexpr bool PREFETCH = LV == 4;
-        StageRegs<T> nxt;
-        if constexpr (PREFETCH) res_stage_rows_load<T>(mine + (c0 - (int64_t)IB * kpre), (int)lda, nvalid, nxt);
+        StageRegs<T> nxt, nb;
+        const int cmax = future_diag ? (w + 1 < nsteps ? w + 1 : nsteps) : nsteps;        // blocks c < cmax take part
+        int lkc = 0, lc = -1;                                   // the B block (lkc, lc) that is in flight into nb
+        auto advance = [&]() { do { if (++lc >= cmax) { lc = 0; ++lkc; } } while (lkc < kpre && lc == w); };
+        auto bsrc = [&](int kc_, int c_) { return A + (r0 + (int64_t)IB * c_) * lda + (c0 - (int64_t)IB * (kpre - kc_)); };
+        if constexpr (PREFETCH) {
+            res_stage_rows_load<T>(mine + (c0 - (int64_t)IB * kpre), (int)lda, nvalid, nxt);
+            advance();
+            if (lkc < kpre) res_stage_rows_load<T>(bsrc(lkc, lc), (int)lda, IB, nb);
+        }
         for (int kc = 0; kc < kpre; ++kc) {
             const int64_t pc = c0 - (int64_t)IB * (kpre - kc);
             __syncthreads();
@@ -319,7 +330,13 @@ __global__ __launch_bounds__(256, LV == 4 ? 1 : 2) void panel_res_kernel(T *__re
                     continue;
                 }
                 __syncthreads();                                // sA is in; the previous block's sB has been consumed
-                res_stage_rows<T, PT>(A + (r0 + (int64_t)IB * c) * lda + pc, (int)lda, IB, sB);
+                if constexpr (PREFETCH) {
+                    res_stage_rows_store<T, PT>(nb, sB);        // (block (kc, c): the loads were issued in this loop's order)
+                    advance();
+                    if (lkc < kpre) res_stage_rows_load<T>(bsrc(lkc, lc), (int)lda, IB, nb);
+                } else {
+                    res_stage_rows<T, PT>(A + (r0 + (int64_t)IB * c) * lda + pc, (int)lda, IB, sB);
+                }
                 __syncthreads();
                 res_prod<T, PT, true>(sA, sB, acc[c], wave, li, lq);
             }
