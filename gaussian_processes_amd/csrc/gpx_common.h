@@ -98,6 +98,18 @@ struct DeviceGuard {
     ~DeviceGuard() { if (switched && prev >= 0) (void)hipSetDevice(prev); }
 };
 
+// Everything a host thread enqueues through this library shares that thread's grow-only scratch buffers (block inverses and
+// operators of the solves, the panels' hand-off blocks, reduction scratch ...).  Calls on ONE stream are ordered by the stream;
+// a call on ANOTHER stream first waits for the work of the call before it: handles fitted asynchronously back to back from
+// one thread (each on its own stream) would otherwise race on those buffers (seen once as a wrong log_lh in the four-handle
+// test of tests/test_gpu_configs.py, when faster panels changed the overlap).  One event record per API call; nothing is
+// recorded or waited for while a stream is being captured.
+struct StreamTurn {
+    hipStream_t st;
+    explicit StreamTurn(hipStream_t s);
+    ~StreamTurn();
+};
+
 // parameters of a kernel-matrix member, precomputed on the host in f64
 struct KParams {
     double c[6];     // member-specific constants (see gpx_kmat.hip)

@@ -621,6 +621,7 @@ int gpx_d_kmat(int dtype, int kernel, int member, const void *x1, int64_t n, con
 int gpx_d_mean_member(int dtype, int kernel, int member, const void *xo, int64_t m, const void *x,
                       int64_t n, int d, const double *params, const void *alpha, void *out, void *stream)
 {
+    gpx::StreamTurn turn__((hipStream_t)stream);     // (this thread's scratch buffers: one stream at a time, gpx_common.h)
     GPX_TRY(ensure_device());
     GPX_ARG(dtype == GPX_F64 || dtype == GPX_F32, "dtype must be GPX_F64 or GPX_F32");
     GPX_ARG(n >= 0 && m >= 0 && d >= 1, "need n, m >= 0 and d >= 1");
@@ -635,6 +636,7 @@ int gpx_d_mean_member(int dtype, int kernel, int member, const void *xo, int64_t
 int gpx_d_mean(int dtype, int kernel, const void *xo, int64_t m, const void *x, int64_t n, int d,
                const double *params, const void *alpha, void *out, void *stream)
 {
+    gpx::StreamTurn turn__((hipStream_t)stream);     // (this thread's scratch buffers: one stream at a time, gpx_common.h)
     return gpx_d_mean_member(dtype, kernel, GPX_K, xo, m, x, n, d, params, alpha, out, stream);
 }
 

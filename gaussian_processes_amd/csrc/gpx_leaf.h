@@ -576,10 +576,56 @@ __device__ __forceinline__ void w1_steps(F &f, std::integer_sequence<int, Is...>
 // The leaf uses register 0 of the strip MFMAs only, reads other registers of a tile only at the places marked "register 3"
 // below, and keeps every read of a tile behind an anchor that follows its last writer by an MFMA or by 18 wait states.
 typedef double w1_v4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void w1_mfma_acc(w1_v4 &c, double a, double b)             // c += a (16 x 4) . b (4 x 16), accumulators in AGPRs
-{ asm volatile("s_nop 2\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b)); }
-__device__ __forceinline__ w1_v4 w1_mfma_strip(double a, double b)                     // a . b (rows 0 .. 3 = register 0 are what is wanted), b an accumulator register
-{ w1_v4 d; asm volatile("s_nop 2\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(b)); return d; }
+// ACC_A: the tiles live in AGPRs (the one-workgroup-per-CU instantiation, 512 registers a lane) or in VGPRs (the two-per-CU
+// instantiation: with 256 registers a lane, AGPRs set aside for the leaf would be taken from the whole kernel)
+template <bool ACC_A>
+__device__ __forceinline__ void w1_mfma_acc(w1_v4 &c, double a, double b)             // c += a (16 x 4) . b (4 x 16)
+{
+    if constexpr (ACC_A) asm volatile("s_nop 2\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    else asm volatile("s_nop 2\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+template <bool ACC_A>
+__device__ __forceinline__ w1_v4 w1_mfma_strip(double a, double b)                     // a . b (rows 0 .. 3 = register 0 are what is wanted), b a register of a tile
+{
+    w1_v4 d;
+    if constexpr (ACC_A) asm volatile("s_nop 2\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(b));
+    else asm volatile("s_nop 2\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// anchors on one to four tiles; NOPS: with 18 wait states in front (a register-3 read follows, see above)
+template <bool ACC_A, bool NOPS>
+__device__ __forceinline__ void w1_anchor(w1_v4 &t0)
+{
+    if constexpr (ACC_A && NOPS) asm volatile("s_nop 15\n\ts_nop 1" : "+a"(t0));
+    if constexpr (ACC_A && !NOPS) asm volatile("" : "+a"(t0));
+    if constexpr (!ACC_A && NOPS) asm volatile("s_nop 15\n\ts_nop 1" : "+v"(t0));
+    if constexpr (!ACC_A && !NOPS) asm volatile("" : "+v"(t0));
+}
+template <bool ACC_A, bool NOPS>
+__device__ __forceinline__ void w1_anchor(w1_v4 &t0, w1_v4 &t1)
+{
+    if constexpr (ACC_A && NOPS) asm volatile("s_nop 15\n\ts_nop 1" : "+a"(t0), "+a"(t1));
+    if constexpr (ACC_A && !NOPS) asm volatile("" : "+a"(t0), "+a"(t1));
+    if constexpr (!ACC_A && NOPS) asm volatile("s_nop 15\n\ts_nop 1" : "+v"(t0), "+v"(t1));
+    if constexpr (!ACC_A && !NOPS) asm volatile("" : "+v"(t0), "+v"(t1));
+}
+template <bool ACC_A, bool NOPS>
+__device__ __forceinline__ void w1_anchor(w1_v4 &t0, w1_v4 &t1, w1_v4 &t2)
+{
+    if constexpr (ACC_A && NOPS) asm volatile("s_nop 15\n\ts_nop 1" : "+a"(t0), "+a"(t1), "+a"(t2));
+    if constexpr (ACC_A && !NOPS) asm volatile("" : "+a"(t0), "+a"(t1), "+a"(t2));
+    if constexpr (!ACC_A && NOPS) asm volatile("s_nop 15\n\ts_nop 1" : "+v"(t0), "+v"(t1), "+v"(t2));
+    if constexpr (!ACC_A && !NOPS) asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2));
+}
+template <bool ACC_A, bool NOPS>
+__device__ __forceinline__ void w1_anchor(w1_v4 &t0, w1_v4 &t1, w1_v4 &t2, w1_v4 &t3)
+{
+    if constexpr (ACC_A && NOPS) asm volatile("s_nop 15\n\ts_nop 1" : "+a"(t0), "+a"(t1), "+a"(t2), "+a"(t3));
+    if constexpr (ACC_A && !NOPS) asm volatile("" : "+a"(t0), "+a"(t1), "+a"(t2), "+a"(t3));
+    if constexpr (!ACC_A && NOPS) asm volatile("s_nop 15\n\ts_nop 1" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
+    if constexpr (!ACC_A && !NOPS) asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
+}
+
 // ---- the leaf itself: TWO waves of the diagonal workgroup ----
 // sM: the block, row-major, lower triangle valid (pitch PT).  On return sM holds L (lower; entries above the diagonal are
 // not written) and sW holds W = inv(L) (all 64 x 64, zeros above the diagonal).  Waves 0 and 1 of the workgroup call this
@@ -602,21 +648,27 @@ __device__ __forceinline__ w1_v4 w1_mfma_strip(double a, double b)              
 //   * only the tile row of the strip needs a mask on its A operand (rows already final), one select;
 //   * finished strips go to LDS at once from the registers the MFMA left them in (nothing is copied back into the tiles).
 constexpr int W1_SLOTS = 5;                                        // per step and lane: aw, then the update operands of tile rows jn .. 3
-constexpr int W1_BUF_DOUBLES = (IB / 4) * W1_SLOTS * 64;          // 40 KB
+constexpr int W1_BUF_DOUBLES = (IB / 4) * W1_SLOTS * 64;          // 40 KB (a slot per step; RING * W1_SLOTS * 64 with a ring)
 
 __device__ __forceinline__ unsigned w1_lds_addr(const void *p)
 {
     return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void *)p;
 }
 
-template <int PT, int STAMP_STEP = -1>
-__device__ __forceinline__ void factor64_wave(double (*sM)[PT], double (*sW)[PT], double *sBuf, int *sStep, int role, int64_t j0,
+// RING: the number of steps the operand buffer holds (sBuf: RING * W1_SLOTS * 64 doubles).  IB / 4 = 16: every step has its own
+// slot and wave 0 never waits for wave 1; 4 (10 KB, for the instantiation that runs two workgroups a CU): wave 0 looks at wave 1's
+// counter (sCtl[1]: steps whose operands it has taken) before it reuses a slot.  sCtl[0] / sCtl[1] must be 0 on entry.
+template <int PT, int RING = IB / 4, int STAMP_STEP = -1>
+__device__ __forceinline__ void factor64_wave(double (*sM)[PT], double (*sW)[PT], double *sBuf, int *sCtl, int role, int64_t j0,
                                               int *__restrict__ info, int lane, unsigned long long *stamps = nullptr)
 {
     typedef w1_v4 v4;
+    static_assert(RING >= 2 && RING <= IB / 4, "ring of 2 .. 16 steps");
+    constexpr bool ACC_A = RING == IB / 4;                      // (the instantiation with a slot per step is the one with 512 registers a lane)
     const int li = lane & 15, lq = lane >> 4;
     double (*buf)[W1_SLOTS][64] = reinterpret_cast<double (*)[W1_SLOTS][64]>(sBuf);
-    unsigned step_addr = w1_lds_addr(sStep);          // (not const: the step lambdas capture it)
+    unsigned step_addr = w1_lds_addr(sCtl);           // (not const: the step lambdas capture it)
+    unsigned done_addr = w1_lds_addr(sCtl + 1);
     if (role == 1) {
         // ================= wave 1: Y = U^-T = L^-1 by the same row operations, from wave 0's operands =================
         v4 Y[10];                          // -Y tiles: Y(ti, tj'), ti >= tj', stored at w1_tix(tj', ti)
@@ -635,25 +687,27 @@ __device__ __forceinline__ void factor64_wave(double (*sM)[PT], double (*sW)[PT]
             do {
                 asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen) : "v"(step_addr) : "memory");
             } while (seen <= jt);
-            const double aw = buf[jt][0][lane];
+            double aw = buf[jt % RING][0][lane];
             double au[4];
 #pragma unroll
-            for (int ti = jn; ti < 4; ++ti) au[ti] = buf[jt][1 + ti - jn][lane];
+            for (int ti = jn; ti < 4; ++ti) au[ti] = buf[jt % RING][1 + ti - jn][lane];
+            if constexpr (RING < IB / 4)                          // the slot is free again once these loads have landed
+                asm volatile("s_waitcnt lgkmcnt(0)\n\tds_write_b32 %1, %2" : "+v"(aw) : "v"(done_addr), "v"(jt + 1) : "memory");
             // (register 3: the tiles of row jj0 were last written by the previous step's updates, possibly by its very last
             //  MFMA; the poll and the loads above are two LDS round trips, the 18 wait states are on top for q == 3)
             if constexpr (q == 3) {
-                if constexpr (jj0 == 0) asm volatile("s_nop 15\n\ts_nop 1" : "+a"(Y[w1_tix(0, 0)]));
-                if constexpr (jj0 == 1) asm volatile("s_nop 15\n\ts_nop 1" : "+a"(Y[w1_tix(0, 1)]), "+a"(Y[w1_tix(1, 1)]));
-                if constexpr (jj0 == 2) asm volatile("s_nop 15\n\ts_nop 1" : "+a"(Y[w1_tix(0, 2)]), "+a"(Y[w1_tix(1, 2)]), "+a"(Y[w1_tix(2, 2)]));
-                if constexpr (jj0 == 3) asm volatile("s_nop 15\n\ts_nop 1" : "+a"(Y[w1_tix(0, 3)]), "+a"(Y[w1_tix(1, 3)]), "+a"(Y[w1_tix(2, 3)]), "+a"(Y[w1_tix(3, 3)]));
+                if constexpr (jj0 == 0) w1_anchor<ACC_A, true>(Y[w1_tix(0, 0)]);
+                if constexpr (jj0 == 1) w1_anchor<ACC_A, true>(Y[w1_tix(0, 1)], Y[w1_tix(1, 1)]);
+                if constexpr (jj0 == 2) w1_anchor<ACC_A, true>(Y[w1_tix(0, 2)], Y[w1_tix(1, 2)], Y[w1_tix(2, 2)]);
+                if constexpr (jj0 == 3) w1_anchor<ACC_A, true>(Y[w1_tix(0, 3)], Y[w1_tix(1, 3)], Y[w1_tix(2, 3)], Y[w1_tix(3, 3)]);
             }
             v4 ys[4];
 #pragma unroll
-            for (int tj = 0; tj <= jj0; ++tj) ys[tj] = w1_mfma_strip(aw, Y[w1_tix(tj, jj0)][q]);
+            for (int tj = 0; tj <= jj0; ++tj) ys[tj] = w1_mfma_strip<ACC_A>(aw, Y[w1_tix(tj, jj0)][q]);
 #pragma unroll
             for (int ti = jn; ti < 4; ++ti)
 #pragma unroll
-                for (int tj = 0; tj <= jj0; ++tj) w1_mfma_acc(Y[w1_tix(tj, ti)], au[ti], ys[tj][0]);
+                for (int tj = 0; tj <= jj0; ++tj) w1_mfma_acc<ACC_A>(Y[w1_tix(tj, ti)], au[ti], ys[tj][0]);
             // (an LDS store of register 0 needs 4 wait states behind the MFMA; the anchor provides 8)
             if constexpr (jj0 == 0) asm volatile("s_nop 7" : "+v"(ys[0]));
             if constexpr (jj0 == 1) asm volatile("s_nop 7" : "+v"(ys[0]), "+v"(ys[1]));
@@ -720,7 +774,7 @@ __device__ __forceinline__ void factor64_wave(double (*sM)[PT], double (*sW)[PT]
         for (int c = 0; c <= k; ++c) aw_next = (li == k && lq == c) ? -wi[k][c] : aw_next;
     };
     // anchors: the values a stage hands to the next one pass through an empty volatile asm, which sits in the MFMAs' order
-    auto anchor_tile = [&](v4 &t) { asm volatile("" : "+a"(t)); };
+    auto anchor_tile = [&](v4 &t) { w1_anchor<ACC_A, false>(t); };
     auto anchor_d = [&]() {
         asm volatile("" : "+s"(d[0][0]), "+s"(d[1][0]), "+s"(d[2][0]), "+s"(d[3][0]), "+s"(d[1][1]), "+s"(d[2][1]), "+s"(d[3][1]),
                           "+s"(d[2][2]), "+s"(d[3][2]), "+s"(d[3][3]));
@@ -751,22 +805,22 @@ __device__ __forceinline__ void factor64_wave(double (*sM)[PT], double (*sW)[PT]
         // (register 3: the strips read register q of the tiles of row jj0; their last writers are the previous step's critical
         //  update and the first of its deferred updates, each followed by another MFMA or by the whole pivot chain -- the anchor
         //  keeps hipcc's copies of those registers from moving up behind the writer)
-        if constexpr (jj0 == 0) asm volatile("" : "+a"(T[w1_tix(0, 0)]), "+a"(T[w1_tix(0, 1)]), "+a"(T[w1_tix(0, 2)]), "+a"(T[w1_tix(0, 3)]));
-        if constexpr (jj0 == 1) asm volatile("" : "+a"(T[w1_tix(1, 1)]), "+a"(T[w1_tix(1, 2)]), "+a"(T[w1_tix(1, 3)]));
-        if constexpr (jj0 == 2) asm volatile("" : "+a"(T[w1_tix(2, 2)]), "+a"(T[w1_tix(2, 3)]));
-        if constexpr (jj0 == 3) asm volatile("" : "+a"(T[w1_tix(3, 3)]));
+        if constexpr (jj0 == 0) w1_anchor<ACC_A, false>(T[w1_tix(0, 0)], T[w1_tix(0, 1)], T[w1_tix(0, 2)], T[w1_tix(0, 3)]);
+        if constexpr (jj0 == 1) w1_anchor<ACC_A, false>(T[w1_tix(1, 1)], T[w1_tix(1, 2)], T[w1_tix(1, 3)]);
+        if constexpr (jj0 == 2) w1_anchor<ACC_A, false>(T[w1_tix(2, 2)], T[w1_tix(2, 3)]);
+        if constexpr (jj0 == 3) w1_anchor<ACC_A, false>(T[w1_tix(3, 3)]);
         // ---- critical pair ----
         mark(0);
-        us[ct] = w1_mfma_strip(aw, T[w1_tix(jj0, ct)][q]);
+        us[ct] = w1_mfma_strip<ACC_A>(aw, T[w1_tix(jj0, ct)][q]);
         if constexpr (q < 3) am = (li > 4 * q + 3) ? us[jj0][0] : 0.0;   // A operand for the strip's own tile row: rows up to the strip are final
-        if constexpr (!last) w1_mfma_acc(T[w1_tix(jn, jn)], jn == jj0 ? am : us[jn][0], us[jn][0]);
+        if constexpr (!last) w1_mfma_acc<ACC_A>(T[w1_tix(jn, jn)], jn == jj0 ? am : us[jn][0], us[jn][0]);
         // ---- deferred: ordinals [from, to) of: the other strips, the updates (row-major: the next step's tile row first) ----
         auto defer = [&](int from, int to) {
             int k = 0;
 #pragma unroll
             for (int tj = jj0; tj < 4; ++tj) {
                 if (tj == ct) continue;
-                if (k >= from && k < to) us[tj] = w1_mfma_strip(aw, T[w1_tix(jj0, tj)][q]);
+                if (k >= from && k < to) us[tj] = w1_mfma_strip<ACC_A>(aw, T[w1_tix(jj0, tj)][q]);
                 ++k;
             }
             if constexpr (!last) {
@@ -775,7 +829,7 @@ __device__ __forceinline__ void factor64_wave(double (*sM)[PT], double (*sW)[PT]
 #pragma unroll
                     for (int tj = ti; tj < 4; ++tj) {
                         if (ti == jn && tj == jn) continue;
-                        if (k >= from && k < to) w1_mfma_acc(T[w1_tix(ti, tj)], ti == jj0 ? am : us[ti][0], us[tj][0]);
+                        if (k >= from && k < to) w1_mfma_acc<ACC_A>(T[w1_tix(ti, tj)], ti == jj0 ? am : us[ti][0], us[tj][0]);
                         ++k;
                     }
             }
@@ -787,10 +841,16 @@ __device__ __forceinline__ void factor64_wave(double (*sM)[PT], double (*sW)[PT]
             if constexpr (jj0 == 1) asm volatile("s_nop 4" : "+v"(us[1]), "+v"(us[2]), "+v"(us[3]));
             if constexpr (jj0 == 2) asm volatile("s_nop 4" : "+v"(us[2]), "+v"(us[3]));
             if constexpr (jj0 == 3) asm volatile("s_nop 4" : "+v"(us[3]));
-            buf[jt][0][lane] = aw;
+            if constexpr (RING < IB / 4 && jt >= RING) {          // wave 1 has taken the operands of step jt - RING?
+                int taken;
+                do {
+                    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(taken) : "v"(done_addr) : "memory");
+                } while (taken < jt - RING + 1);
+            }
+            buf[jt % RING][0][lane] = aw;
             if constexpr (!last) {
 #pragma unroll
-                for (int ti = jn; ti < 4; ++ti) buf[jt][1 + ti - jn][lane] = (ti == jj0) ? am : us[ti][0];
+                for (int ti = jn; ti < 4; ++ti) buf[jt % RING][1 + ti - jn][lane] = (ti == jj0) ? am : us[ti][0];
             }
             asm volatile("ds_write_b32 %0, %1" : : "v"(flag_addr), "v"(jt + 1) : "memory");
         };
@@ -800,7 +860,7 @@ __device__ __forceinline__ void factor64_wave(double (*sM)[PT], double (*sW)[PT]
             mark(2);
             // (register 3: the gather reads register (jt + 1) & 3 of the tile the critical update has just written; one deferred
             //  MFMA in between is enough, the last steps have none)
-            if constexpr (((jt + 1) & 3) == 3 && defer_count == 0) asm volatile("s_nop 15\n\ts_nop 1" : "+a"(T[w1_tix(jn, jn)]));
+            if constexpr (((jt + 1) & 3) == 3 && defer_count == 0) w1_anchor<ACC_A, true>(T[w1_tix(jn, jn)]);
             else anchor_tile(T[w1_tix(jn, jn)]);
             gather(jt + 1);
             anchor_d();

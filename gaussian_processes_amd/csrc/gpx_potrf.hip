@@ -729,6 +729,7 @@ extern "C" {
 
 int gpx_d_potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, void *stream)
 {
+    gpx::StreamTurn turn__((hipStream_t)stream);     // (this thread's scratch buffers: one stream at a time, gpx_common.h)
     GPX_TRY(ensure_device());
     GPX_ARG(dtype == GPX_F64 || dtype == GPX_F32, "dtype must be GPX_F64 or GPX_F32");
     GPX_ARG(n >= 0, "n < 0");
@@ -756,6 +757,7 @@ int gpx_d_tril(int dtype, void *A, int64_t n, int64_t lda, void *stream)
 extern "C" int gpx_d_potrf_panel(int dtype, void *A, int64_t lda, int64_t n, int64_t r0, int64_t c0,
                                  int64_t kb, int *info_dev, void *stream)
 {
+    gpx::StreamTurn turn__((hipStream_t)stream);     // (this thread's scratch buffers: one stream at a time, gpx_common.h)
     GPX_TRY(ensure_device());
     GPX_ARG(dtype == GPX_F64 || dtype == GPX_F32, "dtype must be GPX_F64 or GPX_F32");
     GPX_ARG(n >= 0 && r0 >= 0 && c0 >= 0 && kb >= 0 && r0 + kb <= n, "bad dimensions");

@@ -113,6 +113,39 @@ int set_max_lds(const void *fn, int bytes)
 
 using namespace gpx;
 
+// ---- StreamTurn (gpx_common.h): one turn at a time for the streams a host thread drives ----
+namespace gpx {
+struct TurnState { hipEvent_t ev = nullptr; hipStream_t last = nullptr; bool have = false; };
+static thread_local TurnState g_turn[16];                      // per device
+
+static TurnState *turn_state()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return (dev >= 0 && dev < 16) ? &g_turn[dev] : nullptr;
+}
+static bool capturing(hipStream_t st)
+{
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return cs != hipStreamCaptureStatusNone;
+}
+StreamTurn::StreamTurn(hipStream_t s) : st(s)
+{
+    TurnState *t = turn_state();
+    if (!t || !t->have || t->last == st || capturing(st)) return;
+    if (hipStreamWaitEvent(st, t->ev, 0) != hipSuccess) (void)hipGetLastError();
+}
+StreamTurn::~StreamTurn()
+{
+    TurnState *t = turn_state();
+    if (!t || capturing(st)) return;
+    if (!t->ev && hipEventCreateWithFlags(&t->ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); t->ev = nullptr; return; }
+    if (hipEventRecord(t->ev, st) == hipSuccess) { t->last = st; t->have = true; }
+    else (void)hipGetLastError();
+}
+}  // namespace gpx
+
 extern "C" {
 
 int gpx_version(void) { return GPX_VERSION; }

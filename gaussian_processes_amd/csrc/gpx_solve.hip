@@ -1046,6 +1046,7 @@ extern "C" {
 int gpx_d_trsv_lower(int dtype, const void *L, int64_t n, int64_t ldl, void *b, void *x,
                      int transpose, void *stream)
 {
+    gpx::StreamTurn turn__((hipStream_t)stream);     // (this thread's scratch buffers: one stream at a time, gpx_common.h)
     GPX_TRY(ensure_device());
     GPX_ARG(dtype == GPX_F64 || dtype == GPX_F32, "dtype must be GPX_F64 or GPX_F32");
     GPX_ARG(n >= 0, "n < 0");
@@ -1058,6 +1059,7 @@ int gpx_d_trsv_lower(int dtype, const void *L, int64_t n, int64_t ldl, void *b, 
 int gpx_d_trsm_right_lt(int dtype, const void *L, int64_t n, int64_t ldl, void *X, int64_t m,
                         int64_t ldx, void *stream)
 {
+    gpx::StreamTurn turn__((hipStream_t)stream);     // (this thread's scratch buffers: one stream at a time, gpx_common.h)
     GPX_TRY(ensure_device());
     GPX_ARG(dtype == GPX_F64 || dtype == GPX_F32, "dtype must be GPX_F64 or GPX_F32");
     GPX_ARG(n >= 0 && m >= 0, "negative dimension");
@@ -1092,6 +1094,7 @@ extern "C" {
 int gpx_d_trsv_lower_cols(int dtype, const void *L, int64_t n, int64_t ldl, int64_t ncols, void *b,
                           void *x, void *stream)
 {
+    gpx::StreamTurn turn__((hipStream_t)stream);     // (this thread's scratch buffers: one stream at a time, gpx_common.h)
     GPX_TRY(ensure_device());
     GPX_ARG(dtype == GPX_F64 || dtype == GPX_F32, "dtype must be GPX_F64 or GPX_F32");
     GPX_ARG(n >= 0 && ncols >= 0 && ncols <= n, "need 0 <= ncols <= n");

@@ -612,16 +612,18 @@ def test_mlii_batch_matches_oracle_and_reference_conventions():
     i, th, best = mlii.best_restart(X, y, thetas)
     assert i == int(np.argmax(llh[:6])) and best == llh[i]
     # the row-at-a-time route (one fit per row) and several handles at once (one host thread each) give the
-    # same table as the default lock-step batched route.  Round 4: single matrices of up to 5120 rows take the one-wave leaf,
-    # batches keep the four-wave one -- same factorisation, different rounding inside the 64 x 64 leaves: equal to a few ulp
-    # by default, and bit for bit when both routes are told to use the same leaf (same kernels, same summation order)
+    # same table as the default lock-step batched route, bit for bit: single matrices and batches run the same leaf
+    # (gpx_leaf.h factor64_wave; two instantiations of the panel kernel, same arithmetic in the same order) -- and again
+    # when both routes are told to use the round-3 leaf
     llh1 = mlii.log_lh_batch(X, y, thetas, batched=False)
-    np.testing.assert_allclose(llh1, llh, rtol=1e-13)
+    np.testing.assert_array_equal(llh1, llh)
     llh3 = mlii.log_lh_batch(X, y, thetas, batched=False, concurrency=3)
     np.testing.assert_array_equal(llh3, llh1)
     os.environ["GPX_LEAF"] = "1"
     try:
-        np.testing.assert_array_equal(mlii.log_lh_batch(X, y, thetas, batched=False), llh)
+        b1 = mlii.log_lh_batch(X, y, thetas)
+        np.testing.assert_array_equal(mlii.log_lh_batch(X, y, thetas, batched=False), b1)
+        np.testing.assert_allclose(b1, llh, rtol=1e-13)
     finally:
         del os.environ["GPX_LEAF"]
 

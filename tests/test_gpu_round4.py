@@ -162,25 +162,29 @@ def test_soak_repeat_fits_are_bitwise_identical(monkeypatch, n, dtype):
         assert _residual(X, y, a0, h, w, s, rows) < (1e-9 if f64 else 2e-3)
 
 
-# ------------------------------------------------- the round-4 leaf (pivot lane ahead) --
+# ------------------------------------------------- the round-4 leaf (two waves, MFMAs in a fixed order) --
 @pytest.mark.parametrize("N", [64, 130, 700, 1990, 4171])
 def test_fp64_leaves_vs_oracle_and_each_other(monkeypatch, N):
     """The fp64 resident panel kernel has two leaves for the 64 x 64 diagonal block (gpx_leaf.h, GPX_LEAF):
-      4 (default for single matrices)  factor64_wave: ONE wave factors the TRANSPOSE held in accumulator tiles -- a strip's
-                   registers serve as MFMA A and B operands as they are -- without LDS or barriers inside its 16 steps;
-      1            factor64_mfma (round 3; lock-step batches): four waves, three barriers and five LDS round trips a step.
-    Both against the oracle's factor, log_lh, alpha and explicit inverse (W = inv(L_jj) of every leaf feeds it), and against
-    each other (they differ in rounding only)."""
+      4 / 5        factor64_wave: wave 0 factors the TRANSPOSE held in accumulator tiles -- a strip's registers serve as MFMA
+                   A and B operands as they are -- its MFMAs issued from asm in a fixed order between the stages of the pivot
+                   arithmetic; wave 1 follows with the inverse from operands left in LDS.  4: one workgroup a CU, tiles in
+                   AGPRs, a slot per step (single matrices up to 8192 rows); 5: two workgroups a CU, tiles in VGPRs, a ring
+                   of four slots (everything else in fp64);
+      1            factor64_mfma (round 3): four waves, three barriers and five LDS round trips a step.
+    All three against the oracle's factor, log_lh, alpha and explicit inverse (W = inv(L_jj) of every leaf feeds it), and
+    against each other (they differ in rounding only)."""
     d = 3
     X, y, Xo = orc.synth_inputs(N, d, 16)
     h, w, s = 1.0, 0.5 * np.sqrt(d), 0.9
     o = orc.OracleGP("gaussian", (h, w), X, y, s)
     out = {}
-    for label, env in (("one_wave", None), ("four_waves", "1")):
-        if env is None:
-            monkeypatch.delenv("GPX_LEAF", raising=False)
-        else:
-            monkeypatch.setenv("GPX_LEAF", env)
+    routes = (("two_waves_lv4", {}), ("two_waves_lv5", {"GPX_LEAF4_ROWS": "0", "GPX_PANEL_EXCL_ROWS": "0"}), ("four_waves", {"GPX_LEAF": "1"}))
+    for label, env in routes:
+        for k in ("GPX_LEAF", "GPX_LEAF4_ROWS", "GPX_PANEL_EXCL_ROWS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
         g = gp.GP(gp.GaussianKernel(h, w), X, y, s=s)
         out[label] = (float(g.log_lh), np.array(g.Lxx), np.array(g.inv_Kxx_y), np.array(g.inv_Kxx) if N <= 700 else None)
         np.testing.assert_allclose(out[label][0], o.log_lh, rtol=1e-10, err_msg=label)
@@ -188,17 +192,58 @@ def test_fp64_leaves_vs_oracle_and_each_other(monkeypatch, N):
         np.testing.assert_allclose(out[label][2], o.inv_Kxx_y, rtol=1e-8, atol=1e-11, err_msg=label)
         if N <= 700:
             np.testing.assert_allclose(out[label][3], o.inv_Kxx, rtol=1e-7, atol=1e-10, err_msg=label)
-    monkeypatch.delenv("GPX_LEAF", raising=False)
-    np.testing.assert_allclose(np.tril(out["one_wave"][1]), np.tril(out["four_waves"][1]), rtol=1e-11, atol=1e-13)
-    # a lock-step batch may take the one-wave leaf too (GPX_LEAF=4 forces it): same values
+    for k in ("GPX_LEAF", "GPX_LEAF4_ROWS", "GPX_PANEL_EXCL_ROWS"):
+        monkeypatch.delenv(k, raising=False)
+    np.testing.assert_allclose(np.tril(out["two_waves_lv4"][1]), np.tril(out["four_waves"][1]), rtol=1e-11, atol=1e-13)
+    # the two instantiations of the two-wave leaf do the same arithmetic in the same order
+    np.testing.assert_array_equal(np.tril(out["two_waves_lv4"][1]), np.tril(out["two_waves_lv5"][1]))
+    # lock-step batches take the LV = 5 instantiation by default; GPX_LEAF = 1 / 4 force the others: same values
     from gaussian_processes_amd import mlii
     thetas = np.array([[h, w, s], [0.8, 1.1, 1.2]])
+    b5 = mlii.log_lh_batch(X, y, thetas)
+    monkeypatch.setenv("GPX_LEAF", "1")
     b1 = mlii.log_lh_batch(X, y, thetas)
     monkeypatch.setenv("GPX_LEAF", "4")
     b4 = mlii.log_lh_batch(X, y, thetas)
     monkeypatch.delenv("GPX_LEAF", raising=False)
-    np.testing.assert_allclose(b1[0], o.log_lh, rtol=1e-10)
-    np.testing.assert_allclose(b4, b1, rtol=1e-12)
+    np.testing.assert_allclose(b5[0], o.log_lh, rtol=1e-10)
+    np.testing.assert_allclose(b1, b5, rtol=1e-12)
+    np.testing.assert_array_equal(b4, b5)
+
+
+def test_async_fits_of_several_handles_on_one_thread_take_turns():
+    """Handles fitted asynchronously back to back from ONE host thread run on their own streams but share that thread's
+    scratch buffers (block inverses of the solves, solve operators, the panels' hand-off blocks): a call on another stream
+    waits for the call before it (StreamTurn, csrc/gpx_common.h).  Four handles with different data and sizes, fits enqueued
+    without a synchronisation in between, every log_lh and alpha equal to the value of the same handle fitted alone."""
+    lib = _lib.load()
+    sizes = [256, 1000, 1990, 640]
+    hs, alone = [], []
+    try:
+        for k, N in enumerate(sizes):
+            d = 2 + k
+            X, y, _ = orc.synth_inputs(N, d, 4, seed=30 + k)
+            prm = np.array([1.0 + 0.1 * k, 0.6 * np.sqrt(d)])
+            h = ctypes.c_void_p()
+            _lib.check(lib.gpx_gp_create(ctypes.byref(h), _lib.F64, _lib.KERNEL_GAUSSIAN, N, d))
+            _lib.check(lib.gpx_gp_set_data(h, _lib.dptr(np.ascontiguousarray(X)), _lib.dptr(np.ascontiguousarray(y))))
+            _lib.check(lib.gpx_gp_set_params(h, _lib.dptr(prm), 0.9))
+            hs.append(h)
+            _lib.check(lib.gpx_gp_fit(h, None))
+            v = ctypes.c_double(0.0)
+            _lib.check(lib.gpx_gp_log_lh(h, ctypes.byref(v)))                     # (synchronises: this handle alone)
+            np.testing.assert_allclose(v.value, orc.OracleGP("gaussian", prm, X, y, 0.9).log_lh, rtol=1e-10)
+            alone.append(v.value)
+        for rep in range(40):
+            for h in hs:
+                _lib.check(lib.gpx_gp_fit(h, None))                               # enqueue only: four streams
+            for h, r in zip(hs, alone):
+                v = ctypes.c_double(0.0)
+                _lib.check(lib.gpx_gp_log_lh(h, ctypes.byref(v)))
+                assert v.value == r, (rep, v.value, r)
+    finally:
+        for h in hs:
+            lib.gpx_gp_destroy(h)
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])

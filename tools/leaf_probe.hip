@@ -1,6 +1,6 @@
 // tools/leaf_probe.hip -- the one-wave 64 x 64 leaf (csrc/gpx_leaf.h, factor64_wave) alone: L and W = inv(L) of a random SPD block
 // against a host Cholesky, and the leaf's duration in core cycles (s_memtime) with the CU to itself.  diagnostic.
-// build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -Igaussian_processes_amd/csrc tools/leaf_probe.hip -o tools/leaf_probe
+// build: hipcc -O3 -std=c++17 --offload-arch=gfx950 [-DSTAMP=<step>] [-DPROBE_RING=4] -Igaussian_processes_amd/csrc tools/leaf_probe.hip -o tools/leaf_probe
 #include "gpx_leaf.h"
 #include <cstdio>
 #include <cmath>
@@ -10,16 +10,19 @@ constexpr int PT = 66;
 #ifndef STAMP
 #define STAMP -1
 #endif
+#ifndef PROBE_RING
+#define PROBE_RING 16
+#endif
 __global__ __launch_bounds__(256, 1) void k(const double *A, double *L, double *W, int *info, unsigned long long *st, int reps)
 {
     __shared__ double sA[64][PT], sB[64][PT], sBuf[W1_BUF_DOUBLES];
-    __shared__ int sStep;
+    __shared__ int sCtl[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int rep = 0; rep < reps; ++rep) {
         for (int i = tid; i < 64 * 64; i += 256) { sA[i / 64][i % 64] = A[i]; sB[i / 64][i % 64] = -7.0; }
-        if (tid == 0) sStep = 0;
+        if (tid < 2) sCtl[tid] = 0;
         __syncthreads();
-        if (wave < 2) factor64_wave<PT, STAMP>(sA, sB, sBuf, &sStep, wave, 0, info, lane, st);
+        if (wave < 2) factor64_wave<PT, PROBE_RING, STAMP>(sA, sB, sBuf, sCtl, wave, 0, info, lane, st);
         __syncthreads();
         if (tid == 0) st[50] = __builtin_amdgcn_s_memtime();
     }

@@ -1,0 +1,6 @@
+#!/bin/bash
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+for e in "GPX_X=0" "GPX_X=1" "GPX_LEAF4_ROWS=0"; do
+  echo "== $e"; env $e timeout -k 10 400 python -m pytest tests/test_gpu_configs.py -m gpu -q -p no:cacheprovider 2>&1 | grep -E "passed|failed|ACTUAL|DESIRED|^FAILED"
+done

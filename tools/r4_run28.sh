@@ -1,0 +1,9 @@
+#!/bin/bash
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+timeout -k 10 300 python -m pytest tests/test_gpu_parity.py -m gpu -q -p no:cacheprovider -k "mlii or batch" 2>&1 | tail -3
+for rep in 1 2; do
+  for e in "GPX_LEAF=5" "GPX_LEAF=1"; do echo "== $e"; env $e timeout -k 10 200 python tools/r3_batch8.py || exit 1; done
+done
+for n in 12288 16384; do timeout -k 10 400 bash tools/r4_ab_sized.sh $n 8 f64 2 "GPX_LEAF=5" "GPX_LEAF=1" || exit 1; done
+timeout -k 10 600 bash tools/r4_ab_sized.sh 65536 32 f64 1 "GPX_LEAF=5" "GPX_LEAF=1" || exit 1
