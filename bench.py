@@ -313,6 +313,7 @@ def secondary_measurements(args, lib, _lib, local_rank, headline):
     """The other BASELINE.json configs and the drop-in API path on the driver's clock, same process, after the timed
     headline region (a list; every entry names its config):
       configs[1]  N=8192  d=8  fp64, m=1024          handle path
+      small_fits  N=2048 / 4096, d=8 fp64            handle path (the reference's own sizes are smaller still)
       configs[2]  N=32768 d=16 fp32, m=1024          handle path, with the fp32 trailing kernel's roofline fraction
       configs[4]  64 (and 8) restarts x N=8192 d=8   one lock-step gpx_gp_fit_batch call (mlii.BatchEvaluator)
       headline workload once more through gp.GP(...).log_lh / .mean(xo) -- the reference's own API"""
@@ -321,6 +322,15 @@ def secondary_measurements(args, lib, _lib, local_rank, headline):
     out.append({"name": "configs[1]", "config": sec["config"]["workload"], "value": sec["value"], "unit": "s",
                 "stages_ms": sec["stages_ms"], "potrf_tflops": sec["potrf_tflops"],
                 "potrf_frac_of_peak": sec["potrf_frac_of_peak"], "log_lh": sec["log_lh"], "check": sec["check"]})
+    # the sizes the reference is used at are smaller still: the latency-bound end of the same path (fp64, d = 8, m = 1024)
+    small = {"name": "small_fits", "unit": "s", "config": "handle path at N=2048 / 4096, d=8, fp64, m=1024 (chain-bound: one resident "
+             "launch per 256-column panel)"}
+    for n_small in (2048, 4096):
+        sm = measure_single(args, lib, _lib, n_small, 8, 1024, _lib.F64, np.float64, 20, 3, local_rank, prof_on=False)
+        small["n%d" % n_small] = {"value": sm["value"], "potrf_ms": sm["stages_ms"]["potrf"], "potrf_tflops": sm["potrf_tflops"],
+                                  "log_lh": sm["log_lh"], "check": sm["check"]}
+    small["value"] = small["n2048"]["value"]
+    out.append(small)
     # (the per-launch HIP events behind `roofline` cost a few per cent at this size: the value is timed without them)
     sec = measure_single(args, lib, _lib, 32768, 16, 1024, _lib.F32, np.float32, 5, 2, local_rank, prof_on=False)
     prof = measure_single(args, lib, _lib, 32768, 16, 1024, _lib.F32, np.float32, 3, 1, local_rank, prof_on=True)

@@ -47,7 +47,7 @@ lsx = st.to_host().reshape(-1, 16).astype(np.int64)[2040:2048].ravel()
 if lsx[16] and lsx[17]:
     # the one-wave leaf (factor64_wave): [16] / [17] = s_memrealtime (100 MHz) at its start / end, [32] / [33] = s_memtime (core clock)
     us = (lsx[17] - lsx[16]) / 100.0
-    print("one-wave leaf of workgroup 0: %.2f us for 16 steps = %.2f us a step; %d core cycles a step; clock %.2f GHz" % (
+    print("leaf of workgroup 0 (wave 0, factor64_wave): %.2f us for 16 steps = %.2f us a step; %d core cycles a step; clock %.2f GHz" % (
         us, us / 16, (lsx[33] - lsx[32]) // 16, (lsx[33] - lsx[32]) / (us * 1e3)))
 ends = (s[live, 6] - t0) / 100.0; starts = (s[live, 0] - t0) / 100.0
 print("last start %.1f us, last end %.1f us (workgroup %d)" % (starts.max(), ends.max(), live[ends.argmax()]))
