@@ -658,8 +658,11 @@ __device__ __forceinline__ unsigned w1_lds_addr(const void *p)
 // RING: the number of steps the operand buffer holds (sBuf: RING * W1_SLOTS * 64 doubles).  IB / 4 = 16: every step has its own
 // slot and wave 0 never waits for wave 1; 4 (10 KB, for the instantiation that runs two workgroups a CU): wave 0 looks at wave 1's
 // counter (sCtl[1]: steps whose operands it has taken) before it reuses a slot.  sCtl[0] / sCtl[1] must be 0 on entry.
-template <int PT, int RING = IB / 4, int STAMP_STEP = -1>
-__device__ __forceinline__ void factor64_wave(double (*sM)[PT], double (*sW)[PT], double *sBuf, int *sCtl, int role, int64_t j0,
+// TS: the type the block is STORED in (sM / sW): double, or float -- the fp32 panel kernel hands its diagonal blocks to this
+// same fp64 leaf (the leaf is latency, not throughput: the chain of 64 dependent pivots costs the same in either precision,
+// and the fp32 factorisation's diagonal blocks come out better than fp32 arithmetic would leave them).
+template <int PT, int RING = IB / 4, int STAMP_STEP = -1, typename TS = double>
+__device__ __forceinline__ void factor64_wave(TS (*sM)[PT], TS (*sW)[PT], double *sBuf, int *sCtl, int role, int64_t j0,
                                               int *__restrict__ info, int lane, unsigned long long *stamps = nullptr)
 {
     typedef w1_v4 v4;
@@ -716,7 +719,7 @@ __device__ __forceinline__ void factor64_wave(double (*sM)[PT], double (*sW)[PT]
 #pragma unroll
             for (int tj = 0; tj < 4; ++tj) {
                 const int row = c0 + lq, col = 16 * tj + li;      // W = Y with zeros right of the diagonal
-                sW[row][col] = (tj <= jj0 && col <= row) ? ys[tj <= jj0 ? tj : 0][0] : 0.0;
+                sW[row][col] = (TS)((tj <= jj0 && col <= row) ? ys[tj <= jj0 ? tj : 0][0] : 0.0);
             }
         };
         w1_steps(ystep, std::make_integer_sequence<int, IB / 4>{});
@@ -734,7 +737,7 @@ __device__ __forceinline__ void factor64_wave(double (*sM)[PT], double (*sW)[PT]
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * ti + lq + 4 * r, col = 16 * tj + li;
-                T[w1_tix(ti, tj)][r] = -(row <= col ? sM[col][row] : sM[row][col]);
+                T[w1_tix(ti, tj)][r] = -(double)(row <= col ? sM[col][row] : sM[row][col]);
             }
     int bad_at = 0;
     double d[4][4], wi[4][4], aw = 0.0, aw_next = 0.0;
@@ -892,7 +895,7 @@ __device__ __forceinline__ void factor64_wave(double (*sM)[PT], double (*sW)[PT]
 #pragma unroll
         for (int tj = jj0; tj < 4; ++tj) {
             const int row = 16 * tj + li, col = c0 + lq;          // U[col][row] = L[row][col]
-            if (col <= row) sM[row][col] = us[tj][0];
+            if (col <= row) sM[row][col] = (TS)us[tj][0];
         }
         aw = aw_next;
         mark(9);

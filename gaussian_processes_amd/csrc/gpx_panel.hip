@@ -477,10 +477,11 @@ __global__ __launch_bounds__(256, LV == 4 ? 1 : 2) void panel_res_kernel(T *__re
             res_prod<T, PT, true>(sA, sB, acc[c], wave, li, lq);
         }
     }
-    if constexpr (LEAF_MFMA && (LV == 4 || LV == 5) && sizeof(T) == 8) {
+    if constexpr (LEAF_MFMA && (LV == 4 || LV == 5)) {
         if (dg_step >= 0) {
             // ---- the diagonal block: the leaf of gpx_leaf.h (factor64_wave): the block is in sA by rows; wave 0 factors it
-            // without a barrier, wave 1 follows it with the inverse; L is left in sA and W = inv(L) in sB ----
+            // without a barrier, wave 1 follows it with the inverse; L is left in sA and W = inv(L) in sB.  (fp32 panels use the
+            // same fp64 leaf: it converts on the way in and out of LDS.) ----
             constexpr int RING = LV == 4 ? IB / 4 : 4;            // LV = 5 runs two workgroups a CU: a 10 KB ring instead of 40 KB
             __shared__ __attribute__((aligned(16))) double sLeaf[RING * W1_SLOTS * 64];   // wave 0's per-step operands for wave 1
             __shared__ int sLeafCtl[2];
@@ -488,19 +489,21 @@ __global__ __launch_bounds__(256, LV == 4 ? 1 : 2) void panel_res_kernel(T *__re
             if (tid < 2) sLeafCtl[tid] = 0;
             __syncthreads();                                      // sA is complete
             if (wave < 2)
-                factor64_wave<PT, RING>(sA, sB, sLeaf, sLeafCtl, wave, r0 + (int64_t)IB * j, info, lane,
-                                        (stamps && w == 0 && blockIdx.y == 0) ? stamps + 2040 * 16 : nullptr);
+                factor64_wave<PT, RING, -1, T>(sA, sB, sLeaf, sLeafCtl, wave, r0 + (int64_t)IB * j, info, lane,
+                                               (stamps && w == 0 && blockIdx.y == 0) ? stamps + 2040 * 16 : nullptr);
             __syncthreads();
-            // publish W: its 10 lower 16 x 16 tiles, 16-byte agent-scope stores (what res_stage_w loads)
+            // publish W: its 10 lower 16 x 16 tiles, 16-byte agent-scope stores (fp64: what res_stage_w loads; fp32: res_stage
+            // loads all 16 tiles, the six above the diagonal are zero since the buffer was cleared)
             T *W = pub + (int64_t)j * (IB * IB);
-            constexpr int UPT = 16 * 8, TOTAL = 10 * UPT;           // 16-byte units per tile (16 rows x 8), lower tiles
+            constexpr int E = 16 / (int)sizeof(T), UPR = 16 / E;   // elements per 16 bytes; units per tile row
+            constexpr int UPT = 16 * UPR, TOTAL = 10 * UPT;         // 16-byte units per tile, lower tiles
 #pragma unroll
             for (int i = 0; i < (TOTAL + 255) / 256; ++i) {
                 const int u = tid + 256 * i;
                 if (u < TOTAL) {
                     const int tile = u / UPT, wq = u % UPT;
                     const int ti = tile < 1 ? 0 : tile < 3 ? 1 : tile < 6 ? 2 : 3, tj = tile - ti * (ti + 1) / 2;
-                    const int row = 16 * ti + wq / 8, col = 16 * tj + (wq % 8) * 2;
+                    const int row = 16 * ti + wq / UPR, col = 16 * tj + (wq % UPR) * E;
                     pub_store16(W + row * IB + col, *reinterpret_cast<const uint4v *>(&sB[row][col]));
                 }
             }
@@ -658,10 +661,10 @@ static int panel_res_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int
     // batches keep 1.)
     const int64_t excl_rows = env_i64("GPX_PANEL_EXCL_ROWS", 5120);
     const bool idle_chip = potrf_take_idle_chip_hint();        // (always taken: a hint is for ONE launch)
-    const bool excl = F64 && !bt && idle_chip && rows <= excl_rows;
+    const bool excl = !bt && idle_chip && rows <= excl_rows;
     // (panels of up to GPX_LEAF4_ROWS rows take the LV = 4 instantiation beside an update too: n = 8192 5.94 -> 5.79 ms; taller
     //  ones lose more CUs to its one-workgroup-per-CU footprint than the leaf gives back: n = 16384 27.85 -> 28.4 ms)
-    const bool v4 = F64 && env_i64("GPX_LEAF", (excl || (!bt && rows <= env_i64("GPX_LEAF4_ROWS", 8192))) ? 4 : 1) == 4;
+    const bool v4 = env_i64("GPX_LEAF", (excl || (!bt && rows <= env_i64("GPX_LEAF4_ROWS", 8192))) ? 4 : 1) == 4;
     // A CU of its own for every workgroup of a SHORT panel (single matrix, rows <= GPX_PANEL_EXCL_ROWS).  Per-step stamps
     // of every leaf variant say the same thing (profiles/r04_leaf_steps_*.log): a leaf step takes 3 - 4 times longer while
     // workgroups of the trailing update share the CU (matrix pipe, issue slots) -- a panel took 120 us alone and 140 - 230 us
@@ -675,8 +678,8 @@ static int panel_res_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int
     // (profiles/r04_ab_exclusive_cus.log, measured with the first one-wave leaf).
     size_t pad_lds = 0;
     if (v4 && excl) {
-        pad_lds = (size_t)env_i64("GPX_PANEL_PAD_LDS", 8 * 1024);
-        GPX_TRY(set_max_lds((const void *)panel_res_kernel<T, true, F64 ? 4 : 1>, (int)pad_lds));
+        pad_lds = (size_t)env_i64("GPX_PANEL_PAD_LDS", F64 ? 8 * 1024 : 40 * 1024);   // (fp32: 75 KB of static LDS)
+        GPX_TRY(set_max_lds((const void *)panel_res_kernel<T, true, 4>, (int)pad_lds));
     }
 #define GPX_PANEL_LAUNCH_LDS(KERNEL, GRID, W0, DYN)                                                                             \
     hipLaunchKernelGGL((KERNEL), GRID, dim3(256), DYN, st, A, lda, n, r0, c0, nsteps, info_dev, (T *)pub, flags, serial,       \
@@ -684,19 +687,20 @@ static int panel_res_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int
 #define GPX_PANEL_LAUNCH(KERNEL, GRID, W0) GPX_PANEL_LAUNCH_LDS(KERNEL, GRID, W0, 0)
     // every other fp64 panel (lock-step batches, panels taller than GPX_LEAF4_ROWS): the same leaf in the LV = 5 instantiation --
     // two workgroups a CU like the round-3 kernel (a 10 KB ring of operand slots instead of 40 KB, no operand prefetch)
-    const bool v5 = F64 && !v4 && env_i64("GPX_LEAF", 5) == 5;
+    // (fp32 panels hand their diagonal blocks to the same fp64 leaf wherever they used the fp32 MFMA leaf: GPX_LEAF=1 keeps that one)
+    const bool v5 = !v4 && env_i64("GPX_LEAF", 5) == 5;
     if (two_part && (int64_t)grid.x > nsteps) {
         const bool mfma_chain = F64 || env_i64("GPX_LEAF_MFMA_F32_ROWS", 16384) > 0;
         const dim3 gdiag((unsigned)nsteps, grid.y), grows(grid.x - (unsigned)nsteps, grid.y);
-        if (v4) GPX_PANEL_LAUNCH_LDS((panel_res_kernel<T, true, F64 ? 4 : 1>), gdiag, 0, pad_lds);
-        else if (v5) GPX_PANEL_LAUNCH((panel_res_kernel<T, true, F64 ? 5 : 1>), gdiag, 0);
+        if (v4) GPX_PANEL_LAUNCH_LDS((panel_res_kernel<T, true, 4>), gdiag, 0, pad_lds);
+        else if (v5 && mfma_chain) GPX_PANEL_LAUNCH((panel_res_kernel<T, true, 5>), gdiag, 0);
         else if (mfma_chain) GPX_PANEL_LAUNCH((panel_res_kernel<T, true>), gdiag, 0);
         else GPX_PANEL_LAUNCH((panel_res_kernel<T, F64>), gdiag, 0);
         GPX_PANEL_LAUNCH((panel_res_kernel<T, F64>), grows, nsteps);          // (the rows never run a leaf: the lean instantiation)
     } else if (v4) {
-        GPX_PANEL_LAUNCH_LDS((panel_res_kernel<T, true, F64 ? 4 : 1>), grid, 0, pad_lds);
-    } else if (v5) {
-        GPX_PANEL_LAUNCH((panel_res_kernel<T, true, F64 ? 5 : 1>), grid, 0);
+        GPX_PANEL_LAUNCH_LDS((panel_res_kernel<T, true, 4>), grid, 0, pad_lds);
+    } else if (v5 && mfma_single) {
+        GPX_PANEL_LAUNCH((panel_res_kernel<T, true, 5>), grid, 0);
     } else if (mfma_single) {
         GPX_PANEL_LAUNCH((panel_res_kernel<T, true>), grid, 0);
     } else {

@@ -211,6 +211,34 @@ def test_fp64_leaves_vs_oracle_and_each_other(monkeypatch, N):
     np.testing.assert_array_equal(b4, b5)
 
 
+@pytest.mark.parametrize("N", [64, 700, 4171])
+def test_fp32_panels_on_the_fp64_leaf_vs_oracle(monkeypatch, N):
+    """fp32 panels hand their 64 x 64 diagonal blocks to the same fp64 two-wave leaf (it converts on the way in and out of LDS;
+    GPX_LEAF = 1 keeps the round-3 fp32 MFMA leaf): all routes against the oracle at the fp32 tolerances, the two instantiations
+    of the new leaf bit for bit, and the new leaf no further from the fp64 answer than the fp32 one."""
+    d = 3
+    X, y, Xo = orc.synth_inputs(N, d, 16)
+    h, w, s = 1.0, 0.5 * np.sqrt(d), 0.9
+    o = orc.OracleGP("gaussian", (h, w), X, y, s)
+    out = {}
+    routes = (("lv4", {}), ("lv5", {"GPX_LEAF4_ROWS": "0", "GPX_PANEL_EXCL_ROWS": "0"}), ("fp32_leaf", {"GPX_LEAF": "1"}))
+    for label, env in routes:
+        for k in ("GPX_LEAF", "GPX_LEAF4_ROWS", "GPX_PANEL_EXCL_ROWS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        g = gp.GP(gp.GaussianKernel(h, w), X, y, s=s, dtype="float32")
+        out[label] = (float(g.log_lh), np.array(g.Lxx, dtype=np.float64), np.array(g.inv_Kxx_y, dtype=np.float64))
+        np.testing.assert_allclose(out[label][0], o.log_lh, rtol=1e-4, err_msg=label)
+        np.testing.assert_allclose(np.tril(out[label][1]), o.Lxx, rtol=2e-3, atol=2e-4, err_msg=label)
+        np.testing.assert_allclose(out[label][2], o.inv_Kxx_y, rtol=2e-3, atol=2e-4, err_msg=label)
+    for k in ("GPX_LEAF", "GPX_LEAF4_ROWS", "GPX_PANEL_EXCL_ROWS"):
+        monkeypatch.delenv(k, raising=False)
+    np.testing.assert_array_equal(np.tril(out["lv4"][1]), np.tril(out["lv5"][1]))
+    err = {k: np.abs(np.tril(v[1]) - o.Lxx).max() for k, v in out.items()}
+    assert err["lv4"] <= 1.5 * err["fp32_leaf"] + 1e-7, err
+
+
 def test_async_fits_of_several_handles_on_one_thread_take_turns():
     """Handles fitted asynchronously back to back from ONE host thread run on their own streams but share that thread's
     scratch buffers (block inverses of the solves, solve operators, the panels' hand-off blocks): a call on another stream
