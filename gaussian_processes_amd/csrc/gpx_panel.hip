@@ -664,7 +664,7 @@ static int panel_res_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int
     const bool excl = !bt && idle_chip && rows <= excl_rows;
     // (panels of up to GPX_LEAF4_ROWS rows take the LV = 4 instantiation beside an update too: n = 8192 5.94 -> 5.79 ms; taller
     //  ones lose more CUs to its one-workgroup-per-CU footprint than the leaf gives back: n = 16384 27.85 -> 28.4 ms)
-    const bool v4 = env_i64("GPX_LEAF", (excl || (!bt && rows <= env_i64("GPX_LEAF4_ROWS", 8192))) ? 4 : 1) == 4;
+    const bool v4 = env_i64("GPX_LEAF", (excl || (!bt && rows <= env_i64("GPX_LEAF4_ROWS", F64 ? 8192 : 5120))) ? 4 : 1) == 4;   // (fp32: N = 32768 94.5 -> 94.2 ms with 5120)
     // A CU of its own for every workgroup of a SHORT panel (single matrix, rows <= GPX_PANEL_EXCL_ROWS).  Per-step stamps
     // of every leaf variant say the same thing (profiles/r04_leaf_steps_*.log): a leaf step takes 3 - 4 times longer while
     // workgroups of the trailing update share the CU (matrix pipe, issue slots) -- a panel took 120 us alone and 140 - 230 us
