@@ -34,10 +34,14 @@
  *     passed as void* (NULL = the null stream); they enqueue work and return.
  *     Device matrices must have ld % 16 == 0 and 16-byte aligned bases.
  *     Threading: the library keeps its scratch blocks, the look-ahead side
- *     stream and its event pool PER HOST THREAD.  gpx_d_potrf, gpx_d_potrf_panel,
- *     gpx_d_trsv_lower*, gpx_d_mean issued from one host thread must therefore
- *     not be in flight on two streams at once (synchronise before switching
- *     streams, or drive each stream from its own host thread).  Handles
+ *     stream and its event pool PER HOST THREAD.  Work one host thread issues on
+ *     two streams therefore takes turns: gpx_d_potrf, gpx_d_potrf_panel,
+ *     gpx_d_trsv_lower*, gpx_d_trsm_right_lt, gpx_d_mean* and every gpx_gp_* call
+ *     on another stream than the thread's previous call first wait (on the device,
+ *     not the host) for that call's work (round 4; before that it was the caller's
+ *     duty, and gpx_gp_fit(gp, NULL) on several handles broke it).  Drive streams
+ *     that should overlap from different host threads.  Nothing is ordered while a
+ *     stream is being captured.  Handles
  *     (gpx_gp_*) remember the device they were created on and make it current
  *     for the duration of every call (the caller's current device is restored);
  *     they synchronise their stream before they return -- the one exception is
