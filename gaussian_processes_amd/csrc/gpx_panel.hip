@@ -171,7 +171,7 @@ __device__ __forceinline__ void res_stage(const T *__restrict__ src, T (*dst)[PT
 }
 
 // the same in two halves -- global -> registers, registers -> LDS -- so that the next block's loads can be in flight under
-// the current block's products (the one-wave-leaf instantiation has the registers for it)
+// the current block's products (the LV = 4 instantiation has the registers for it)
 template <typename T> struct StageRegs {
     static constexpr int E = 16 / (int)sizeof(T), RPW = 256 / (IB / E), PER = IB / RPW;
     typedef uint4v Q;                                           // (a vector type, not a struct of words: stays in registers)

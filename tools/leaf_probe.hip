@@ -1,4 +1,4 @@
-// tools/leaf_probe.hip -- the one-wave 64 x 64 leaf (csrc/gpx_leaf.h, factor64_wave) alone: L and W = inv(L) of a random SPD block
+// tools/leaf_probe.hip -- the two-wave 64 x 64 leaf (csrc/gpx_leaf.h, factor64_wave) alone: L and W = inv(L) of a random SPD block
 // against a host Cholesky, and the leaf's duration in core cycles (s_memtime) with the CU to itself.  diagnostic.
 // build: hipcc -O3 -std=c++17 --offload-arch=gfx950 [-DSTAMP=<step>] [-DPROBE_RING=4] -Igaussian_processes_amd/csrc tools/leaf_probe.hip -o tools/leaf_probe
 #include "gpx_leaf.h"

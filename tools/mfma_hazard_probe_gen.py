@@ -1,6 +1,6 @@
 """tools/mfma_hazard_probe_gen.py -- writes tools/mfma_hazard_probe.hip: how many wait states v_mfma_f64_16x16x4_f64 needs on gfx950
 before its result is read (VALU, a dependent MFMA's srcA/B, srcC), with and without independent MFMAs in between, and the
-write-after-write / write-after-read windows.  hipcc's hazard recogniser inserts these for MFMAs it emits itself; the one-wave
+write-after-write / write-after-read windows.  hipcc's hazard recogniser inserts these for MFMAs it emits itself; the two-wave
 leaf (csrc/gpx_leaf.h) issues its MFMAs from volatile asm to pin their order, so it has to provide them itself.  diagnostic."""
 import os
 

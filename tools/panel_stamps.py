@@ -45,7 +45,7 @@ elif ls[0] and os.environ.get("GPX_LEAF", "4") in ("2", "3"):
           % (ls[1] - ls[0], ls[2] - ls[0], ls[3] - ls[0], ls[4] - ls[0], ls[4] - ls[3], ls[5] - ls[0], ls[5] - ls[3], ls[7] - ls[0]))
 lsx = st.to_host().reshape(-1, 16).astype(np.int64)[2040:2048].ravel()
 if lsx[16] and lsx[17]:
-    # the one-wave leaf (factor64_wave): [16] / [17] = s_memrealtime (100 MHz) at its start / end, [32] / [33] = s_memtime (core clock)
+    # wave 0 of the leaf (factor64_wave): [16] / [17] = s_memrealtime (100 MHz) at its start / end, [32] / [33] = s_memtime (core clock)
     us = (lsx[17] - lsx[16]) / 100.0
     print("leaf of workgroup 0 (wave 0, factor64_wave): %.2f us for 16 steps = %.2f us a step; %d core cycles a step; clock %.2f GHz" % (
         us, us / 16, (lsx[33] - lsx[32]) // 16, (lsx[33] - lsx[32]) / (us * 1e3)))
