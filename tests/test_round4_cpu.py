@@ -2,6 +2,7 @@
 the benchmark launcher's watchdog."""
 import ctypes
 import os
+import shutil
 import subprocess
 import sys
 import threading
@@ -85,3 +86,23 @@ def test_watchdog_ends_a_hung_process_with_its_status():
     assert r.returncode == multi_gpu.WATCHDOG_EXIT, (r.returncode, r.stderr[-500:])
     assert "WATCHDOG rank 1" in r.stderr and "communicator set-up (test)" in r.stderr
     assert "not reached" not in r.stdout
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+def test_hazard_and_leaf_probes_still_build_for_gfx950(tmp_path):
+    """tools/mfma_hazard_probe_gen.py (the measured wait-state table the asm MFMAs of csrc/gpx_leaf.h rely on) and
+    tools/leaf_probe.hip (the leaf alone against a host Cholesky) are the evidence behind DESIGN section 3.2c: they must keep
+    generating / compiling against the current gpx_leaf.h (cross-compilation, no GPU needed)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    gen = subprocess.run([sys.executable, os.path.join(root, "tools", "mfma_hazard_probe_gen.py")], stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, timeout=120)
+    assert gen.returncode == 0, gen.stderr[-1000:]
+    for src, extra in ((os.path.join(root, "tools", "mfma_hazard_probe.hip"), ["-O2"]),
+                       (os.path.join(root, "tools", "leaf_probe.hip"), ["-O3", "-std=c++17", "-I" + os.path.join(root, "gaussian_processes_amd", "csrc")]),
+                       (os.path.join(root, "tools", "leaf_probe.hip"), ["-O3", "-std=c++17", "-DPROBE_RING=4", "-DSTAMP=5",
+                                                                         "-I" + os.path.join(root, "gaussian_processes_amd", "csrc")])):
+        out = str(tmp_path / (os.path.basename(src) + ".o"))
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-Wno-unused-value", "-Wno-unused-result", "-c", src, "-o", out] + extra,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
