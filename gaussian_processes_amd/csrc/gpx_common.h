@@ -73,9 +73,20 @@ extern bool g_prof_on;
 // the registry is shared by all host threads (mutex inside); a scope ends its OWN record
 int  prof_begin(int cls, double work, hipStream_t st);    // record index, -1 when nothing was recorded
 void prof_end(int rec, hipStream_t st);
+// roctx ranges (GPX_ROCTX=1; libroctx64.so by dlopen): every gpx_gp_* call and every launch class below it is a nested host
+// range, so `rocprofv3 --marker-trace --kernel-trace` shows which stage of a fit a kernel belongs to.  Off: one getenv per scope.
+bool roctx_push(const char *name);          // false: ranges are off (or the library is not there): nothing to pop
+void roctx_pop();
+struct RoctxRange {
+    bool on;
+    explicit RoctxRange(const char *name) : on(roctx_push(name)) {}
+    ~RoctxRange() { if (on) roctx_pop(); }
+};
+const char *prof_class_name(int cls);
+
 struct ProfScope {
-    hipStream_t st; int rec;
-    ProfScope(int cls, double work, hipStream_t s) : st(s), rec(g_prof_on ? prof_begin(cls, work, s) : -1) {}
+    hipStream_t st; int rec; RoctxRange range;
+    ProfScope(int cls, double work, hipStream_t s) : st(s), rec(g_prof_on ? prof_begin(cls, work, s) : -1), range(prof_class_name(cls)) {}
     ~ProfScope() { if (rec >= 0) prof_end(rec, st); }
 };
 

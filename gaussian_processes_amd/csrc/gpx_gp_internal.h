@@ -44,10 +44,11 @@ int gp_scan_finite(gpx_gp *g);
 }
 
 // every gpx_gp_* entry: the handle's device becomes current for the duration of the call, and the handle's stream takes
-// its turn among the streams this host thread drives (StreamTurn, gpx_common.h)
+// its turn among the streams this host thread drives (StreamTurn, gpx_common.h); with GPX_ROCTX=1 the call is a roctx range
 #define GP_ENTER(g)                                                          \
     GPX_ARG((g) != nullptr, "gp is NULL");                                   \
     gpx::DeviceGuard guard__((g)->device);                                   \
     if (guard__.rc != GPX_OK) return guard__.rc;                             \
-    gpx::StreamTurn turn__((g)->st)
+    gpx::StreamTurn turn__((g)->st);                                         \
+    gpx::RoctxRange api_range__(__func__)
 

@@ -1,6 +1,7 @@
 // gpx_runtime.hip -- device / memory / stream / event plumbing of the C ABI.
 #include "gpx_common.h"
 #include <stdarg.h>
+#include <dlfcn.h>
 #include <atomic>
 #include <mutex>
 #include <set>
@@ -112,6 +113,53 @@ int set_max_lds(const void *fn, int bytes)
 }  // namespace gpx
 
 using namespace gpx;
+
+// ---- roctx ranges (gpx_common.h) ----
+namespace gpx {
+static std::atomic<long long> g_roctx_ranges{0};
+struct RoctxLib { int (*push)(const char *) = nullptr; int (*pop)() = nullptr; bool tried = false; };
+static RoctxLib g_roctx;
+static std::mutex g_roctx_mu;
+const char *prof_class_name(int cls)
+{
+    static const char *names[PC_COUNT] = {"gpx:kernel_matrix", "gpx:gemm_trailing_update", "gpx:potrf_panel", "gpx:trsm_rows", "gpx:trsv",
+                                          "gpx:mean", "gpx:reduce", "gpx:gemm_skinny", "gpx:gemm_generic", "gpx:gemm_panel", "gpx:gemm_n64"};
+    return (cls >= 0 && cls < PC_COUNT) ? names[cls] : "gpx:other";
+}
+bool roctx_push(const char *name)
+{
+    if (!env_set("GPX_ROCTX")) return false;
+    {
+        std::lock_guard<std::mutex> lk(g_roctx_mu);
+        if (!g_roctx.tried) {
+            g_roctx.tried = true;
+            // (rocprofv3 intercepts the rocprofiler-sdk flavour; the roctracer one is the fall-back for older tools)
+            const char *libs[] = {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "/opt/rocm/lib/librocprofiler-sdk-roctx.so",
+                                  "libroctx64.so", "libroctx64.so.4", "/opt/rocm/lib/libroctx64.so"};
+            for (const char *l : libs) {
+                void *h = dlopen(l, RTLD_NOW | RTLD_GLOBAL);
+                if (!h) continue;
+                g_roctx.push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+                g_roctx.pop = (int (*)())dlsym(h, "roctxRangePop");
+                if (g_roctx.push && g_roctx.pop) break;
+                g_roctx.push = nullptr; g_roctx.pop = nullptr;
+            }
+        }
+    }
+    if (!g_roctx.push) return false;
+    (void)g_roctx.push(name);
+    g_roctx_ranges.fetch_add(1, std::memory_order_relaxed);
+    return true;
+}
+void roctx_pop() { if (g_roctx.pop) (void)g_roctx.pop(); }
+}  // namespace gpx
+
+extern "C" int gpx_debug_roctx_ranges(int64_t *count)
+{
+    if (!count) return GPX_ERR_ARG;
+    *count = (int64_t)gpx::g_roctx_ranges.load(std::memory_order_relaxed);
+    return GPX_OK;
+}
 
 // ---- StreamTurn (gpx_common.h): one turn at a time for the streams a host thread drives ----
 namespace gpx {

@@ -638,3 +638,28 @@ def test_bench_four_ranks_line_schema_over_gloo():
     o = orc.OracleGP("gaussian", (1.0, 0.5 * np.sqrt(4)), X, y, 1.0)
     np.testing.assert_allclose(out["log_lh"], o.log_lh, rtol=1e-10)
     np.testing.assert_allclose(out["first_fit_log_lh"], o.log_lh, rtol=1e-10)
+
+
+def test_roctx_ranges_are_emitted_when_asked_for_and_change_nothing(monkeypatch):
+    """GPX_ROCTX=1: every gpx_gp_* call and every launch class below it pushes a roctx range (SURVEY section 5's tracing
+    suggestion; `rocprofv3 --marker-trace` shows them, profiles/r04_roctx_marker_trace.txt).  Off by default: no range is pushed;
+    on: ranges are counted and the results are bit for bit the same."""
+    lib = _lib.load()
+    def count():
+        v = ctypes.c_int64(0)
+        _lib.check(lib.gpx_debug_roctx_ranges(ctypes.byref(v)))
+        return v.value
+    N, d = 700, 3
+    X, y, Xo = orc.synth_inputs(N, d, 16)
+    monkeypatch.delenv("GPX_ROCTX", raising=False)
+    c0 = count()
+    g = gp.GP(gp.GaussianKernel(1.0, 0.9), X, y, s=0.9)
+    ref = (float(g.log_lh), np.array(g.mean(Xo)))
+    assert count() == c0
+    monkeypatch.setenv("GPX_ROCTX", "1")
+    g2 = gp.GP(gp.GaussianKernel(1.0, 0.9), X, y, s=0.9)
+    got = (float(g2.log_lh), np.array(g2.mean(Xo)))
+    monkeypatch.delenv("GPX_ROCTX", raising=False)
+    assert count() >= c0 + 4                                   # the fit call, its kernel build, panels, solves ...
+    assert got[0] == ref[0]
+    np.testing.assert_array_equal(got[1], ref[1])
