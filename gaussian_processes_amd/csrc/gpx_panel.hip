@@ -65,8 +65,11 @@ template <typename T> __device__ __forceinline__ T pub_load(const T *p)
 // issue" (the poll loop consumes the value; the barrier follows).  What a formal release / acquire pair adds on
 // gfx942 / gfx950 is buffer_wbl2 sc1 / buffer_inv sc1 -- write back and invalidate this XCD's whole L2 for the sake of
 // NON-atomic data, of which the hand-off has none; the first version of the kernel paid that next to a trailing
-// update with gigabytes of dirty tiles.  `strict` (GPX_RES_STRICT=1) issues the formal pair anyway: the soak test
-// (tests/test_gpu_round4.py) runs both forms and compares them bit for bit.
+// update with gigabytes of dirty tiles.  `strict` issues the formal pair anyway and has been the DEFAULT since the end of round 4
+// (GPX_RES_STRICT=0 is the relaxed form argued above): with hand-offs that now raise one flag per block it costs nothing that
+// can be measured beside a trailing update (N = 65536: 1.3742 vs 1.3748 s; n = 8192: 5.91 vs 5.83 ms, i.e. none) and 1.5 % where
+// the chain is all there is (n = 2048: 0.933 vs 0.95 ms) -- the price of not resting the library's results on an argument about
+// what sc1 accesses do.  The soak test (tests/test_gpu_round4.py) runs both forms and compares them bit for bit.
 __device__ __forceinline__ void res_raise(int *flag, int serial, int strict)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -633,7 +636,7 @@ static int panel_res_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int
     unsigned long long *stamps = (g_res_stamps && g_res_stamp_at-- == 0) ? g_res_stamps : (unsigned long long *)nullptr;
     const int serial = ++scr->serial;
     const int nsteps = (int)(kb / IB);
-    const int strict = env_i64("GPX_RES_STRICT", 0) != 0 ? 1 : 0;   // formal release / acquire hand-offs (see res_raise)
+    const int strict = env_i64("GPX_RES_STRICT", 1) != 0 ? 1 : 0;   // formal release / acquire hand-offs (see res_raise); default since round 4
     // TALL panels go out as TWO launches on the same stream: first the diagonal workgroups alone (the chain of leaves),
     // then all the rows below.  In one launch the row workgroups sit on their CUs for the whole chain -- ~230 us at
     // 32768 rows, of which they compute for ~30 -- and each of them keeps a trailing-update workgroup of the other
