@@ -52,7 +52,7 @@ static inline int64_t env_i64(const char *name, int64_t dflt)
 // point of decision.  Tests that force a route through an environment switch assert it here.
 enum Route { RT_TRSV_OPS = 0, RT_TRSV_STEPS = 1, RT_PANEL_RES = 2, RT_PANEL_CHAIN = 3, RT_FIT_RIDE = 4,
              RT_FIT_TWO_SOLVES = 5, RT_GEMM_FAST = 6, RT_GEMM_GENERIC = 7, RT_SYRK_EXACT = 8, RT_SYRK_PATCH = 9,
-             RT_MG_BCAST_ONE = 10, RT_MG_BCAST_SAG = 11, RT_FIT_OPS_AHEAD = 12, RT_TRSM_OPS = 13, RT_PANEL_NESTED = 14, RT_COUNT = 16 };
+             RT_MG_BCAST_ONE = 10, RT_MG_BCAST_SAG = 11, RT_FIT_OPS_AHEAD = 12, RT_TRSM_OPS = 13, RT_PANEL_NESTED = 14, RT_PANEL_TALL = 15, RT_COUNT = 16 };
 void route_hit(int route);
 
 // LAPACK-style info of a factorisation as the host sees it: > 0 "not positive definite" (the caller's business),
@@ -142,7 +142,9 @@ struct Batch {
 // C = beta * C + alpha * A * B^T with beta = 1 (default) or 0 (beta0 != 0: C is not read)
 int gemm_nt(int dtype, int64_t M, int64_t N, int64_t K, const void *A, int64_t lda, const void *B,
             int64_t ldb, void *C, int64_t ldc, double alpha, int tri, int64_t row0, int64_t col0,
-            hipStream_t st, int beta0 = 0, int ktri = 0, const Batch *bt = nullptr);
+            hipStream_t st, int beta0 = 0, int ktri = 0, const Batch *bt = nullptr,
+            int wide_tiles = 0);   // wide_tiles: 128-wide tiles whatever the tile count (N <= 128: ONE tile per row block,
+                                   // which is what makes C == A legal -- a tile reads its rows of A before it stores them)
 // (ktri != 0: A == B is upper triangular in (row, k) and M == N == K -- the k-loop of tile row i skips k < i)
 // X[r, 0:jb] <- X[r, 0:jb] * Ljj^-T for rows r in [0, rows); Ljj = jb x jb lower block
 int trsm_rows(int dtype, void *X, int64_t ldx, int64_t rows, const void *Ljj, int64_t ldl, int jb,

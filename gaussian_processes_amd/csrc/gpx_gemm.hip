@@ -893,7 +893,7 @@ static int fast_bm()
 
 int gemm_nt(int dtype, int64_t M, int64_t N, int64_t K, const void *A, int64_t lda, const void *B,
             int64_t ldb, void *C, int64_t ldc, double alpha, int tri, int64_t row0, int64_t col0,
-            hipStream_t st, int beta0, int ktri, const Batch *bt)
+            hipStream_t st, int beta0, int ktri, const Batch *bt, int wide_tiles)
 {
     if (M <= 0 || N <= 0 || K <= 0) return GPX_OK;
     const bool no_fast = env_set("GPX_GEMM_NO_FAST");
@@ -905,7 +905,7 @@ int gemm_nt(int dtype, int64_t M, int64_t N, int64_t K, const void *A, int64_t l
         // few 128 x 128 tiles (a product that cannot fill the chip anyway): 128 x 64 tiles halve the time of the one round
         // there is -- the posterior covariance's in-block products, 1024 x 512 x 512: 32 tiles
         const int64_t t128 = cdiv(M, 128) * cdiv(N, 128) * (bt ? (int64_t)bt->count * std::max(1, bt->count2) : 1);
-        const bool few = !ktri && tri == GPX_FULL && t128 <= env_i64("GPX_GEMM_BN64_TILES", 256);
+        const bool few = !wide_tiles && !ktri && tri == GPX_FULL && t128 <= env_i64("GPX_GEMM_BN64_TILES", 256);
         if ((N <= 64 || few) && fast_bm() == 128) {
             if (dtype == GPX_F64)
                 return launch_gemm_nt_fast<double, 64, 0, 128>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0, col0,
