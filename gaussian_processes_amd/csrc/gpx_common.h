@@ -8,6 +8,7 @@
 #include <math.h>
 
 #include "../../include/gpx.h"
+#include "gpx_tune.h"
 
 namespace gpx {
 
@@ -38,15 +39,9 @@ int  ensure_device();   // GPX_OK when a GPU is usable
         if (e__ != hipSuccess) return gpx::hip_fail(e__, "kernel launch", __FILE__, __LINE__); \
     } while (0)
 
-// Environment switches: ONE convention -- every switch is read at the point of use, per call, so
-// that a test (or a tuning script) that sets a variable always gets the route it asked for.  A getenv is a scan of
-// the environment block (~0.1 us); the launch paths read a handful per kernel launch.
-static inline bool env_set(const char *name) { const char *e = getenv(name); return e != nullptr && *e != 0; }
-static inline int64_t env_i64(const char *name, int64_t dflt)
-{
-    const char *e = getenv(name);
-    return (e && *e) ? (int64_t)atoll(e) : dflt;
-}
+// Environment switches: ONE table, gpx_tune.h -- every extern "C" entry takes one snapshot of the
+// GPX_* variables for the calling thread (tune_refresh), everything below reads tune().field.  Nothing in the library
+// calls getenv.
 
 // Route counters (gpx_debug_route_count): which of the alternative routes a call took, counted on the host at the
 // point of decision.  Tests that force a route through an environment switch assert it here.

@@ -841,7 +841,7 @@ static int launch_gemm_nt_fast(int64_t M, int64_t N, int64_t K, const void *A, i
     fm.ktri = (ktri == 1 && M == N && N == K) ? 1 : ((ktri == 2 && N == K) ? 2 : 0);
     int64_t dblocks = 0;
     {
-        const bool no_split = env_set("GPX_GEMM_NO_DSPLIT");
+        const bool no_split = tune().gemm_no_dsplit;
         if (!no_split && !fm.exact && BM == 128 && BN == 128 && tri == GPX_LOWER && fm.a == 1 && fm.csh == 3 && fm.pm1nb == 0 &&
             col0 - row0 == (int64_t)fm.b * 1024 && fm.np > 0) {
             const int64_t pbc = cdiv(N, 1024);
@@ -862,14 +862,14 @@ static int launch_gemm_nt_fast(int64_t M, int64_t N, int64_t K, const void *A, i
     if (BM == 128 && fm.exact) { if (fm.eT <= 0) return GPX_OK; }
     else if (np <= 0 && dblocks == 0) return GPX_OK;
     {
-        const bool no_vec = env_set("GPX_GEMM_NO_VEC_C");
+        const bool no_vec = tune().gemm_no_vec_c;
         fm.vec_c = (!no_vec && ldc % 2 == 0 && N % 2 == 0 && N >= 2 && ((uintptr_t)C) % (2 * sizeof(T)) == 0) ? 1 : 0;
         // default on: measured epilogue 20 k -> 11.7 k cycles per tile, whole fit 1.59 -> 1.54 s
-        fm.atomic_c = (int)env_i64("GPX_GEMM_ATOMIC_C", 1);
+        fm.atomic_c = (int)tune().gemm_atomic_c;
     }
     {
         fm.stamps = g_gemm_stamps;
-        fm.ablate = (int)env_i64("GPX_GEMM_ABLATE", 0);      // timing-only ablations: wrong results on purpose
+        fm.ablate = (int)tune().gemm_ablate;      // timing-only ablations: wrong results on purpose
     }
     const int64_t ablocks = (cdiv(np, 8) * 8 * (1024 / BM)) << fm.csh;
     if (dblocks) fm.dbegin = (int)ablocks;
@@ -888,7 +888,7 @@ static int launch_gemm_nt_fast(int64_t M, int64_t N, int64_t K, const void *A, i
 // 1.466 -> 1.435 s; n = 32768 f32: 131 -> 128.5 ms; n = 8192: 19.2 -> 18.1 ms.
 static int fast_bm()
 {
-    return env_i64("GPX_GEMM_BM", 128) == 256 ? 256 : 128;
+    return tune().gemm_bm == 256 ? 256 : 128;
 }
 
 int gemm_nt(int dtype, int64_t M, int64_t N, int64_t K, const void *A, int64_t lda, const void *B,
@@ -896,7 +896,7 @@ int gemm_nt(int dtype, int64_t M, int64_t N, int64_t K, const void *A, int64_t l
             hipStream_t st, int beta0, int ktri, const Batch *bt, int wide_tiles)
 {
     if (M <= 0 || N <= 0 || K <= 0) return GPX_OK;
-    const bool no_fast = env_set("GPX_GEMM_NO_FAST");
+    const bool no_fast = tune().gemm_no_fast;
     const int64_t epk = 128 / (int64_t)esize(dtype), ch = 16 / (int64_t)esize(dtype);
     const bool fast = !no_fast && K % epk == 0 && lda % ch == 0 && ldb % ch == 0 &&
                       ((uintptr_t)A) % 16 == 0 && ((uintptr_t)B) % 16 == 0;
@@ -905,7 +905,7 @@ int gemm_nt(int dtype, int64_t M, int64_t N, int64_t K, const void *A, int64_t l
         // few 128 x 128 tiles (a product that cannot fill the chip anyway): 128 x 64 tiles halve the time of the one round
         // there is -- the posterior covariance's in-block products, 1024 x 512 x 512: 32 tiles
         const int64_t t128 = cdiv(M, 128) * cdiv(N, 128) * (bt ? (int64_t)bt->count * std::max(1, bt->count2) : 1);
-        const bool few = !wide_tiles && !ktri && tri == GPX_FULL && t128 <= env_i64("GPX_GEMM_BN64_TILES", 256);
+        const bool few = !wide_tiles && !ktri && tri == GPX_FULL && t128 <= tune().gemm_bn64_tiles;
         if ((N <= 64 || few) && fast_bm() == 128) {
             if (dtype == GPX_F64)
                 return launch_gemm_nt_fast<double, 64, 0, 128>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0, col0,
@@ -978,7 +978,7 @@ int syrk_bc(int dtype, int64_t n, int64_t row_begin, void *Cloc, int64_t ldc, in
     }
     const double work = 2.0 * (double)kb * elems;
     const bool fast = kb % epk == 0 && ldp % ch == 0 && ((uintptr_t)Pb) % 16 == 0 && cl0 % 128 == 0 &&
-                      nb % 128 == 0 && (1024 % nb == 0) && !env_set("GPX_GEMM_NO_FAST");
+                      nb % 128 == 0 && (1024 % nb == 0) && !tune().gemm_no_fast;
     char *C = (char *)Cloc + (row_begin * ldc + cl0) * es;
     const char *A = (const char *)Pb + (row_begin - k0) * ldp * es;
     if (fast) {
@@ -1005,7 +1005,7 @@ int syrk_bc(int dtype, int64_t n, int64_t row_begin, void *Cloc, int64_t ldc, in
         bool bn64 = false;
         {
             // single rank, triangle aligned to the 128 x 128 tiles: enumerate exactly the tiles that exist
-            const int64_t exact_env = env_i64("GPX_GEMM_EXACT", 1);
+            const int64_t exact_env = tune().gemm_exact;
             const int64_t off = row_begin - G0;                       // row origin minus column origin (global)
             if (exact_env && fast_bm() == 128 && off % 128 == 0 && cdiv(M, 1024) <= 64 && cl0 % nb == 0) {
                 // Short updates take 128 x 64 tiles: twice the tiles at little more than half the time each, so the
@@ -1017,7 +1017,7 @@ int syrk_bc(int dtype, int64_t n, int64_t row_begin, void *Cloc, int64_t ldc, in
                 // 13.86 / 13.83 / 13.96 / 14.08; fp32 n = 8192 4.60 -> 4.47, N = 32768 94.45 -> 93.89 with 4000.
                 const int64_t t128 = std::min<int64_t>((int64_t)cdiv(M, 128) * (cdiv(M, 128) + 1) / 2, (int64_t)cdiv(M, 128) * cdiv(Ncols, 128)) *
                                      (bt ? bt->count : 1);
-                bn64 = t128 <= env_i64("GPX_SYRK_BN64_TILES", dtype == GPX_F64 ? 2600 : 4000) && nb % 64 == 0;
+                bn64 = t128 <= tune().syrk_bn64_tiles[dtype == GPX_F64 ? 0 : 1] && nb % 64 == 0;
                 const int cs = bn64 ? 1 : 0, cw = 128 >> cs;
                 const int TR = (int)cdiv(M, 128), TC = (int)cdiv(Ncols, cw), D = (int)(off / 128);
                 const int bands = (int)cdiv(TR, 8);
@@ -1051,7 +1051,7 @@ int syrk_bc(int dtype, int64_t n, int64_t row_begin, void *Cloc, int64_t ldc, in
                 // ~75 us where 4 / 3 / 2 would do (gpurun_out/r3_timeline8192.txt).  Up to GPX_GEMM_FINE_TILES tiles the
                 // chunk is one tile COLUMN of a band (8 tiles: the same 8 A-slices as its neighbours on that XCD, one
                 // B-slice), which keeps the slices per resident tile the same and evens the XCDs out to within 8 tiles.
-                int cl = total <= env_i64("GPX_GEMM_FINE_TILES", 16384) ? 3 : 6;
+                int cl = total <= tune().gemm_fine_tiles ? 3 : 6;
                 while (cl > 2 && ((int64_t)8 << cl) > total) --cl;   // few tiles: smaller chunks, every XCD still gets some
                 fm.ecl = cl;
                 if (total <= 0) return GPX_OK;

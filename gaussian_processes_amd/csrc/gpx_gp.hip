@@ -331,20 +331,20 @@ int gpx_gp_fit(gpx_gp_t *g, int *info)
     // Small and mid sizes: y rides along as row n of the matrix -- every panel substitutes it, every update reduces it,
     // exactly what the forward solve L t = y would do afterwards -- so only the backward solve is left (n = 8192: the
     // two solves were 1.0 ms of an 8 ms fit).  At large n the extra row of tiles in every update costs what it saves.
-    const int64_t ride_max = env_i64("GPX_FIT_RIDE_MAX", 16384);
+    const int64_t ride_max = tune().fit_ride_max;
     const bool ride = g->n <= ride_max;
     route_hit(ride ? RT_FIT_RIDE : RT_FIT_TWO_SOLVES);
     char *row_n = (char *)g->A + (size_t)g->n * g->lda * es;
     if (ride) GPX_HIP(hipMemcpyAsync(row_n, g->y, (size_t)g->n * es, hipMemcpyDeviceToDevice, st));
     g->ops.invalidate();                                  // a new factor: its block operators are rebuilt once
-    const bool ahead = env_i64("GPX_FIT_OPS_AHEAD", 1) != 0 && g->n >= env_i64("GPX_FIT_OPS_AHEAD_MIN", 8192) &&
+    const bool ahead = tune().fit_ops_ahead != 0 && g->n >= tune().fit_ops_ahead_min &&
                        trsv_ops_ahead_ok(g->dtype, g->A, g->n, g->lda);
     // ONE instalment, when all but the last `tail` blocks are final: the build is a chain of ~11 launches batched over its
     // blocks (~0.6 ms whatever their number), so instalments of 4 blocks cost the factorisation what the solve saves
     // (n = 8192: fit 6.71 -> 6.73 ms with groups of 4, 6.62 with one; n = 12288: 15.57 -> 15.04; n = 4096: no gain), and
     // the last blocks' operators would only be waited for: the backward sweep takes those blocks by steps
-    const int64_t nfull = g->n / 512, tail = env_i64("GPX_FIT_OPS_TAIL", 4);
-    const int64_t group = std::max<int64_t>(1, std::min(env_i64("GPX_FIT_OPS_GROUP", nfull), nfull - tail));
+    const int64_t nfull = g->n / 512, tail = tune().fit_ops_tail;
+    const int64_t group = std::max<int64_t>(1, std::min(tune().fit_ops_group_set ? tune().fit_ops_group : nfull, nfull - tail));
     OpsAhead oa = {g, group, std::max<int64_t>(0, nfull - tail)};
     PotrfHook hook = {ops_ahead_step, &oa};
     if (ahead) {
@@ -641,13 +641,13 @@ int gpx_gp_fit_batch(gpx_gp_t *g, const double *thetas, int64_t B, double *log_l
     const int64_t n = g->n, lda = g->lda;
     const size_t es = esize(g->dtype);
     const int np = g->nparams;
-    const int64_t ride_max = env_i64("GPX_FIT_RIDE_MAX", 16384);
+    const int64_t ride_max = tune().fit_ride_max;
     const bool ride = n <= ride_max;                      // y rides along as row n of every matrix (see gpx_gp_fit)
     const size_t per = (size_t)(n + (ride ? 1 : 0)) * lda * es;
     size_t freeb = 0, totalb = 0;
     GPX_HIP(hipMemGetInfo(&freeb, &totalb));
     int64_t Bc = (int64_t)((double)freeb * 0.85 / (double)(per + 4 * (size_t)n * es + 64));
-    if (env_set("GPX_BATCH_MAX")) Bc = std::min<int64_t>(Bc, std::max<int64_t>(1, env_i64("GPX_BATCH_MAX", 1)));
+    if (tune().batch_max_set) Bc = std::min<int64_t>(Bc, std::max<int64_t>(1, tune().batch_max));
     Bc = std::max<int64_t>(1, std::min<int64_t>(Bc, B));
     if (!g->bw && (double)per > (double)freeb * 0.85) { set_error("fit_batch: not even one more n x n matrix fits in HBM"); return GPX_ERR_NOMEM; }
     // one block, kept in the handle between calls (an ML-II loop calls this once per sweep; a fresh

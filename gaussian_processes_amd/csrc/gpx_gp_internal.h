@@ -47,6 +47,7 @@ int gp_scan_finite(gpx_gp *g);
 // its turn among the streams this host thread drives (StreamTurn, gpx_common.h); with GPX_ROCTX=1 the call is a roctx range
 #define GP_ENTER(g)                                                          \
     GPX_ARG((g) != nullptr, "gp is NULL");                                   \
+    gpx::tune_refresh();                                                     \
     gpx::DeviceGuard guard__((g)->device);                                   \
     if (guard__.rc != GPX_OK) return guard__.rc;                             \
     gpx::StreamTurn turn__((g)->st);                                         \

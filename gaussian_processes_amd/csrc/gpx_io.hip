@@ -75,7 +75,7 @@ static bool expected_file_bytes(const FactorHeader &hd, size_t es, unsigned long
 
 static int64_t io_block_rows(int64_t n, size_t es)
 {
-    const size_t target = (size_t)std::max<int64_t>(1, env_i64("GPX_IO_BLOCK_BYTES", (int64_t)64 << 20));
+    const size_t target = (size_t)std::max<int64_t>(1, tune().io_block_bytes);
     int64_t r = (int64_t)(target / ((size_t)std::max<int64_t>(n, 1) * es));
     return std::max<int64_t>(1, std::min<int64_t>(r, n));
 }
@@ -323,7 +323,7 @@ int gpx_kmat_host(int kernel, int member, double *out, const double *x1, int64_t
     GPX_ARG(out && x1 && x2 && params, "NULL pointer");
     const int64_t ld = round_up(m, 16);
     // panel height: GPX_KMAT_PANEL_BYTES of device memory per panel (default 256 MiB), a multiple of 64 rows
-    const size_t target = (size_t)std::max<int64_t>(1, env_i64("GPX_KMAT_PANEL_BYTES", (int64_t)256 << 20));
+    const size_t target = (size_t)std::max<int64_t>(1, tune().kmat_panel_bytes);
     int64_t R = (int64_t)(target / ((size_t)ld * 8));
     R = std::max<int64_t>(64, R / 64 * 64);
     R = std::min<int64_t>(R, round_up(n, 64));

@@ -68,7 +68,7 @@ static Rccl g_rccl;
 static int rccl_load()
 {
     if (g_rccl.lib) return GPX_OK;
-    const char *names[] = {getenv("GPX_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    const char *names[] = {tune().rccl_lib[0] ? tune().rccl_lib : nullptr, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void *h = nullptr;
     for (const char *nm : names) {
         if (!nm || !*nm) continue;
@@ -276,7 +276,7 @@ static int mg_bcast(gpx_mg *g, void *dev_ptr, size_t count, int root, hipStream_
         if (rc != 0) { set_error("broadcast callback failed (%d)", rc); return GPX_ERR_HIP; }
         return GPX_OK;
     }
-    if (g->world == 1 && !env_set("GPX_FORCE_COLLECTIVES")) return GPX_OK;
+    if (g->world == 1 && !tune().force_collectives) return GPX_OK;
     GPX_NCCL(g_rccl.Broadcast(dev_ptr, dev_ptr, count, nccl_type(g->dtype), root, g->comm, st));
     return GPX_OK;
 }
@@ -291,7 +291,7 @@ static int mg_allreduce(gpx_mg *g, void *dev_ptr, size_t count, int dtype, int o
         if (rc != 0) { set_error("all-reduce callback failed (%d)", rc); return GPX_ERR_HIP; }
         return GPX_OK;
     }
-    if (g->world == 1 && !env_set("GPX_FORCE_COLLECTIVES")) return GPX_OK;
+    if (g->world == 1 && !tune().force_collectives) return GPX_OK;
     const ncclDataType_t t = dtype == GPX_F64 ? ncclFloat64 : (dtype == GPX_F32 ? ncclFloat32 : ncclInt32);
     GPX_NCCL(g_rccl.AllReduce(dev_ptr, dev_ptr, count, t, op == 0 ? ncclSum : ncclMax, g->comm, st));
     return GPX_OK;
@@ -634,9 +634,9 @@ static int mg_new(gpx_mg **out, int dtype, int kernel, int64_t n, int d, int64_t
     g->ld = g->ncols_local;
     g->nr = n + 1;
     g->ops.resize(std::max<size_t>(1, g->my_blocks.size()));
-    g->bcast_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(16, env_i64("GPX_MG_BCAST_CHUNKS", 4)));
-    g->timing = !env_set("GPX_MG_NO_TIMING");
-    if (const char *e = getenv("GPX_MG_BCAST")) g->bcast_sag = strcmp(e, "sag") == 0;
+    g->bcast_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(16, tune().mg_bcast_chunks));
+    g->timing = !tune().mg_no_timing;
+    if (tune().mg_bcast_set) g->bcast_sag = tune().mg_bcast_sag;
     *out = g;
     return GPX_OK;
 }
@@ -645,6 +645,7 @@ static int mg_new(gpx_mg **out, int dtype, int kernel, int64_t n, int d, int64_t
 
 #define MG_ENTER(g)                                                          \
     GPX_ARG((g) != nullptr, "mg is NULL");                                   \
+    gpx::tune_refresh();                                                     \
     gpx::DeviceGuard guard__((g)->device);                                   \
     if (guard__.rc != GPX_OK) return guard__.rc
 

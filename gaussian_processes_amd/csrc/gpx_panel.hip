@@ -647,7 +647,7 @@ struct ResScratch {
 };
 constexpr int RES_MAXDEV = 16;
 static thread_local ResScratch g_res_dev[RES_MAXDEV];       // one per device: a thread that alternates between GPUs keeps both
-#define RES_TRACE(...) do { if (env_set("GPX_TRACE")) { fprintf(stderr, "[gpx] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
+#define RES_TRACE(...) do { if (tune().trace) { fprintf(stderr, "[gpx] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
 constexpr size_t RES_W256 = (size_t)(RES_MAXSTEPS * IB) * (RES_MAXSTEPS * IB);      // elements of inv(L_256) (tall panels, single matrices)
 static int res_scratch(int nbatch, size_t es, void **pub, int **flags, ResScratch **out, void **w256 = nullptr)
 {
@@ -692,7 +692,7 @@ static int res_scratch(int nbatch, size_t es, void **pub, int **flags, ResScratc
 
 int64_t panel_res_max()
 {
-    const int64_t v = env_i64("GPX_POTRF_RES", (int64_t)RES_MAXSTEPS * IB);
+    const int64_t v = tune().potrf_res;
     return std::min<int64_t>(v, (int64_t)RES_MAXSTEPS * IB);
 }
 
@@ -721,7 +721,7 @@ static int panel_res_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int
     unsigned long long *stamps = (g_res_stamps && g_res_stamp_at-- == 0) ? g_res_stamps : (unsigned long long *)nullptr;
     const int serial = ++scr->serial;
     const int nsteps = (int)(kb / IB);
-    const int strict = env_i64("GPX_RES_STRICT", 1) != 0 ? 1 : 0;   // formal release / acquire hand-offs (see res_raise); default since round 4
+    const int strict = tune().res_strict != 0 ? 1 : 0;   // formal release / acquire hand-offs (see res_raise); default since round 4
     // TALL panels go out as TWO launches on the same stream: first the diagonal workgroups alone (the chain of leaves),
     // then all the rows below.  In one launch the row workgroups sit on their CUs for the whole chain -- ~230 us at
     // 32768 rows, of which they compute for ~30 -- and each of them keeps a trailing-update workgroup of the other
@@ -730,11 +730,11 @@ static int panel_res_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int
     // row pass (it no longer hides under the chain), which only matters where the panel chain is the critical path:
     // short panels (rows <= GPX_POTRF_TWO_PART_ROWS) stay one launch.
     // (measured: n = 32768 fp32 96.7 -> 95.5 ms with 16384; n = 65536 fp64 unchanged; n = 16384 28.8 -> 29.3 with 12288)
-    const int64_t two_part_rows = env_i64("GPX_POTRF_TWO_PART_ROWS", 16384);
+    const int64_t two_part_rows = tune().two_part_rows;
     // fp32: which instantiation holds the leaf (see panel_res_kernel): the MFMA leaf for single launches of up to
     // GPX_LEAF_MFMA_F32_ROWS rows and for the chain part of a two-part panel; the lean kernel for everything taller
     constexpr bool F64 = sizeof(T) == 8;
-    const bool mfma_single = F64 || rows <= env_i64("GPX_LEAF_MFMA_F32_ROWS", 16384);
+    const bool mfma_single = F64 || rows <= tune().leaf_mfma_f32_rows;
     // (`done` is recorded behind the launch.  Carrying it as the completion signal of the dispatch packet itself --
     //  hipExtLaunchKernelGGL(..., stopEvent) -- saves ~2.5 us per panel (tools/sync_probe.hip) and was tried; one run of
     //  the parity suite then produced a wrong log_lh at n = 1990 that never reproduced.  Not worth 1 %: dropped.)
@@ -742,17 +742,18 @@ static int panel_res_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int
     // lock-step batches: the same trade per launch over ALL matrices -- many matrices' row workgroups crowd out the
     // update of the step before (64 x n = 8192: 0.213 -> 0.199 s with two parts, 16 x: 55.0 -> 54.6 ms, 8 x: 29.4 -> 30.8)
     const int64_t nmat = bt ? bt->count : 1;
-    const bool two_part = nmat > 1 ? rows * nmat > env_i64("GPX_POTRF_TWO_PART_BATCH", 98304) : rows > two_part_rows;
+    const bool two_part = nmat > 1 ? rows * nmat > tune().two_part_batch : rows > two_part_rows;
     // fp64 leaf (gpx_leaf.h): GPX_LEAF = 4 the two-wave leaf without barriers (default for single matrices' short panels), 1 the
     // round-3 leaf on four waves.  (The LV = 4 instantiation runs ONE workgroup per CU -- its accumulator tiles and 107 KB of
     // LDS -- which a single matrix's panels never notice (at most 256 workgroups per launch) but a lock-step batch's would:
     // batches keep 1.)
-    const int64_t excl_rows = env_i64("GPX_PANEL_EXCL_ROWS", 5120);
+    const int64_t excl_rows = tune().panel_excl_rows;
     const bool idle_chip = potrf_take_idle_chip_hint();        // (always taken: a hint is for ONE launch)
     const bool excl = !bt && idle_chip && rows <= excl_rows;
     // (panels of up to GPX_LEAF4_ROWS rows take the LV = 4 instantiation beside an update too: n = 8192 5.94 -> 5.79 ms; taller
     //  ones lose more CUs to its one-workgroup-per-CU footprint than the leaf gives back: n = 16384 27.85 -> 28.4 ms)
-    const bool v4 = env_i64("GPX_LEAF", (excl || (!bt && rows <= env_i64("GPX_LEAF4_ROWS", F64 ? 8192 : 5120))) ? 4 : 1) == 4;   // (fp32: N = 32768 94.5 -> 94.2 ms with 5120)
+    const int64_t leaf_dflt = (excl || (!bt && rows <= tune().leaf4_rows[F64 ? 0 : 1])) ? 4 : 1;
+    const bool v4 = (tune().leaf_set ? tune().leaf : leaf_dflt) == 4;   // (fp32: N = 32768 94.5 -> 94.2 ms with 5120)
     // A CU of its own for every workgroup of a SHORT panel (single matrix, rows <= GPX_PANEL_EXCL_ROWS).  Per-step stamps
     // of every leaf variant say the same thing (profiles/r04_leaf_steps_*.log): a leaf step takes 3 - 4 times longer while
     // workgroups of the trailing update share the CU (matrix pipe, issue slots) -- a panel took 120 us alone and 140 - 230 us
@@ -766,7 +767,7 @@ static int panel_res_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int
     // (profiles/r04_ab_exclusive_cus.log, measured with the first one-wave leaf).
     size_t pad_lds = 0;
     if (v4 && excl) {
-        pad_lds = (size_t)env_i64("GPX_PANEL_PAD_LDS", F64 ? 8 * 1024 : 40 * 1024);   // (fp32: 75 KB of static LDS)
+        pad_lds = (size_t)tune().panel_pad_lds[F64 ? 0 : 1];   // (fp32: 75 KB of static LDS)
         GPX_TRY(set_max_lds((const void *)panel_res_kernel<T, true, 4>, (int)pad_lds));
     }
 #define GPX_PANEL_LAUNCH_LDS(KERNEL, GRID, W0, DYN)                                                                             \
@@ -776,7 +777,7 @@ static int panel_res_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int
     // every other fp64 panel (lock-step batches, panels taller than GPX_LEAF4_ROWS): the same leaf in the LV = 5 instantiation --
     // two workgroups a CU like the round-3 kernel (a 10 KB ring of operand slots instead of 40 KB, no operand prefetch)
     // (fp32 panels hand their diagonal blocks to the same fp64 leaf wherever they used the fp32 MFMA leaf: GPX_LEAF=1 keeps that one)
-    const bool v5 = !v4 && env_i64("GPX_LEAF", 5) == 5;
+    const bool v5 = !v4 && (tune().leaf_set ? tune().leaf : 5) == 5;
     // TALL panels of single matrices (256 columns, more than GPX_POTRF_TALL_ROWS rows): only the diagonal workgroups stay on the
     // resident kernel; the rows below are products on the GEMM kernel (winv256_kernel above has the why)
     // MEASURED (round 5, profiles/r05_ab_tall_*.log, r05_timeline_n65536_*.txt, r05_panel_alone_tall_vs_resident.log) and OFF by
@@ -786,15 +787,15 @@ static int panel_res_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int
     // panel stream's FLOPS on the same matrix pipes -- ~2.3 TF per fit, which cost it ~38 ms, i.e. they already run at the
     // equivalent of 60 TF/s -- not the shape of the kernels that carry them.  (With the first inverse kernel, whose 135 KB
     // of LDS starved it behind the update, the update ran at 0.898 and the fit took 40 ms LONGER.)
-    const bool tall = !bt && nsteps == RES_MAXSTEPS && (int64_t)grid.x > nsteps && rows > env_i64("GPX_POTRF_TALL_ROWS", (int64_t)1 << 40) &&
-                      lda % (16 / (int64_t)sizeof(T)) == 0 && ((uintptr_t)A) % 16 == 0 && c0 % 16 == 0 && !env_set("GPX_GEMM_NO_FAST");
+    const bool tall = !bt && nsteps == RES_MAXSTEPS && (int64_t)grid.x > nsteps && rows > tune().tall_rows &&
+                      lda % (16 / (int64_t)sizeof(T)) == 0 && ((uintptr_t)A) % 16 == 0 && c0 % 16 == 0 && !tune().gemm_no_fast;
     // (the profiling class of the resident launches; the tall route's products are counted by their own classes)
     const double res_rows = tall ? (double)kb : (double)rows;
     std::optional<ProfScope> prof;
     prof.emplace(PC_POTRF_DIAG, (kd * kd * kd / 3.0 + (res_rows - (double)kb) * kd * kd + 2.0 * res_rows * kd * (double)kpre) * nbatch, st);
     if (tall) {
         route_hit(RT_PANEL_TALL);
-        const bool mfma_chain = F64 || env_i64("GPX_LEAF_MFMA_F32_ROWS", 16384) > 0;
+        const bool mfma_chain = F64 || tune().leaf_mfma_f32_rows > 0;
         const dim3 gdiag((unsigned)nsteps, 1);
         if (v4) GPX_PANEL_LAUNCH_LDS((panel_res_kernel<T, true, 4>), gdiag, 0, pad_lds);
         else if (v5 && mfma_chain) GPX_PANEL_LAUNCH((panel_res_kernel<T, true, 5>), gdiag, 0);
@@ -816,7 +817,7 @@ static int panel_res_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int
         GPX_TRY(gemm_nt(dtype, below, H, H, P, lda, (const T *)w256, LDW, P, lda, 1.0, GPX_FULL, 0, 0, st, 1, 0, nullptr, 1));
     } else
     if (two_part && (int64_t)grid.x > nsteps) {
-        const bool mfma_chain = F64 || env_i64("GPX_LEAF_MFMA_F32_ROWS", 16384) > 0;
+        const bool mfma_chain = F64 || tune().leaf_mfma_f32_rows > 0;
         const dim3 gdiag((unsigned)nsteps, grid.y), grows(grid.x - (unsigned)nsteps, grid.y);
         if (v4) GPX_PANEL_LAUNCH_LDS((panel_res_kernel<T, true, 4>), gdiag, 0, pad_lds);
         else if (v5 && mfma_chain) GPX_PANEL_LAUNCH((panel_res_kernel<T, true, 5>), gdiag, 0);
@@ -855,8 +856,8 @@ int potrf_panel_res(int dtype, void *A, int64_t lda, int64_t n, int64_t r0, int6
 // run in several rounds and the tuned GEMM does the same update faster than they do)
 bool panel_res_fold(int64_t rows, int64_t kpre, int64_t kb, size_t es, int64_t lda, const void *base)
 {
-    const int64_t rows_max = env_i64("GPX_POTRF_FOLD_ROWS", 16384);
-    const int64_t kpre_max = env_i64("GPX_POTRF_FOLD_K", 256);
+    const int64_t rows_max = tune().fold_rows;
+    const int64_t kpre_max = tune().fold_k;
     return kb % IB == 0 && kb <= panel_res_max() && kpre % IB == 0 && kpre > 0 && kpre <= kpre_max && rows <= rows_max &&
            lda % (16 / (int64_t)es) == 0 && ((uintptr_t)base) % 16 == 0;
 }

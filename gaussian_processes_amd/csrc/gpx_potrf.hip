@@ -230,7 +230,7 @@ int tril(int dtype, void *A, int64_t n, int64_t lda, hipStream_t st)
 
 static int64_t outer_block(int64_t n, bool batched = false)
 {
-    const int64_t forced = env_i64("GPX_POTRF_NB", 0);
+    const int64_t forced = tune().potrf_nb;
     if (forced >= IB && forced % IB == 0) return forced;
     // lock-step batches: the chain is shared by all matrices, so the deeper K = 512 tiles of the trailing update
     // win (64 x n = 8192: 0.238 -> 0.214 s; 8 x: 0.290 -> 0.272 s)
@@ -245,11 +245,7 @@ static int64_t outer_block(int64_t n, bool batched = false)
     // (fp32: 105.9 / 100.5).  The width is re-evaluated per panel with the rows that are left (potrf()), thresholds
     // (rows for 128 / 256 / 512) measured with that taper: 128 never pays with the one-launch panel (n = 2048:
     // 1.45 -> 1.35 ms), 512 -> 1024 above 12288 (n = 16384: 31.6 -> 31.3 ms, n = 32768 fp32: 101.1 -> 99.9)
-    long long thr[3] = {1, 8192, 12288};
-    if (const char *e = getenv("GPX_POTRF_WIDTHS")) {          // "rows128,rows256,rows512"
-        long long a, b, c;
-        if (sscanf(e, "%lld,%lld,%lld", &a, &b, &c) == 3) { thr[0] = a; thr[1] = b; thr[2] = c; }
-    }
+    const long long *thr = tune().potrf_widths;                 // GPX_POTRF_WIDTHS = "rows128,rows256,rows512"; default 1, 8192, 12288
     if (n <= thr[0]) return 128;
     if (n <= thr[1]) return 256;
     if (n <= thr[2]) return 512;
@@ -310,7 +306,7 @@ static int potrf_panel_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, i
         const int64_t below = n - (r0 + jb);
         // measured: the inverse + MFMA route wins for short panels (N = 8192: -2.7 % per fit) and
         // loses for tall ones (N = 65536: +2 %, its 120 KiB tiles displace trailing-update workgroups)
-        const bool via_inverse = !env_set("GPX_POTRF_TRSM_ROWS") && below > 0 && below <= env_i64("GPX_POTRF_INV_MAX", 16384) &&
+        const bool via_inverse = !tune().potrf_trsm_rows && below > 0 && below <= tune().potrf_inv_max &&
                                  jb == IB && lda % (16 / (int64_t)sizeof(T)) == 0 &&
                                  ((uintptr_t)(A + (r0 + jb) * lda + c0)) % 16 == 0;
         T *inv = nullptr;
@@ -324,9 +320,9 @@ static int potrf_panel_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, i
             // the 320-thread pivot-wave leaf wins where CUs are set aside for the panel stream (n <= 12288: 30.4 -> 27 us)
             // and loses where it has to wait for a slot among the trailing update's workgroups (fp64 n = 16384:
             // potrf 37.2 -> 40.2 ms, n = 24576: 94.4 -> 98.1): GPX_LEAF_PIPE = 1 always, 0 never, default by reservation
-            const int64_t pipe_env = env_i64("GPX_LEAF_PIPE", -1);
+            const int64_t pipe_env = tune().leaf_pipe;
             const bool pipe = pipe_env < 0 ? g_leaf_pipe : pipe_env != 0;
-            const int nsteps = (int)env_i64("GPX_LEAF_ABLATE", IB / 4);   // timing only
+            const int nsteps = (int)tune().leaf_ablate;   // timing only
             if (pipe) {
                 if (inv)
                     hipLaunchKernelGGL((potrf_diag_pipe_kernel<T, true>), dim3(nbatch), dim3(320), 0, st, D, lda, r0, jb,
@@ -469,9 +465,9 @@ bool potrf_take_idle_chip_hint() { const bool v = g_idle_chip; g_idle_chip = fal
 static bool panel_nested_ok(int64_t rows, int64_t r0, int64_t c0, int64_t kb, int64_t kpre, size_t es, int64_t lda, const void *base)
 {
     const int64_t sub = panel_res_max();
-    if (!g_in_potrf || env_i64("GPX_POTRF_NESTED", 0) == 0) return false;
+    if (!g_in_potrf || tune().potrf_nested == 0) return false;
     // (r0 != c0: a rank's local block column of the multi-GPU schedule -- the in-panel updates' tile map assumes global columns)
-    return r0 == c0 && kpre == 0 && sub == 256 && kb % sub == 0 && kb / sub >= 3 && rows <= env_i64("GPX_POTRF_NESTED_ROWS", 16384) &&
+    return r0 == c0 && kpre == 0 && sub == 256 && kb % sub == 0 && kb / sub >= 3 && rows <= tune().potrf_nested_rows &&
            panel_res_fold(rows, sub, sub, es, lda, base);
 }
 
@@ -544,7 +540,7 @@ static int trailing_stream(int reserve, hipStream_t *out)
 
 static int reserve_cus(int64_t n)
 {
-    const int64_t env = env_i64("GPX_POTRF_RESERVE_CUS", -1);
+    const int64_t env = tune().reserve_cus;
     if (env >= 0) return (int)std::min<int64_t>(128, env);
     // Round 1 (a panel = a dozen small launches): 32 CUs for n <= 12288, n = 8192 13.3 -> 12.3 ms.  With one resident
     // launch per panel the reservation no longer pays -- round 3, 32 vs 0 reserved: n = 2048 0.965 / 0.957 ms, 4096
@@ -562,7 +558,7 @@ static int reserve_cus(int64_t n)
 // 29.4 either way with one masked stream).  GPX_POTRF_RESERVE_CUS_BATCH still forces a value.)
 static int reserve_cus_batch(int64_t n, int count)
 {
-    const int64_t env = env_i64("GPX_POTRF_RESERVE_CUS_BATCH", -1);
+    const int64_t env = tune().reserve_cus_batch;
     if (env >= 0) return (int)std::min<int64_t>(128, env);
     (void)n; (void)count;
     return 0;
@@ -582,7 +578,7 @@ int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t
     const int64_t nb = outer_block(n, bt != nullptr);
     const int64_t nblk = cdiv(n, nb);
     const size_t es = esize(dtype);
-    const bool no_la = env_set("GPX_POTRF_NO_LOOKAHEAD");
+    const bool no_la = tune().no_lookahead;
     g_leaf_pipe = false;
     if (nblk <= 1) return potrf_panel(dtype, A, lda, N, 0, 0, n, info_dev, st, bt);
     auto at = [&](int64_t r, int64_t c) { return (char *)A + (r * lda + c) * es; };
@@ -611,7 +607,7 @@ int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t
     // ... once the step is bound by the panel chain: while the trailing update is the longer of the two (many
     // rows left) it keeps the whole chip
     // (round 3, with the XCD-balanced tile map: 8192 -> 4096: n = 8192 potrf 6.37 -> 6.27 ms, tools/r3_ab.sh)
-    const int64_t reserve_below = env_i64("GPX_POTRF_RESERVE_BELOW", 4096);
+    const int64_t reserve_below = tune().reserve_below;
     auto switch_to = [&](hipStream_t want) -> int {
         if (want == st) return GPX_OK;
         hipEvent_t es;
@@ -626,7 +622,7 @@ int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t
     // update is the longer of the two, narrow once the step is bound by the panel chain); widths only ever shrink
     // and each divides the one before, so every panel stays aligned to its own width.  Lock-step batches and a
     // forced GPX_POTRF_NB keep one width.
-    const bool taper = env_i64("GPX_POTRF_TAPER", 1) != 0 && !env_set("GPX_POTRF_NB");
+    const bool taper = tune().taper != 0 && !tune().potrf_nb_set;
     auto nominal = [&](int64_t k0) -> int64_t { return (taper && !bt) ? std::min(nb, outer_block(n - k0)) : nb; };
     // (Round 4 also built a "pair phase" here -- while many rows are left, the far trailing matrix updated once per TWO 256-wide
     //  panels with one K = 512 product, the panels in between applying their predecessors themselves, 512 / 256 columns deep --
@@ -642,7 +638,7 @@ int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t
     hipEvent_t e_rest = nullptr;                                // fires when the trailing update of the step before is done
     // host pacing blocks the calling thread inside the loop: only where the caller said it may (the handle's gpx_gp_fit,
     // documented in include/gpx.h; gpx_d_potrf stays a pure enqueue) and never while the stream is being captured
-    bool host_paced = may_block && !bt && n <= env_i64("GPX_POTRF_HOST_PACED", 16384);
+    bool host_paced = may_block && !bt && n <= tune().host_paced;
     if (host_paced) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(user, &cs) != hipSuccess) (void)hipGetLastError();
@@ -672,7 +668,7 @@ int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t
             // every CU slot taken and ran for as long as the update did (n = 8192 with 512-wide blocks: the left half 504 us
             // beside a 441 us update, the right half 107 us after it; profiles/r04_timeline_n8192_nb512_before_gate.txt).
             // An event recorded on the panel's stream right behind its wait gates the rest of the update.
-            if ((bt ? env_i64("GPX_POTRF_GATE_BATCH", 0) != 0 : true) && N - r <= env_i64("GPX_POTRF_GATE_ROWS", 16384)) {
+            if ((bt ? tune().gate_batch != 0 : true) && N - r <= tune().gate_rows) {
                 GPX_TRY(g_la.get(&e_gate));
                 GPX_HIP(hipEventRecord(e_gate, q));
             }

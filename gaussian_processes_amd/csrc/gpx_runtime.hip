@@ -1,6 +1,7 @@
 // gpx_runtime.hip -- device / memory / stream / event plumbing of the C ABI.
 #include "gpx_common.h"
 #include <stdarg.h>
+#include <stddef.h>
 #include <dlfcn.h>
 #include <atomic>
 #include <mutex>
@@ -30,6 +31,7 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line)
 
 int ensure_device()
 {
+    tune_refresh();                                            // (every gpx_d_* / host entry comes through here: gpx_tune.h)
     static thread_local int ok = 0;
     if (ok) return GPX_OK;
     int n = 0;
@@ -44,6 +46,73 @@ int ensure_device()
     return GPX_OK;
 }
 
+
+}  // namespace gpx
+
+// ---- switches: one snapshot per API call (gpx_tune.h) -------------------------------------------------------------
+extern "C" char **environ;
+namespace gpx {
+static thread_local Tune g_tune;
+static std::atomic<long long> g_tune_refreshes{0};
+const Tune &tune() { return g_tune; }
+int64_t tune_refresh_count() { return (int64_t)g_tune_refreshes.load(std::memory_order_relaxed); }
+
+namespace {
+enum TuneKind { TK_I64, TK_FLAG, TK_I64_SET, TK_I64_2 };
+struct TuneEntry { const char *name; size_t len; int kind; size_t off, off2; };
+#define GPX_E_X(f, e, d) {e, sizeof(e) - 1, TK_I64, offsetof(Tune, f), 0},
+#define GPX_E_XF(f, e) {e, sizeof(e) - 1, TK_FLAG, offsetof(Tune, f), 0},
+#define GPX_E_XS(f, e, d) {e, sizeof(e) - 1, TK_I64_SET, offsetof(Tune, f), offsetof(Tune, f##_set)},
+#define GPX_E_X2(f, e, d0, d1) {e, sizeof(e) - 1, TK_I64_2, offsetof(Tune, f), 0},
+const TuneEntry g_tune_table[] = { GPX_TUNE_LIST(GPX_E_X, GPX_E_XF, GPX_E_XS, GPX_E_X2) };
+#undef GPX_E_X
+#undef GPX_E_XF
+#undef GPX_E_XS
+#undef GPX_E_X2
+}  // namespace
+
+void tune_refresh()
+{
+    Tune t;                                                    // defaults
+    for (char **e = environ; e && *e; ++e) {
+        const char *kv = *e;
+        if (kv[0] != 'G' || kv[1] != 'P' || kv[2] != 'X' || kv[3] != '_') continue;
+        const char *eq = strchr(kv, '=');
+        if (!eq || eq[1] == 0) continue;                       // (empty: as if unset -- the convention of env_i64 / env_set)
+        const size_t len = (size_t)(eq - kv);
+        const char *val = eq + 1;
+        if (len == 16 && memcmp(kv, "GPX_POTRF_WIDTHS", 16) == 0) {
+            long long a, b, c;
+            if (sscanf(val, "%lld,%lld,%lld", &a, &b, &c) == 3) { t.potrf_widths[0] = a; t.potrf_widths[1] = b; t.potrf_widths[2] = c; }
+            continue;
+        }
+        if (len == 12 && memcmp(kv, "GPX_MG_BCAST", 12) == 0) { t.mg_bcast_set = true; t.mg_bcast_sag = strcmp(val, "sag") == 0; continue; }
+        if (len == 12 && memcmp(kv, "GPX_RCCL_LIB", 12) == 0) { snprintf(t.rccl_lib, sizeof(t.rccl_lib), "%s", val); continue; }
+        for (const TuneEntry &en : g_tune_table) {
+            if (en.len != len || memcmp(en.name, kv, len) != 0) continue;
+            char *base = (char *)&t;
+            switch (en.kind) {
+            case TK_FLAG: *(bool *)(base + en.off) = true; break;
+            case TK_I64: *(int64_t *)(base + en.off) = (int64_t)atoll(val); break;
+            case TK_I64_SET: *(int64_t *)(base + en.off) = (int64_t)atoll(val); *(bool *)(base + en.off2) = true; break;
+            case TK_I64_2: ((int64_t *)(base + en.off))[0] = ((int64_t *)(base + en.off))[1] = (int64_t)atoll(val); break;
+            }
+            break;
+        }
+    }
+    g_tune = t;
+    g_tune_refreshes.fetch_add(1, std::memory_order_relaxed);
+}
+}  // namespace gpx
+
+extern "C" int gpx_debug_tune_refreshes(int64_t *count)
+{
+    if (!count) return GPX_ERR_ARG;
+    *count = gpx::tune_refresh_count();
+    return GPX_OK;
+}
+
+namespace gpx {
 // ---- profiling registry -----------------------------------------------------
 // One registry for all host threads (mlii drives one handle per thread): every access is
 // under g_prof_mu, a scope ends the record it began (by index), and the registry is capped so a
@@ -128,7 +197,7 @@ const char *prof_class_name(int cls)
 }
 bool roctx_push(const char *name)
 {
-    if (!env_set("GPX_ROCTX")) return false;
+    if (!tune().roctx) return false;
     {
         std::lock_guard<std::mutex> lk(g_roctx_mu);
         if (!g_roctx.tried) {

@@ -618,13 +618,13 @@ static int trsv_ops_prepare(const T *L, int64_t n, int64_t ldl, void *buf, hipSt
 
 static bool trsv_ops_enabled()
 {
-    return env_i64("GPX_TRSV_OPS", 1) != 0;
+    return tune().trsv_ops != 0;
 }
 // below this the ~0.7 ms of operator products (11 under-filled launches) costs what the shorter steps save
 // (n = 8192: 1.17 vs 1.10 ms for both sweeps; n = 16384: 1.78 vs 2.49; n = 65536: 9.7 vs 12.1)
 static int64_t trsv_ops_min_n()
 {
-    return std::max<int64_t>(2 * OB, env_i64("GPX_TRSV_OPS_MIN", 10240));
+    return std::max<int64_t>(2 * OB, tune().trsv_ops_min);
 }
 
 template <typename T>
@@ -645,7 +645,7 @@ static int trsv_t(const T *L, int64_t n, int64_t ldl, T *b, T *x, int transpose,
     GPX_TRY(scratch((size_t)nbt * sLinv * sizeof(T), &scr));
     T *Linv = (T *)scr;
     const int aligned = (((uintptr_t)L) % (2 * sizeof(T)) == 0) && (ldl % 2 == 0);
-    const int ablate = (int)env_i64("GPX_TRSV_ABLATE", 0);   // timing diagnostics only
+    const int ablate = (int)tune().trsv_ablate;   // timing diagnostics only
     const int64_t nb = cdiv(ncols, TB);
     auto width = [&](int64_t blk) { return (int)std::min<int64_t>(TB, ncols - blk * TB); };
     // operator form: square systems of at least two full blocks, aligned rows, one system
@@ -677,7 +677,7 @@ static int trsv_t(const T *L, int64_t n, int64_t ldl, T *b, T *x, int transpose,
         if (fresh) GPX_TRY(trsv_ops_prepare<T>(L, n, ldl, buf, st, dtype, ops ? std::min(ops->built, nfull) : 0, nfull));
         if (ops) { ops->valid = true; ops->built = nfull; }
         const T *W = (const T *)buf, *Wt = W + nfull * BS, *Tf = Wt + 2 * nfull * BS, *Tb = Tf + nfull * BS;
-        const bool wide = env_i64("GPX_TRSV_OP_PARTS", 32) == 32;
+        const bool wide = tune().trsv_op_parts == 32;
         const int NCH = wide ? OB / (TBT / 32) : OB / (TBT / 8);
         if (!transpose) {
             for (int64_t k = 0; k < nfull; ++k) {
@@ -766,7 +766,7 @@ static int trsv_t(const T *L, int64_t n, int64_t ldl, T *b, T *x, int transpose,
             route_hit(RT_TRSV_OPS);
             const int64_t nfull = n / OB, BS = (int64_t)OB * OB;
             const T *W = (const T *)ops->buf, *Wt = W + nfull * BS, *Tb = Wt + 3 * nfull * BS;
-            const bool wide = env_i64("GPX_TRSV_OP_PARTS", 32) == 32;
+            const bool wide = tune().trsv_op_parts == 32;
             const int NCH = wide ? OB / (TBT / 32) : OB / (TBT / 8);
             for (int64_t k = kpart - 1; k >= 0; --k) {
                 const int64_t k0 = k * OB, q0 = k0 + OB;
@@ -937,7 +937,7 @@ int trsm_right_lt(int dtype, const void *L, int64_t n, int64_t ldl, void *X, int
     // is ONE product with W_k = inv(L_kk) (into a scratch block, copied back) instead of eight 64-wide substitutions with
     // seven small products between them -- 16 latency-bound launches a block, which were most of a posterior covariance
     // (n = 8192, m = 1024: cov 11.0 -> see DESIGN 3.3).  The operators are completed here if the factor has only some.
-    if (ops && trsv_ops_ahead_ok(dtype, L, n, ldl) && env_i64("GPX_TRSM_OPS", 1) != 0 && ldx % (16 / (int64_t)es) == 0 &&
+    if (ops && trsv_ops_ahead_ok(dtype, L, n, ldl) && tune().trsm_ops != 0 && ldx % (16 / (int64_t)es) == 0 &&
         ((uintptr_t)X) % 16 == 0) {
         const int64_t nfull = n / OB, BS = (int64_t)OB * OB;
         if (!ops->valid) GPX_TRY(trsv_ops_build_upto(dtype, L, n, ldl, ops, nfull, st));
@@ -960,7 +960,7 @@ int trsm_right_lt(int dtype, const void *L, int64_t n, int64_t ldl, void *X, int
             return GPX_OK;
         }
     }
-    const int64_t nb_env = env_i64("GPX_TRSM_NB", 0);
+    const int64_t nb_env = tune().trsm_nb;
     const int64_t NB = nb_env > 0 ? nb_env : (n >= 8192 ? 512 : 256);
     auto Lp = [&](int64_t r, int64_t c) { return (const char *)L + (r * ldl + c) * es; };
     auto Xp = [&](int64_t c) { return (char *)X + c * es; };

@@ -185,6 +185,10 @@ int gpx_debug_route_count(int route, int64_t *count);
  * `rocprofv3 --marker-trace`; libroctx64.so is loaded on first use; 0 while the switch is off) */
 int gpx_debug_roctx_ranges(int64_t *count);
 int gpx_debug_route_reset(void);
+/* Switch snapshots taken so far: every entry point re-reads the GPX_* environment variables ONCE for the calling thread
+ * (one pass over `environ`; csrc/gpx_tune.h is the table of all of them); nothing below an entry point reads the
+ * environment -- libgpx.so does not import getenv. */
+int gpx_debug_tune_refreshes(int64_t *count);
 
 /* ------------------------------------------------- device-level hot path -- */
 

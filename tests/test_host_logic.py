@@ -38,6 +38,37 @@ def test_library_exports_every_declared_symbol():
     assert lib.gpx_version() == 100
 
 
+def test_library_never_calls_getenv():
+    """Every GPX_* switch is read through ONE snapshot per API call (csrc/gpx_tune.h: a pass over `environ` at the entry
+    point), never by a getenv at its point of use -- round 4 had 66 such sites, a dozen of them per panel launch.  The
+    library does not even import getenv; every name in the table is documented in DESIGN.md, and no source file reads a
+    switch that is not in the table."""
+    import subprocess
+    und = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in und, [l for l in und.splitlines() if "getenv" in l]
+    csrc = os.path.join(ROOT, "gaussian_processes_amd", "csrc")
+    table = open(os.path.join(csrc, "gpx_tune.h")).read()
+    names = set(re.findall(r'"(GPX_[A-Z0-9_]+)"', table)) | {"GPX_POTRF_WIDTHS", "GPX_MG_BCAST", "GPX_RCCL_LIB"}
+    assert len(names) >= 55
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    missing = [n for n in sorted(names) if ("`%s`" % n) not in design and ("`%s=" % n) not in design]
+    assert not missing, missing
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".h")) and f != "gpx_tune.h":
+            src = open(os.path.join(csrc, f)).read()
+            assert not re.search(r"\bgetenv\s*\(|env_i64\s*\(|env_set\s*\(", src), f
+            for n in re.findall(r'"(GPX_[A-Z0-9_]+)"', src):
+                assert n in names, (f, n)
+    # a snapshot without a GPU: the counter moves with every entry point (here one that fails for lack of arguments)
+    lib = _lib.load()
+    import ctypes
+    a, b = ctypes.c_int64(), ctypes.c_int64()
+    assert lib.gpx_debug_tune_refreshes(ctypes.byref(a)) == 0
+    lib.gpx_d_potrf(0, None, -1, 0, None, None)
+    assert lib.gpx_debug_tune_refreshes(ctypes.byref(b)) == 0
+    assert b.value == a.value + 1
+
+
 def test_no_cpu_fallback_without_gpu():
     if _lib.device_count() > 0:
         pytest.skip("a GPU is present")
