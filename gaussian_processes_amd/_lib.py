@@ -124,6 +124,7 @@ _SIGNATURES = {
     "gpx_debug_route_count": (c_int, [c_int, POINTER(c_int64)]),
     "gpx_debug_roctx_ranges": (c_int, [POINTER(c_int64)]),
     "gpx_debug_tune_refreshes": (c_int, [POINTER(c_int64)]),
+    "gpx_debug_leaf_selfcheck": (c_int, [c_int, POINTER(c_int)]),
     "gpx_debug_route_reset": (c_int, []),
     "gpx_debug_mg_inject_info": (c_int, [c_void_p, c_int]),
     "gpx_debug_mg_plan": (c_int, [c_int64, c_int64, c_int, c_int, c_int64, POINTER(c_int64), c_int]),

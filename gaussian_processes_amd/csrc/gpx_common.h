@@ -110,6 +110,7 @@ struct DeviceGuard {
 // one thread (each on its own stream) would otherwise race on those buffers (seen once as a wrong log_lh in the four-handle
 // test of tests/test_gpu_configs.py, when faster panels changed the overlap).  One event record per API call; nothing is
 // recorded or waited for while a stream is being captured.
+void stream_epoch_bump();          // call before destroying any stream (see TurnState, gpx_runtime.hip)
 struct StreamTurn {
     hipStream_t st;
     explicit StreamTurn(hipStream_t s);

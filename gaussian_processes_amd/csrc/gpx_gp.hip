@@ -222,6 +222,7 @@ int gpx_gp_destroy(gpx_gp_t *g)
     if (!g) return GPX_OK;
     gpx::DeviceGuard guard__(g->device);
     if (g->st) (void)hipStreamSynchronize(g->st);
+    stream_epoch_bump();                                       // (StreamTurn: a later stream at this one's address is a different stream)
     if (g->st_ops) { (void)hipStreamSynchronize(g->st_ops); (void)hipStreamDestroy(g->st_ops); }
     if (g->ev_ops) (void)hipEventDestroy(g->ev_ops);
     void *bufs[] = {g->x, g->y, g->A, g->alpha, g->t0, g->t1, g->scal, g->bw, g->ops.buf};
@@ -821,6 +822,7 @@ int gpx_gemm_nt_host(double *C, const double *A, const double *B, int64_t M, int
 int gpx_cholesky(double *L, const double *A, int64_t n, int *info)
 {
     GPX_TRY(ensure_device());
+    gpx::StreamTurn turn__(nullptr);                           // (this thread's scratch buffers: one stream at a time, gpx_common.h)
     GPX_ARG(n >= 0 && info, "bad arguments");
     *info = 0;
     if (n == 0) return GPX_OK;
@@ -841,6 +843,7 @@ int gpx_cholesky(double *L, const double *A, int64_t n, int *info)
 int gpx_cho_solve(const double *L, int64_t n, double *b)
 {
     GPX_TRY(ensure_device());
+    gpx::StreamTurn turn__(nullptr);                           // (this thread's scratch buffers: one stream at a time, gpx_common.h)
     GPX_ARG(n >= 0, "n < 0");
     if (n == 0) return GPX_OK;
     GPX_ARG(L && b, "NULL pointer");

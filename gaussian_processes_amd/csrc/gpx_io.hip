@@ -155,7 +155,11 @@ int gpx_gp_save(gpx_gp_t *g, const char *path)
     File fp;
     fp.f = fdopen(tfd, "wb");
     if (!fp.f) { (void)close(tfd); set_error("gpx_gp_save: cannot open %s for writing", tmp_path.c_str()); return GPX_ERR_ARG; }
-    (void)fchmod(tfd, 0644);                                        // mkstemp creates 0600; a checkpoint is an ordinary file
+    {   // mkstemp creates 0600; a checkpoint is an ordinary file: what fopen would have given it under the caller's umask
+        const mode_t um = umask(0);
+        (void)umask(um);
+        (void)fchmod(tfd, 0666 & ~um);
+    }
     bool ok = fwrite(&hd, sizeof(hd), 1, fp.f) == 1;
     std::vector<double> v;
     GPX_TRY(vec_d2h_f64(g, g->x, n * g->d, v)); ok = ok && fwrite(v.data(), 8, v.size(), fp.f) == v.size();
@@ -360,6 +364,7 @@ int gpx_kmat_host(int kernel, int member, double *out, const double *x1, int64_t
                              hipMemcpyDeviceToHost, st[p & 1]) != hipSuccess ||
             hipStreamSynchronize(st[p & 1]) != hipSuccess) { rc = GPX_ERR_HIP; break; }
     }
+    stream_epoch_bump();
     for (int i = 0; i < 2; ++i) if (st[i]) { (void)hipStreamSynchronize(st[i]); (void)hipStreamDestroy(st[i]); }
     if (rc == GPX_ERR_HIP) { set_error("gpx_kmat_host: HIP failure while streaming panels"); return rc; }
     if (rc != GPX_OK) return rc;

@@ -569,60 +569,69 @@ __device__ __forceinline__ void w1_steps(F &f, std::integer_sequence<int, Is...>
 //   * an LDS store of a result needs 4 wait states for register 0 and 17 for register 3;
 //   * an MFMA whose source register (VGPR or AGPR, srcA or srcB) a VALU instruction wrote 0 - 1 wait states earlier reads the
 //     old value (2 and more: right) -- hipcc puts such copies in front of an asm operand as it likes, so every asm MFMA
-//     starts with an s_nop 2 (3 wait states);
+//     starts with an s_nop 3 (4 wait states: twice the measured need);
 //   * a VALU write into the destination of an MFMA in flight, or over its sources, is held back correctly (but costs the
 //     writer the MFMA's whole duration: the strip MFMAs' destinations stay allocated for that reason);
 //   * back-to-back accumulation into one tile is right.
 // The leaf uses register 0 of the strip MFMAs only, reads other registers of a tile only at the places marked "register 3"
 // below, and keeps every read of a tile behind an anchor that follows its last writer by an MFMA or by 18 wait states.
+// The wait states below are MEASURED properties of gfx950's matrix pipe, not architectural guarantees: this file must not be
+// compiled for any other target (the Makefile's ARCH is overridable), and the library checks the leaf against the
+// compiler-scheduled one on the device it actually runs on before it uses it (leaf_selfcheck, gpx_panel.hip).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "gpx_leaf.h: the asm-scheduled MFMA leaf carries wait states measured on gfx950 only"
+#endif
+// Margins (round 5): the probe found the thresholds moving under contention (an LDS store of register 3 passes with 16 wait
+// states alone and fails contended), so every anchor carries the measured minimum plus a third: register-3 readers 24 wait
+// states (measured 18), LDS stores of register 0 at least 8 (measured 4).  ~6 cycles per anchor, ~0.1 us a leaf.
 typedef double w1_v4 __attribute__((ext_vector_type(4)));
 // ACC_A: the tiles live in AGPRs (the one-workgroup-per-CU instantiation, 512 registers a lane) or in VGPRs (the two-per-CU
 // instantiation: with 256 registers a lane, AGPRs set aside for the leaf would be taken from the whole kernel)
 template <bool ACC_A>
 __device__ __forceinline__ void w1_mfma_acc(w1_v4 &c, double a, double b)             // c += a (16 x 4) . b (4 x 16)
 {
-    if constexpr (ACC_A) asm volatile("s_nop 2\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-    else asm volatile("s_nop 2\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+    if constexpr (ACC_A) asm volatile("s_nop 3\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    else asm volatile("s_nop 3\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
 template <bool ACC_A>
 __device__ __forceinline__ w1_v4 w1_mfma_strip(double a, double b)                     // a . b (rows 0 .. 3 = register 0 are what is wanted), b a register of a tile
 {
     w1_v4 d;
-    if constexpr (ACC_A) asm volatile("s_nop 2\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(b));
-    else asm volatile("s_nop 2\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
+    if constexpr (ACC_A) asm volatile("s_nop 3\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(b));
+    else asm volatile("s_nop 3\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
     return d;
 }
-// anchors on one to four tiles; NOPS: with 18 wait states in front (a register-3 read follows, see above)
+// anchors on one to four tiles; NOPS: with 24 wait states in front (a register-3 read follows: 18 measured, see above)
 template <bool ACC_A, bool NOPS>
 __device__ __forceinline__ void w1_anchor(w1_v4 &t0)
 {
-    if constexpr (ACC_A && NOPS) asm volatile("s_nop 15\n\ts_nop 1" : "+a"(t0));
+    if constexpr (ACC_A && NOPS) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(t0));
     if constexpr (ACC_A && !NOPS) asm volatile("" : "+a"(t0));
-    if constexpr (!ACC_A && NOPS) asm volatile("s_nop 15\n\ts_nop 1" : "+v"(t0));
+    if constexpr (!ACC_A && NOPS) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(t0));
     if constexpr (!ACC_A && !NOPS) asm volatile("" : "+v"(t0));
 }
 template <bool ACC_A, bool NOPS>
 __device__ __forceinline__ void w1_anchor(w1_v4 &t0, w1_v4 &t1)
 {
-    if constexpr (ACC_A && NOPS) asm volatile("s_nop 15\n\ts_nop 1" : "+a"(t0), "+a"(t1));
+    if constexpr (ACC_A && NOPS) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(t0), "+a"(t1));
     if constexpr (ACC_A && !NOPS) asm volatile("" : "+a"(t0), "+a"(t1));
-    if constexpr (!ACC_A && NOPS) asm volatile("s_nop 15\n\ts_nop 1" : "+v"(t0), "+v"(t1));
+    if constexpr (!ACC_A && NOPS) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(t0), "+v"(t1));
     if constexpr (!ACC_A && !NOPS) asm volatile("" : "+v"(t0), "+v"(t1));
 }
 template <bool ACC_A, bool NOPS>
 __device__ __forceinline__ void w1_anchor(w1_v4 &t0, w1_v4 &t1, w1_v4 &t2)
 {
-    if constexpr (ACC_A && NOPS) asm volatile("s_nop 15\n\ts_nop 1" : "+a"(t0), "+a"(t1), "+a"(t2));
+    if constexpr (ACC_A && NOPS) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(t0), "+a"(t1), "+a"(t2));
     if constexpr (ACC_A && !NOPS) asm volatile("" : "+a"(t0), "+a"(t1), "+a"(t2));
-    if constexpr (!ACC_A && NOPS) asm volatile("s_nop 15\n\ts_nop 1" : "+v"(t0), "+v"(t1), "+v"(t2));
+    if constexpr (!ACC_A && NOPS) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(t0), "+v"(t1), "+v"(t2));
     if constexpr (!ACC_A && !NOPS) asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2));
 }
 template <bool ACC_A, bool NOPS>
 __device__ __forceinline__ void w1_anchor(w1_v4 &t0, w1_v4 &t1, w1_v4 &t2, w1_v4 &t3)
 {
-    if constexpr (ACC_A && NOPS) asm volatile("s_nop 15\n\ts_nop 1" : "+a"(t0), "+a"(t1), "+a"(t2), "+a"(t3));
+    if constexpr (ACC_A && NOPS) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(t0), "+a"(t1), "+a"(t2), "+a"(t3));
     if constexpr (ACC_A && !NOPS) asm volatile("" : "+a"(t0), "+a"(t1), "+a"(t2), "+a"(t3));
-    if constexpr (!ACC_A && NOPS) asm volatile("s_nop 15\n\ts_nop 1" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
+    if constexpr (!ACC_A && NOPS) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
     if constexpr (!ACC_A && !NOPS) asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
 }
 
@@ -838,12 +847,13 @@ __device__ __forceinline__ void factor64_wave(TS (*sM)[PT], TS (*sW)[PT], double
             }
         };
         constexpr int defer_count = (3 - jj0) + (last ? 0 : (4 - jn) * (5 - jn) / 2 - 1);     // strips besides the critical one + updates besides it
-        // wave 1's operands of this step: the strips are complete (issued at least three stages ago), 5 wait states for the stores
+        // wave 1's operands of this step: the strips are complete (issued at least three stages ago), 8 wait states for the stores
+        // (register 0: 4 measured)
         auto publish = [&](unsigned flag_addr) {
-            if constexpr (jj0 == 0) asm volatile("s_nop 4" : "+v"(us[0]), "+v"(us[1]), "+v"(us[2]), "+v"(us[3]));
-            if constexpr (jj0 == 1) asm volatile("s_nop 4" : "+v"(us[1]), "+v"(us[2]), "+v"(us[3]));
-            if constexpr (jj0 == 2) asm volatile("s_nop 4" : "+v"(us[2]), "+v"(us[3]));
-            if constexpr (jj0 == 3) asm volatile("s_nop 4" : "+v"(us[3]));
+            if constexpr (jj0 == 0) asm volatile("s_nop 7" : "+v"(us[0]), "+v"(us[1]), "+v"(us[2]), "+v"(us[3]));
+            if constexpr (jj0 == 1) asm volatile("s_nop 7" : "+v"(us[1]), "+v"(us[2]), "+v"(us[3]));
+            if constexpr (jj0 == 2) asm volatile("s_nop 7" : "+v"(us[2]), "+v"(us[3]));
+            if constexpr (jj0 == 3) asm volatile("s_nop 7" : "+v"(us[3]));
             if constexpr (RING < IB / 4 && jt >= RING) {          // wave 1 has taken the operands of step jt - RING?
                 int taken;
                 do {

@@ -647,7 +647,8 @@ static int mg_new(gpx_mg **out, int dtype, int kernel, int64_t n, int d, int64_t
     GPX_ARG((g) != nullptr, "mg is NULL");                                   \
     gpx::tune_refresh();                                                     \
     gpx::DeviceGuard guard__((g)->device);                                   \
-    if (guard__.rc != GPX_OK) return guard__.rc
+    if (guard__.rc != GPX_OK) return guard__.rc;                             \
+    gpx::StreamTurn turn__((g)->S)      /* this thread's scratch buffers: one stream at a time (gpx_common.h) */
 
 extern "C" {
 
@@ -676,6 +677,7 @@ int gpx_mg_destroy(gpx_mg_t *g)
     for (gpx::TrsvOps &o : g->ops) if (o.buf) (void)hipFree(o.buf);
     for (hipEvent_t e : g->ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : g->tev) (void)hipEventDestroy(e);
+    stream_epoch_bump();
     if (g->S) (void)hipStreamDestroy(g->S);
     if (g->Q) (void)hipStreamDestroy(g->Q);
     if (g->B) (void)hipStreamDestroy(g->B);

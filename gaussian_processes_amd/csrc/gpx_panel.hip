@@ -35,6 +35,8 @@
 
 #include <algorithm>
 #include <optional>
+#include <mutex>
+#include <vector>
 #include <stdlib.h>
 
 namespace gpx {
@@ -696,6 +698,35 @@ int64_t panel_res_max()
     return std::min<int64_t>(v, (int64_t)RES_MAXSTEPS * IB);
 }
 
+// ---- the asm-scheduled leaf is checked on the device it runs on --------------------------------------------------------
+// factor64_wave (gpx_leaf.h) issues its MFMAs from volatile asm with wait states that were MEASURED on gfx950
+// (tools/mfma_hazard_probe_gen.py), not taken from a hazard table the compiler maintains; a miss would not fault, it would
+// leave about single precision in rows 12 .. 15 of some tiles.  Before the first panel of a process uses it on a device,
+// both of its instantiations (LV = 4: tiles in AGPRs, LV = 5: in VGPRs; fp64 and fp32 storage) factor a full-mantissa
+// 256 x 256 panel -- four leaves, three hand-offs -- BESIDE a product that keeps every matrix pipe busy (the probe's
+// thresholds moved under contention), and the result is compared with the compiler-scheduled MFMA leaf (LV = 1, whose
+// hazards hipcc handles) on the same input: agreement to 1e-12 relative or the library falls back to LV = 1 for the rest of
+// the process and says so on stderr (gpx_debug_leaf_selfcheck: 1 passed, 2 failed -> fallback, 0 not run yet).
+static thread_local int g_leaf_force = 0;                      // the self-check's own launches: 1 / 4 / 5, no check
+static std::mutex g_leaf_mu;
+static int g_leaf_state[RES_MAXDEV] = {};                      // 0 unknown, 1 ok, 2 failed (guarded by g_leaf_mu)
+static int leaf_selfcheck_run(int dev, hipStream_t st);
+static bool leaf_asm_ok(hipStream_t st = nullptr)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return true; }
+    if (dev < 0 || dev >= RES_MAXDEV) return true;
+    std::lock_guard<std::mutex> lk(g_leaf_mu);
+    if (g_leaf_state[dev] == 0) {
+        const int rc = leaf_selfcheck_run(dev, st);
+        if (rc == 1 || rc == 2) g_leaf_state[dev] = rc;         // (anything else: could not run now -- e.g. a capture is open: ask again)
+        if (rc == 2)
+            fprintf(stderr, "[gpx] WARNING: the asm-scheduled MFMA leaf failed its self-check on device %d: "
+                            "falling back to the compiler-scheduled leaf (GPX_LEAF=1)\n", dev);
+    }
+    return g_leaf_state[dev] != 2;
+}
+
 template <typename T>
 static int panel_res_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int64_t kb, int *info_dev, hipStream_t st,
                        const Batch *bt, int64_t kpre, hipEvent_t done)
@@ -753,7 +784,10 @@ static int panel_res_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int
     // (panels of up to GPX_LEAF4_ROWS rows take the LV = 4 instantiation beside an update too: n = 8192 5.94 -> 5.79 ms; taller
     //  ones lose more CUs to its one-workgroup-per-CU footprint than the leaf gives back: n = 16384 27.85 -> 28.4 ms)
     const int64_t leaf_dflt = (excl || (!bt && rows <= tune().leaf4_rows[F64 ? 0 : 1])) ? 4 : 1;
-    const bool v4 = (tune().leaf_set ? tune().leaf : leaf_dflt) == 4;   // (fp32: N = 32768 94.5 -> 94.2 ms with 5120)
+    // (the asm-scheduled leaf only where it has passed its self-check on this device; the check's own launches force a level)
+    const bool asm_ok = g_leaf_force != 0 || leaf_asm_ok(st);
+    const int64_t leaf_want = g_leaf_force ? g_leaf_force : (tune().leaf_set ? tune().leaf : -1);
+    const bool v4 = asm_ok && (leaf_want >= 0 ? leaf_want : leaf_dflt) == 4;   // (fp32: N = 32768 94.5 -> 94.2 ms with 5120)
     // A CU of its own for every workgroup of a SHORT panel (single matrix, rows <= GPX_PANEL_EXCL_ROWS).  Per-step stamps
     // of every leaf variant say the same thing (profiles/r04_leaf_steps_*.log): a leaf step takes 3 - 4 times longer while
     // workgroups of the trailing update share the CU (matrix pipe, issue slots) -- a panel took 120 us alone and 140 - 230 us
@@ -777,7 +811,7 @@ static int panel_res_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int
     // every other fp64 panel (lock-step batches, panels taller than GPX_LEAF4_ROWS): the same leaf in the LV = 5 instantiation --
     // two workgroups a CU like the round-3 kernel (a 10 KB ring of operand slots instead of 40 KB, no operand prefetch)
     // (fp32 panels hand their diagonal blocks to the same fp64 leaf wherever they used the fp32 MFMA leaf: GPX_LEAF=1 keeps that one)
-    const bool v5 = !v4 && (tune().leaf_set ? tune().leaf : 5) == 5;
+    const bool v5 = asm_ok && !v4 && (leaf_want >= 0 ? leaf_want : 5) == 5;
     // TALL panels of single matrices (256 columns, more than GPX_POTRF_TALL_ROWS rows): only the diagonal workgroups stay on the
     // resident kernel; the rows below are products on the GEMM kernel (winv256_kernel above has the why)
     // MEASURED (round 5, profiles/r05_ab_tall_*.log, r05_timeline_n65536_*.txt, r05_panel_alone_tall_vs_resident.log) and OFF by
@@ -852,6 +886,94 @@ int potrf_panel_res(int dtype, void *A, int64_t lda, int64_t n, int64_t r0, int6
     return panel_res_t<float>((float *)A, lda, n, r0, c0, kb, info_dev, st, bt, kpre, done);
 }
 
+// 1 passed, 2 failed, 0 could not run (see leaf_asm_ok).  Called under g_leaf_mu.
+static int leaf_selfcheck_run(int dev, hipStream_t st)
+{
+    (void)dev;
+    constexpr int64_t N = RES_MAXSTEPS * IB, LD = N, GM = 4096, GK = 512;
+    // not while any capture is open on this thread's streams (synchronising calls are illegal then)
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (cs != hipStreamCaptureStatusNone) return 0;
+    // a full-mantissa SPD panel: A = B B^T / 8 + 2 I, B (N x 32) from a fixed linear congruential stream
+    constexpr int64_t KB = 32;
+    std::vector<double> hA((size_t)N * LD), hB((size_t)N * KB);
+    unsigned long long z = 0x9E3779B97F4A7C15ull;
+    for (auto &v : hB) { z = z * 6364136223846793005ull + 1442695040888963407ull; v = (double)(int64_t)(z >> 11) / 9007199254740992.0 - 0.5; }
+    for (int64_t i = 0; i < N; ++i)
+        for (int64_t j = 0; j <= i; ++j) {
+            double acc = 0;
+            for (int64_t k = 0; k < KB; ++k) acc += hB[i * KB + k] * hB[j * KB + k];
+            hA[i * LD + j] = hA[j * LD + i] = acc / 8.0 + (i == j ? 2.0 : 0.0);
+        }
+    std::vector<float> hAf(hA.begin(), hA.end());
+    void *dA = nullptr, *dG = nullptr, *dC = nullptr; int *dinfo = nullptr;
+    hipStream_t s1 = nullptr, s2 = nullptr;
+    int verdict = 0;
+    auto cleanup = [&]() {
+        stream_epoch_bump();
+        if (s1) { (void)hipStreamSynchronize(s1); (void)hipStreamDestroy(s1); }
+        if (s2) { (void)hipStreamSynchronize(s2); (void)hipStreamDestroy(s2); }
+        (void)hipFree(dA); (void)hipFree(dG); (void)hipFree(dC); (void)hipFree(dinfo);
+    };
+#define GPX_SC(call) do { if ((call) != hipSuccess) { (void)hipGetLastError(); cleanup(); return 0; } } while (0)
+    GPX_SC(hipMalloc(&dA, (size_t)N * LD * 8));
+    GPX_SC(hipMalloc(&dG, (size_t)GM * GK * 8));
+    GPX_SC(hipMalloc(&dC, (size_t)GM * GM * 8));
+    GPX_SC(hipMalloc((void **)&dinfo, sizeof(int)));
+    GPX_SC(hipMemset(dG, 0, (size_t)GM * GK * 8));
+    GPX_SC(hipMemset(dC, 0, (size_t)GM * GM * 8));
+    GPX_SC(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
+    GPX_SC(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+    auto factor = [&](int dtype, int level, bool contended, std::vector<double> &L) -> bool {
+        const size_t es = esize(dtype);
+        if (hipMemcpy(dA, dtype == GPX_F64 ? (const void *)hA.data() : (const void *)hAf.data(), (size_t)N * LD * es, hipMemcpyHostToDevice) != hipSuccess) return false;
+        if (hipMemset(dinfo, 0, sizeof(int)) != hipSuccess) return false;
+        if (contended)                                           // ~1 ms of products on every matrix pipe of the chip
+            for (int r = 0; r < 3; ++r)
+                if (gemm_nt(GPX_F64, GM, GM, GK, dG, GK, dG, GK, dC, GM, 1.0, GPX_FULL, 0, 0, s2) != GPX_OK) return false;
+        g_leaf_force = level;
+        const int rc = potrf_panel_res(dtype, dA, LD, N, 0, 0, N, dinfo, s1, nullptr, 0, nullptr);
+        g_leaf_force = 0;
+        if (rc != GPX_OK) return false;
+        if (hipStreamSynchronize(s1) != hipSuccess || hipStreamSynchronize(s2) != hipSuccess) return false;
+        int info = -1;
+        if (hipMemcpy(&info, dinfo, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess || info != 0) return false;
+        L.assign((size_t)N * N, 0.0);
+        if (dtype == GPX_F64) {
+            std::vector<double> t((size_t)N * LD);
+            if (hipMemcpy(t.data(), dA, t.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return false;
+            for (int64_t i = 0; i < N; ++i) for (int64_t j = 0; j <= i; ++j) L[i * N + j] = t[i * LD + j];
+        } else {
+            std::vector<float> t((size_t)N * LD);
+            if (hipMemcpy(t.data(), dA, t.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
+            for (int64_t i = 0; i < N; ++i) for (int64_t j = 0; j <= i; ++j) L[i * N + j] = t[i * LD + j];
+        }
+        return true;
+    };
+    bool ran = true, good = true;
+    for (int dtype : {GPX_F64, GPX_F32}) {
+        std::vector<double> ref, got;
+        // (fp32 storage: the asm leaf works in fp64 on converted blocks and rounds once; the fp32 MFMA leaf it is compared
+        //  with accumulates in fp32 -- the bound is fp32 round-off there, which a single-precision slip in an fp64 tile does not
+        //  exceed either: the fp64 run is the discriminating one, the fp32 run checks the instantiation's plumbing)
+        const double tol = dtype == GPX_F64 ? 1e-12 : 2e-5;
+        if (!factor(dtype, 1, false, ref)) { ran = false; break; }
+        for (int level : {4, 5})
+            for (int pass = 0; pass < 2 && ran; ++pass) {
+                if (!factor(dtype, level, pass == 1, got)) { ran = false; break; }
+                double err = 0, scale = 0;
+                for (size_t i = 0; i < ref.size(); ++i) { err = std::max(err, fabs(got[i] - ref[i])); scale = std::max(scale, fabs(ref[i])); }
+                if (!(err <= tol * scale)) good = false;
+            }
+        if (!ran) break;
+    }
+#undef GPX_SC
+    verdict = !ran ? 0 : (good ? 1 : 2);
+    cleanup();
+    return verdict;
+}
+
 // fold the update by the columns to the left into the panel kernel?  (short panels only: a tall panel's workgroups
 // run in several rounds and the tuned GEMM does the same update faster than they do)
 bool panel_res_fold(int64_t rows, int64_t kpre, int64_t kb, size_t es, int64_t lda, const void *base)
@@ -863,6 +985,20 @@ bool panel_res_fold(int64_t rows, int64_t kpre, int64_t kb, size_t es, int64_t l
 }
 
 }  // namespace gpx
+
+// the state of the asm leaf's self-check on the current device: 0 not run yet, 1 passed, 2 failed (the library then uses the
+// compiler-scheduled leaf); run_now != 0 runs it if it has not run
+extern "C" int gpx_debug_leaf_selfcheck(int run_now, int *state)
+{
+    GPX_TRY(gpx::ensure_device());
+    if (!state) return GPX_ERR_ARG;
+    if (run_now) (void)gpx::leaf_asm_ok();
+    int dev = 0;
+    GPX_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(gpx::g_leaf_mu);
+    *state = (dev >= 0 && dev < gpx::RES_MAXDEV) ? gpx::g_leaf_state[dev] : 0;
+    return GPX_OK;
+}
 
 // diagnostic: the `at`-th resident panel launch from now stores 8 words per workgroup into dev_buffer (tools/panel_stamps.py)
 extern "C" int gpx_debug_panel_stamps(void *dev_buffer, int at)

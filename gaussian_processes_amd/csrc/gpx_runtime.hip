@@ -232,7 +232,12 @@ extern "C" int gpx_debug_roctx_ranges(int64_t *count)
 
 // ---- StreamTurn (gpx_common.h): one turn at a time for the streams a host thread drives ----
 namespace gpx {
-struct TurnState { hipEvent_t ev = nullptr; hipStream_t last = nullptr; bool have = false; };
+// `last` is compared together with the stream EPOCH at which it was recorded: the library bumps the epoch whenever it
+// destroys a stream (gpx_stream_destroy, a handle's own streams), so a new stream that happens to get a destroyed one's
+// address is not mistaken for it.  (Streams the caller creates and destroys with HIP directly are the caller's to order.)
+std::atomic<unsigned long long> g_stream_epoch{1};
+void stream_epoch_bump() { g_stream_epoch.fetch_add(1, std::memory_order_relaxed); }
+struct TurnState { hipEvent_t ev = nullptr; hipStream_t last = nullptr; bool have = false; unsigned long long epoch = 0; };
 static thread_local TurnState g_turn[16];                      // per device
 
 static TurnState *turn_state()
@@ -250,7 +255,7 @@ static bool capturing(hipStream_t st)
 StreamTurn::StreamTurn(hipStream_t s) : st(s)
 {
     TurnState *t = turn_state();
-    if (!t || !t->have || t->last == st || capturing(st)) return;
+    if (!t || !t->have || (t->last == st && t->epoch == g_stream_epoch.load(std::memory_order_relaxed)) || capturing(st)) return;
     if (hipStreamWaitEvent(st, t->ev, 0) != hipSuccess) (void)hipGetLastError();
 }
 StreamTurn::~StreamTurn()
@@ -258,7 +263,7 @@ StreamTurn::~StreamTurn()
     TurnState *t = turn_state();
     if (!t || capturing(st)) return;
     if (!t->ev && hipEventCreateWithFlags(&t->ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); t->ev = nullptr; return; }
-    if (hipEventRecord(t->ev, st) == hipSuccess) { t->last = st; t->have = true; }
+    if (hipEventRecord(t->ev, st) == hipSuccess) { t->last = st; t->have = true; t->epoch = g_stream_epoch.load(std::memory_order_relaxed); }
     else (void)hipGetLastError();
 }
 }  // namespace gpx
@@ -406,6 +411,7 @@ int gpx_stream_create(void **stream)
 int gpx_stream_destroy(void *stream)
 {
     if (!stream) return GPX_OK;
+    gpx::stream_epoch_bump();
     GPX_HIP(hipStreamDestroy(S(stream)));
     return GPX_OK;
 }

@@ -41,7 +41,12 @@
  *     not the host) for that call's work (round 4; before that it was the caller's
  *     duty, and gpx_gp_fit(gp, NULL) on several handles broke it).  Drive streams
  *     that should overlap from different host threads.  Nothing is ordered while a
- *     stream is being captured.  Handles
+ *     stream is being captured.  Since round 5 the multi-GPU handle's entries
+ *     (gpx_mg_*, on the handle's update stream) and the host-array helpers gpx_cholesky /
+ *     gpx_cho_solve (null stream) take their turn in the same way, and "another stream"
+ *     is decided by the stream AND an epoch the library bumps whenever it destroys one
+ *     (a new stream at a destroyed one's address is a different stream); streams the
+ *     caller destroys with HIP directly are the caller's to order.  Handles
  *     (gpx_gp_*) remember the device they were created on and make it current
  *     for the duration of every call (the caller's current device is restored);
  *     they synchronise their stream before they return -- the one exception is
@@ -189,6 +194,11 @@ int gpx_debug_route_reset(void);
  * (one pass over `environ`; csrc/gpx_tune.h is the table of all of them); nothing below an entry point reads the
  * environment -- libgpx.so does not import getenv. */
 int gpx_debug_tune_refreshes(int64_t *count);
+/* The asm-scheduled MFMA leaf of the panel kernel (csrc/gpx_leaf.h) carries wait states measured on gfx950; before a process
+ * first uses it on a device it is checked there against the compiler-scheduled leaf (full-mantissa 256 x 256 panel, alone and
+ * beside a product that loads every matrix pipe).  *state: 0 not run yet, 1 passed, 2 failed -- the library then uses the
+ * compiler-scheduled leaf and says so on stderr.  run_now != 0: run it now if it has not run. */
+int gpx_debug_leaf_selfcheck(int run_now, int *state);
 
 /* ------------------------------------------------- device-level hot path -- */
 

@@ -125,3 +125,82 @@ def test_tall_panel_route_above_16384_rows(monkeypatch, dtype):
     Kr[np.arange(len(rows)), rows] += s * s
     res = np.abs(Kr @ out["tall"][1] - y[rows]).max() / np.abs(y).max()
     assert res < (1e-9 if f64 else 2e-3), res
+
+
+# ------------------------------------------------------------------------- the asm leaf's self-check --
+def test_asm_leaf_self_check_passes_on_this_device(monkeypatch):
+    """The asm-scheduled leaf (csrc/gpx_leaf.h: wait states MEASURED on gfx950) is compared, on the device the process
+    runs on, with the compiler-scheduled leaf before its first use -- alone and beside a product that loads every matrix
+    pipe.  It must pass here (state 1); a fit then takes the asm leaf, and GPX_LEAF=1 still selects the other one: both
+    against the oracle."""
+    lib = _lib.load()
+    st = ctypes.c_int(-1)
+    _lib.check(lib.gpx_debug_leaf_selfcheck(1, ctypes.byref(st)))
+    assert st.value == 1, st.value
+    N, d = 1536, 3
+    X, y, _ = orc.synth_inputs(N, d, 4)
+    o = orc.OracleGP("gaussian", (1.0, 0.9), X, y, 0.7)
+    out = {}
+    for leaf in (None, "1", "5"):
+        if leaf is None:
+            monkeypatch.delenv("GPX_LEAF", raising=False)
+        else:
+            monkeypatch.setenv("GPX_LEAF", leaf)
+        g = gp.GP(gp.GaussianKernel(1.0, 0.9), X, y, s=0.7)
+        out[leaf] = float(g.log_lh)
+        np.testing.assert_allclose(out[leaf], o.log_lh, rtol=1e-10)
+        np.testing.assert_allclose(np.tril(g.Lxx), o.Lxx, rtol=1e-9, atol=1e-12)
+
+
+def test_four_host_threads_factor_n8192_concurrently():
+    """Every single-matrix panel of up to 8192 rows runs the one-workgroup-per-CU instantiation (LV = 4): with four host
+    threads factoring n = 8192 at once, 4 x 128 resident workgroups that each want a whole CU compete for 256 CUs and spin
+    on each other's flags.  Progress rests on in-order dispatch within a launch (a consumer is only ever placed after its
+    producers); a workgroup left unplaced past the spin bound would surface as info = -7 -> GPX_ERR_INTERNAL.  Six rounds of
+    four concurrent fits: every one succeeds and reproduces the single-threaded log_lh bit for bit."""
+    import threading
+    N, d = 8192, 8
+    X, y, _ = orc.synth_inputs(N, d, 4)
+    params, s = (1.0, 0.5 * np.sqrt(d)), 1.0
+
+    def one_fit():
+        g = gp.GP(gp.GaussianKernel(*params), X, y, s=s)
+        return float(g.log_lh)
+
+    ref = one_fit()
+    assert np.isfinite(ref)
+    res, errs = [], []
+
+    def worker():
+        try:
+            for _ in range(6):
+                res.append(one_fit())
+        except Exception as e:                                   # noqa: BLE001 -- reported below
+            errs.append(repr(e))
+
+    ts = [threading.Thread(target=worker) for _ in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    assert len(res) == 24 and all(v == ref for v in res), (ref, sorted(set(res)))
+
+
+def test_checkpoint_file_mode_follows_the_umask(tmp_path):
+    """gpx_gp_save writes through mkstemp (0600) and then gives the file what fopen would have given it: 0666 & ~umask."""
+    X, y, _ = orc.synth_inputs(300, 2, 4)
+    g = gp.GP(gp.GaussianKernel(1.0, 1.0), X, y, s=0.5)
+    old = os.umask(0o077)
+    try:
+        p1 = tmp_path / "a.gpx"
+        g.save_fitted(p1)
+        assert (os.stat(p1).st_mode & 0o777) == 0o600
+        os.umask(0o022)
+        p2 = tmp_path / "b.gpx"
+        g.save_fitted(p2)
+        assert (os.stat(p2).st_mode & 0o777) == 0o644
+    finally:
+        os.umask(old)
+    g2 = gp.GP.load_fitted(p2)
+    assert float(g2.log_lh) == float(g.log_lh)
