@@ -290,6 +290,23 @@ def main():
     params = np.array([h, w], dtype=np.float64)
     X, y, Xo = synth(N, d, m, npdt)
 
+    if world == 1 and os.environ.get("GPX_MG_REHEARSE"):
+        # GPX_MG_REHEARSE=rank,world: ONE process does that rank's share of a world-rank run of this workload on one GPU
+        # (multi_gpu.rehearse_rank: its own panels, packs and updates through the product's C schedule; the panels it does
+        # not own out of a resident single-GPU factor; every broadcast a delay that MODELS the transfer).  Not the headline
+        # measurement: the line says "rehearsal" in `metric`.
+        from gaussian_processes_amd import multi_gpu
+        r_, w_ = (int(v) for v in os.environ["GPX_MG_REHEARSE"].split(","))
+        nb_env = os.environ.get("GPX_POTRF_NB")
+        out = multi_gpu.rehearse_rank(N, d, r_, w_, X.astype(np.float64), y.astype(np.float64), params, s, dtype_id=dtid,
+                                      nb=int(nb_env) if nb_env else None,
+                                      chunks=int(os.environ.get("GPX_MG_BCAST_CHUNKS", "4")),
+                                      sag=1 if os.environ.get("GPX_MG_BCAST") == "sag" else 0, fits=max(2, args.steps),
+                                      link_GBps=float(os.environ.get("GPX_MG_REHEARSE_GBPS", "100")))
+        out.update({"metric": "REHEARSAL of one rank's share of a %d-GPU GP fit (measured compute, modelled transfer)" % w_,
+                    "value": round(out["rank_step_s"], 4), "unit": "s", "n_gpus": 1, "higher_is_better": False})
+        print(json.dumps(out))
+        return
     if world > 1 or os.environ.get("GPX_BENCH_FORCE_DIST"):
         from gaussian_processes_amd import multi_gpu
         result = multi_gpu.bench_distributed(

@@ -144,6 +144,13 @@ _SIGNATURES = {
     "gpx_mg_get_alpha": (c_int, [c_void_p, c_double_p]),
     "gpx_mg_scalars": (c_int, [c_void_p, c_double_p, c_double_p, c_int_p]),
     "gpx_mg_timing": (c_int, [c_void_p, c_double_p]),
+    "gpx_mg_timing_ex": (c_int, [c_void_p, c_double_p, c_int]),
+    "gpx_mg_chain_by_panel": (c_int, [c_void_p, c_double_p, c_int64]),
+    "gpx_mg_set_chunks": (c_int, [c_void_p, c_int]),
+    "gpx_mg_set_owner_first": (c_int, [c_void_p, c_int]),
+    "gpx_mg_device_ptrs": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int64)]),
+    "gpx_mg_create_rehearsal": (c_int, [POINTER(c_void_p), c_int, c_int, c_int64, c_int, c_int64, c_int, c_int, c_void_p, c_int64,
+                                        c_void_p, c_double, c_double]),
     "gpx_gaussian_c": (c_int, [c_int, c_double_p, c_double_p, c_int64, c_double_p, c_int64,
                                c_double, c_double]),
     "gpx_gaussian_c_jacobian": (c_int, [c_double_p, c_double_p, c_int64, c_double_p, c_int64,

@@ -175,6 +175,7 @@ __global__ void info_key_kernel(const int *__restrict__ info, int *__restrict__ 
 
 using namespace gpx;
 
+constexpr int GPX_MG_TIMING_N = 13;
 typedef int (*gpx_mg_bcast_fn)(void *user, void *dev_ptr, size_t bytes, int root, void *stream);
 typedef int (*gpx_mg_allreduce_fn)(void *user, void *dev_ptr, size_t count, int dtype, int op, void *stream);
 
@@ -191,6 +192,9 @@ struct gpx_mg {
     void *cb_user = nullptr;
     int bcast_chunks = 4;
     int bcast_sag = 0;                            // panel broadcast as scatter + all-gather (GPX_MG_BCAST=sag / gpx_mg_set_bcast)
+    int owner_first = 0;                          // the owner of the next panel factors it BEFORE it starts its own trailing update
+                                                  // (gpx_mg_set_owner_first / GPX_MG_OWNER_FIRST; see mg_factor)
+    hipEvent_t last_panel_ev = nullptr;           // behind the last panel this rank factored (stream Q)
     void *sag_tmp = nullptr; size_t sag_tmp_bytes = 0;   // callback back-end only: where a rank drops pieces that are not its own
     int debug_info = 0;                           // gpx_debug_mg_inject_info: written into the device info word after the factorisation
     // device state
@@ -203,12 +207,23 @@ struct gpx_mg {
     size_t ev_next = 0;
     std::vector<hipEvent_t> tev;                  // timing events (pairs)
     std::vector<int> tcls;                        // class of each timing pair
+    std::vector<int64_t> tpan;                    // the panel it belongs to (-1: none)
+    std::vector<double> own_chain_ms;             // per owned panel j of the LAST fit: factor + pack + the last chunk's share of its column update
     size_t tev_next = 0;
     bool have_data = false, fitted = false;
     double logdet = 0, yta = 0;
     int info_host = 0;
-    double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double ms[GPX_MG_TIMING_N] = {0};            // 0 .. 7: stages and chain (gpx_mg_timing); 8 .. 10: exposed waits (gpx_mg_timing_ex)
     bool timing = true;
+    // REHEARSAL of one rank's share of a `world`-rank run in ONE process (gpx_mg_create_rehearsal): no communicator; a
+    // panel this rank does not own is copied out of a resident factor of the same matrix (reh_L: n + 1 rows, the rider row
+    // included), and every broadcast is followed by a delay that models the transfer at reh_GBps per xGMI link
+    bool rehearse = false;
+    const void *reh_L = nullptr; int64_t reh_ld = 0;
+    const void *reh_alpha = nullptr;
+    double reh_GBps = 100.0, reh_lat_us = 20.0;
+    double reh_model_ms = 0;                      // modelled transfer time enqueued by the last fit (all panel broadcasts)
+    double reh_chain_ms = 0;                      // modelled remote-owner chain time enqueued by the last fit
 
     int64_t owner(int64_t j) const { return j % world; }
     int64_t local_col(int64_t j) const { return (j / world) * nb; }
@@ -224,7 +239,8 @@ struct gpx_mg {
 
 namespace gpx {
 
-enum { T_BUILD = 0, T_FACTOR = 1, T_SOLVE = 2, T_REDUCE = 3, T_PANEL = 4, T_PACK = 5, T_BCAST = 6, T_UPDATE = 7 };
+enum { T_BUILD = 0, T_FACTOR = 1, T_SOLVE = 2, T_REDUCE = 3, T_PANEL = 4, T_PACK = 5, T_BCAST = 6, T_UPDATE = 7,
+       T_WAIT = 8 };   // T_WAIT: the update stream sat idle in front of a panel (chunk) that had not arrived: EXPOSED chain time
 
 static int mg_event(gpx_mg *g, hipEvent_t *e)
 {
@@ -249,16 +265,16 @@ static int mg_order(gpx_mg *g, hipStream_t from, hipStream_t to)
 
 struct MgTimer {
     gpx_mg *g; hipStream_t st; size_t idx; bool on;
-    MgTimer(gpx_mg *g_, int cls, hipStream_t s) : g(g_), st(s), idx(0), on(g_->timing)
+    MgTimer(gpx_mg *g_, int cls, hipStream_t s, int64_t panel = -1) : g(g_), st(s), idx(0), on(g_->timing)
     {
         if (!on) return;
         if (g->tev_next + 2 > g->tev.size()) {
             hipEvent_t a, b;
             if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { (void)hipGetLastError(); on = false; return; }
-            g->tev.push_back(a); g->tev.push_back(b); g->tcls.push_back(cls);
+            g->tev.push_back(a); g->tev.push_back(b); g->tcls.push_back(cls); g->tpan.push_back(panel);
         }
         idx = g->tev_next; g->tev_next += 2;
-        g->tcls[idx / 2] = cls;
+        g->tcls[idx / 2] = cls; g->tpan[idx / 2] = panel;
         (void)hipEventRecord(g->tev[idx], st);
     }
     ~MgTimer() { if (on) (void)hipEventRecord(g->tev[idx + 1], st); }
@@ -266,10 +282,41 @@ struct MgTimer {
 
 static ncclDataType_t nccl_type(int dtype) { return dtype == GPX_F64 ? ncclFloat64 : ncclFloat32; }
 
+// rehearsal: hold the stream for `ticks` of the 100 MHz real-time clock (one lane; a modelled transfer)
+__global__ void mg_delay_kernel(unsigned long long ticks)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+static int mg_delay(gpx_mg *g, double us, hipStream_t st)
+{
+    if (us <= 0) return GPX_OK;
+    g->reh_model_ms += us * 1e-3;
+    hipLaunchKernelGGL(mg_delay_kernel, dim3(1), dim3(1), 0, st, (unsigned long long)(us * 100.0));
+    GPX_LAUNCH_CHECK();
+    return GPX_OK;
+}
+// the modelled duration of one panel-chunk broadcast of `bytes` (DESIGN section 5's assumptions, stated in the JSON the
+// rehearsal writes): a ring moves the payload through one link per hop, pipelined -- bytes / rate; scatter + all-gather puts
+// 1 / P of it on each of the root's links, twice -- 2 bytes / (P rate); one latency per collective call
+static double mg_model_us(const gpx_mg *g, size_t bytes, bool sag)
+{
+    const double per_us = g->reh_GBps * 1e3;                      // bytes per microsecond
+    return sag ? 2.0 * (double)bytes / ((double)g->world * per_us) + 2.0 * g->reh_lat_us : (double)bytes / per_us + g->reh_lat_us;
+}
+
 // broadcast `count` elements of the handle's dtype at dev_ptr from `root`, on stream st
 static int mg_bcast(gpx_mg *g, void *dev_ptr, size_t count, int root, hipStream_t st)
 {
     if (count == 0) return GPX_OK;
+    if (g->rehearse) {
+        // (only alpha blocks travel this way: a block this rank does not own comes out of the resident solution)
+        if (root != g->rank && g->reh_alpha) {
+            const size_t off = (size_t)((const char *)dev_ptr - (const char *)g->alpha);
+            GPX_HIP(hipMemcpyAsync(dev_ptr, (const char *)g->reh_alpha + off, count * g->es, hipMemcpyDeviceToDevice, st));
+        }
+        return mg_delay(g, g->reh_lat_us, st);
+    }
     if (g->cb_bcast) {
         if (g->world == 1) return GPX_OK;
         const int rc = g->cb_bcast(g->cb_user, dev_ptr, count * g->es, root, (void *)st);
@@ -285,6 +332,7 @@ static int mg_bcast(gpx_mg *g, void *dev_ptr, size_t count, int root, hipStream_
 static int mg_allreduce(gpx_mg *g, void *dev_ptr, size_t count, int dtype, int op, hipStream_t st)
 {
     if (count == 0) return GPX_OK;
+    if (g->rehearse) return mg_delay(g, g->reh_lat_us, st);       // (local values only: the rehearsal's scalars are this rank's share)
     if (g->cb_allreduce) {
         if (g->world == 1) return GPX_OK;
         const int rc = g->cb_allreduce(g->cb_user, dev_ptr, count, dtype, op, (void *)st);
@@ -327,10 +375,22 @@ static void mg_chunk_plan(int64_t rows, int64_t nb, int nch_req, std::vector<int
     }
 }
 
-static int mg_bcast_panel(gpx_mg *g, void *dev_ptr, size_t count, int root, hipStream_t st)
+static int mg_pack_from(gpx_mg *g, const void *src, int64_t ld, int64_t rows, int64_t kb, void *buf, hipStream_t st);
+// (j, row0, rows: which rows of which panel dev_ptr holds -- the rehearsal needs to know what it stands in for)
+static int mg_bcast_panel(gpx_mg *g, void *dev_ptr, size_t count, int root, hipStream_t st, int64_t j = -1, int64_t row0 = 0, int64_t rows = 0)
 {
     const int P = g->world, me = g->rank;
     const size_t piece = mg_piece(count, P);                      // 32-element (128- / 256-byte) aligned pieces; the last one takes the rest
+    if (g->rehearse) {
+        const bool sag_m = g->bcast_sag && mg_piece_sag_ok(count, P);
+        route_hit(sag_m ? RT_MG_BCAST_SAG : RT_MG_BCAST_ONE);
+        if (root != me) {
+            if (j < 0 || !g->reh_L) { set_error("rehearsal: a panel broadcast without its context"); return GPX_ERR_ARG; }
+            const int64_t k0 = g->k0(j), kb = g->kb(j);
+            GPX_TRY(mg_pack_from(g, (const char *)g->reh_L + ((size_t)(k0 + row0) * g->reh_ld + k0) * g->es, g->reh_ld, rows, kb, dev_ptr, st));
+        }
+        return mg_delay(g, mg_model_us(g, count * g->es, sag_m), st);
+    }
     const bool sag = g->bcast_sag && mg_piece_sag_ok(count, P) && (g->cb_bcast || g->comm);
     if (!sag) { route_hit(RT_MG_BCAST_ONE); return mg_bcast(g, dev_ptr, count, root, st); }
     route_hit(RT_MG_BCAST_SAG);
@@ -377,17 +437,22 @@ static int mg_bcast_panel(gpx_mg *g, void *dev_ptr, size_t count, int root, hipS
     return GPX_OK;
 }
 
-static int mg_pack(gpx_mg *g, int64_t r0, int64_t cl, int64_t rows, int64_t kb, void *buf, hipStream_t st)
+static int mg_pack_from(gpx_mg *g, const void *src, int64_t ld, int64_t rows, int64_t kb, void *buf, hipStream_t st)
 {
+    if (rows <= 0) return GPX_OK;
     const unsigned blocks = (unsigned)std::min<int64_t>(cdiv(rows * cdiv(kb, 2), 256), 4096);
     if (g->dtype == GPX_F64)
-        hipLaunchKernelGGL((pack_panel_kernel<double>), dim3(blocks), dim3(256), 0, st, (const double *)g->Aat(r0, cl), g->ld,
+        hipLaunchKernelGGL((pack_panel_kernel<double>), dim3(blocks), dim3(256), 0, st, (const double *)src, ld,
                            (double *)buf, g->nb, rows, (int)kb);
     else
-        hipLaunchKernelGGL((pack_panel_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float *)g->Aat(r0, cl), g->ld,
+        hipLaunchKernelGGL((pack_panel_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float *)src, ld,
                            (float *)buf, g->nb, rows, (int)kb);
     GPX_LAUNCH_CHECK();
     return GPX_OK;
+}
+static int mg_pack(gpx_mg *g, int64_t r0, int64_t cl, int64_t rows, int64_t kb, void *buf, hipStream_t st)
+{
+    return mg_pack_from(g, g->Aat(r0, cl), g->ld, rows, kb, buf, st);
 }
 
 // Factor (owner, stream Q), pack (owner, Q) and broadcast (everybody, stream B) block column j into buf.  The
@@ -403,17 +468,32 @@ static int mg_factor_and_bcast(gpx_mg *g, int64_t j, void *buf, hipEvent_t buf_f
     hipStream_t Q = g->Q, B = g->B;
     if (g->owner(j) == g->rank) {
         const int64_t cl = g->local_col(j);
-        { MgTimer t(g, T_PANEL, Q); GPX_TRY(potrf_panel(g->dtype, g->A, g->ld, g->nr, r0, cl, kb, g->info, Q)); }
+        { MgTimer t(g, T_PANEL, Q, j); GPX_TRY(potrf_panel(g->dtype, g->A, g->ld, g->nr, r0, cl, kb, g->info, Q)); }
+        GPX_TRY(mg_event(g, &g->last_panel_ev));
+        GPX_HIP(hipEventRecord(g->last_panel_ev, Q));
         if (buf_free) GPX_HIP(hipStreamWaitEvent(Q, buf_free, 0));
-        { MgTimer t(g, T_PACK, Q); GPX_TRY(mg_pack(g, r0, cl, rows, kb, buf, Q)); }
+        { MgTimer t(g, T_PACK, Q, j); GPX_TRY(mg_pack(g, r0, cl, rows, kb, buf, Q)); }
         GPX_TRY(mg_order(g, Q, B));
         // the inverse of this diagonal block for the backward solve: ~11 small launches, on a low-priority stream of
         // their own ordered after the pack (round 4; they used to sit on Q, where with world <= 2 the owner's next panel
         // queued right behind them; their buffers come from mg_alloc, nothing is allocated inside this loop)
         GPX_TRY(mg_order(g, Q, g->O));
         GPX_TRY(trsv_ops_build(g->dtype, g->Aat(r0, cl), kb, g->ld, &g->ops[(size_t)(j / g->world)], g->O));
-    } else if (buf_free) {
-        GPX_HIP(hipStreamWaitEvent(B, buf_free, 0));
+    } else {
+        if (buf_free) GPX_HIP(hipStreamWaitEvent(B, buf_free, 0));
+        // rehearsal: the remote owner's chain behind the arrival of the panel before -- taken to be what THIS rank measured
+        // for the nearest panel it owns in the fit before (symmetric ranks; nothing in the first fit)
+        if (g->rehearse && !g->own_chain_ms.empty()) {
+            double best = 0; int64_t dist = -1;
+            for (int64_t o : g->my_blocks) {
+                const int64_t dd = o > j ? o - j : j - o;
+                if ((size_t)o < g->own_chain_ms.size() && g->own_chain_ms[(size_t)o] > 0 && (dist < 0 || dd < dist)) { dist = dd; best = g->own_chain_ms[(size_t)o]; }
+            }
+            const double before = g->reh_model_ms;
+            GPX_TRY(mg_delay(g, best * 1e3, B));
+            g->reh_chain_ms += g->reh_model_ms - before;          // (kept apart from the transfers)
+            g->reh_model_ms = before;
+        }
     }
     // row chunks (mg_chunk_plan)
     std::vector<int64_t> ends;
@@ -421,7 +501,8 @@ static int mg_factor_and_bcast(gpx_mg *g, int64_t j, void *buf, hipEvent_t buf_f
     MgTimer t(g, T_BCAST, B);
     int64_t done = 0;
     for (const int64_t end : ends) {
-        GPX_TRY(mg_bcast_panel(g, (char *)buf + (size_t)done * g->nb * g->es, (size_t)(end - done) * g->nb, (int)g->owner(j), B));
+        GPX_TRY(mg_bcast_panel(g, (char *)buf + (size_t)done * g->nb * g->es, (size_t)(end - done) * g->nb, (int)g->owner(j), B, j, done,
+                               end - done));
         done = end;
         if (chunk_ev) {
             hipEvent_t e;
@@ -463,7 +544,7 @@ static int mg_factor(gpx_mg *g)
     for (int64_t k = 0; k < g->nblk; ++k) {
         const int64_t k0 = g->k0(k), kb = g->kb(k), r = k0 + kb;
         if (r >= g->n) {                                          // last panel: S must see it before the solve
-            GPX_HIP(hipStreamWaitEvent(S, cev.back(), 0));
+            { MgTimer tw(g, T_WAIT, S); GPX_HIP(hipStreamWaitEvent(S, cev.back(), 0)); }
             break;
         }
         void *Pk = g->pbuf[k % 2];
@@ -473,23 +554,31 @@ static int mg_factor(gpx_mg *g)
         if (own_next) {
             // block column k+1 first, chunk by chunk as the panel lands (rows of chunk c: [lo, hi) global)
             const int64_t cl = g->local_col(nxt);
-            MgTimer t(g, T_UPDATE, S);
             int64_t lo = r;
             for (size_t c = 0; c < cev.size(); ++c) {
                 const int64_t hi = k0 + cend[c];
-                GPX_HIP(hipStreamWaitEvent(S, cev[c], 0));
-                if (hi > lo)
+                { MgTimer tw(g, T_WAIT, S); GPX_HIP(hipStreamWaitEvent(S, cev[c], 0)); }
+                if (hi > lo) {
+                    MgTimer t(g, T_UPDATE, S, c + 1 == cev.size() ? nxt : -1);   // (the last chunk's update is what the panel waits for)
                     GPX_TRY(syrk_bc(g->dtype, hi, lo, g->A, g->ld, cl, cl + g->nb, Pk, g->nb, k0, kb, g->nb, g->world,
                                     g->rank, S));       // (hi reaches nr with the last chunk: the rider row is its last row)
+                }
                 lo = std::max(lo, hi);
             }
             GPX_TRY(mg_order(g, S, Q));
             jl_first = g->first_local_block_after(nxt);
         } else {
-            GPX_HIP(hipStreamWaitEvent(S, cev.back(), 0));        // the whole panel k is here
+            { MgTimer tw(g, T_WAIT, S); GPX_HIP(hipStreamWaitEvent(S, cev.back(), 0)); }   // the whole panel k is here
         }
         std::vector<hipEvent_t> nev; std::vector<int64_t> nend;
         GPX_TRY(mg_factor_and_bcast(g, nxt, g->pbuf[nxt % 2], readers_done[nxt % 2], &nev, &nend));   // (update k-1 has to let go of that buffer)
+        // OWNER FIRST (round 5): the panel is the serial chain of the whole run -- every rank waits for it -- while a
+        // rank's own trailing update has slack whenever the chain is the bound (it owns one panel in `world`).  Beside that
+        // update a 512-wide panel takes 1.2 - 1.5 ms, alone 0.55: with this switch the owner holds its update back until
+        // its panel has left, and only then does its share of the update.  Measured in the rehearsal (N = 65536, one rank's
+        // share, 100 GB/s links assumed; profiles/r05_mg_rehearsal_owner_first.jsonl): the owner's chain per panel 1.50 ->
+        // 0.74 ms; P = 8: 0.285 -> 0.235 s (nb = 512), 0.290 -> 0.226 (nb = 1024); P = 4: 0.434 -> 0.407; P = 2: 0.762 -> 0.738
+        if (own_next && g->owner_first && g->last_panel_ev) GPX_HIP(hipStreamWaitEvent(S, g->last_panel_ev, 0));
         if (jl_first >= 0) {
             MgTimer t(g, T_UPDATE, S);
             GPX_TRY(syrk_bc(g->dtype, g->nr, r, g->A, g->ld, jl_first * g->nb, g->ncols_local, Pk, g->nb, k0, kb, g->nb,
@@ -637,6 +726,7 @@ static int mg_new(gpx_mg **out, int dtype, int kernel, int64_t n, int d, int64_t
     g->bcast_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(16, tune().mg_bcast_chunks));
     g->timing = !tune().mg_no_timing;
     if (tune().mg_bcast_set) g->bcast_sag = tune().mg_bcast_sag;
+    g->owner_first = tune().mg_owner_first_set ? (tune().mg_owner_first != 0) : (world >= 2);
     *out = g;
     return GPX_OK;
 }
@@ -749,6 +839,36 @@ int gpx_mg_set_bcast(gpx_mg_t *g, int sag)
     return GPX_OK;
 }
 
+int gpx_mg_set_owner_first(gpx_mg_t *g, int on)
+{
+    MG_ENTER(g);
+    g->owner_first = on ? 1 : 0;                                  // (local scheduling only: ranks need not agree, but a run should)
+    return GPX_OK;
+}
+
+int gpx_mg_set_chunks(gpx_mg_t *g, int chunks)
+{
+    MG_ENTER(g);
+    GPX_ARG(chunks >= 1 && chunks <= 16, "chunks must be 1 .. 16");
+    g->bcast_chunks = chunks;                                     // collective: every rank sets the same number before the next fit
+    return GPX_OK;
+}
+
+int gpx_mg_create_rehearsal(gpx_mg_t **out, int dtype, int kernel, int64_t n, int d, int64_t nb, int world, int rank,
+                            const void *L_dev, int64_t ldl, const void *alpha_dev, double link_GBps, double latency_us)
+{
+    GPX_ARG(L_dev && ldl >= n && alpha_dev, "the resident factor (n + 1 rows) and solution are needed");
+    GPX_ARG(link_GBps > 0 && latency_us >= 0, "bad transfer model");
+    GPX_TRY(mg_new(out, dtype, kernel, n, d, nb, world, rank));
+    gpx_mg *g = *out;
+    g->rehearse = true;
+    g->reh_L = L_dev; g->reh_ld = ldl; g->reh_alpha = alpha_dev;
+    g->reh_GBps = link_GBps; g->reh_lat_us = latency_us;
+    const int rc = mg_alloc(g);
+    if (rc != GPX_OK) { gpx_mg_destroy(g); *out = nullptr; }
+    return rc;
+}
+
 int gpx_debug_mg_inject_info(gpx_mg_t *g, int value)
 {
     GPX_ARG(g != nullptr, "mg is NULL");
@@ -834,11 +954,22 @@ int gpx_mg_fit(gpx_mg_t *g, const double *params, double s, double *log_lh, int 
     g->fitted = true;
     // stage and chain times of this rank (HIP events, all streams drained by mg_reduce)
     for (double &v : g->ms) v = 0;
+    std::vector<double> chain_now((size_t)g->nblk, 0.0);
     for (size_t i = 0; i + 1 < g->tev_next; i += 2) {
         float t = 0.f;
-        if (hipEventElapsedTime(&t, g->tev[i], g->tev[i + 1]) == hipSuccess) g->ms[g->tcls[i / 2]] += t;
-        else (void)hipGetLastError();
+        if (hipEventElapsedTime(&t, g->tev[i], g->tev[i + 1]) != hipSuccess) { (void)hipGetLastError(); continue; }
+        const int cls = g->tcls[i / 2];
+        g->ms[cls] += t;
+        if (g->tpan[i / 2] >= 0 && (cls == T_PANEL || cls == T_PACK || cls == T_UPDATE)) chain_now[(size_t)g->tpan[i / 2]] += t;
+        if (cls == T_WAIT) {                                      // [9] the longest single wait, [10] waits of more than 20 us
+            g->ms[9] = std::max(g->ms[9], (double)t);
+            if (t > 0.02f) g->ms[10] += 1.0;
+        }
     }
+    g->own_chain_ms.swap(chain_now);
+    g->ms[11] = g->reh_model_ms;                                  // (rehearsal: the modelled transfer time this fit enqueued)
+    g->ms[12] = g->reh_chain_ms;                                  // (rehearsal: the remote owners' chains it stood in for)
+    g->reh_model_ms = 0; g->reh_chain_ms = 0;
     if (info) *info = g->info_host;
     if (log_lh) {
         // gp/gp.py:362-365 and gp_c.pyx:22-29
@@ -919,6 +1050,30 @@ int gpx_mg_timing(gpx_mg_t *g, double *ms8)
     MG_ENTER(g);
     GPX_ARG(g->fitted && ms8, "bad arguments");
     for (int i = 0; i < 8; ++i) ms8[i] = g->ms[i];
+    return GPX_OK;
+}
+
+int gpx_mg_device_ptrs(gpx_mg_t *g, void **A, int64_t *ld)
+{
+    MG_ENTER(g);
+    if (A) *A = g->A;
+    if (ld) *ld = g->ld;
+    return GPX_OK;
+}
+
+int gpx_mg_chain_by_panel(gpx_mg_t *g, double *ms, int64_t count)
+{
+    MG_ENTER(g);
+    GPX_ARG(g->fitted && ms && count >= 0, "bad arguments");
+    for (int64_t j = 0; j < count; ++j) ms[j] = (size_t)j < g->own_chain_ms.size() ? g->own_chain_ms[(size_t)j] : 0.0;
+    return GPX_OK;
+}
+
+int gpx_mg_timing_ex(gpx_mg_t *g, double *ms, int count)
+{
+    MG_ENTER(g);
+    GPX_ARG(g->fitted && ms && count >= 0, "bad arguments");
+    for (int i = 0; i < count; ++i) ms[i] = i < GPX_MG_TIMING_N ? g->ms[i] : 0.0;
     return GPX_OK;
 }
 

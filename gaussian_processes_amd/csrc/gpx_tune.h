@@ -42,6 +42,7 @@ namespace gpx {
     XF(force_collectives, "GPX_FORCE_COLLECTIVES")                                                                     \
     X(mg_bcast_chunks, "GPX_MG_BCAST_CHUNKS", 4)                                                                       \
     XF(mg_no_timing, "GPX_MG_NO_TIMING")                                                                               \
+    XS(mg_owner_first, "GPX_MG_OWNER_FIRST", 0)                                                                        \
     /* ---- resident panel kernel (gpx_panel.hip) ---- */                                                              \
     XF(trace, "GPX_TRACE")                                                                                             \
     X(potrf_res, "GPX_POTRF_RES", 256)                                                                                 \

@@ -129,14 +129,33 @@ class NativeDistributedGP(object):
 
     TIMING_KEYS = ("kernel_build", "factor", "solve", "reduce", "chain_panel", "chain_pack", "chain_bcast",
                    "chain_update")
+    # gpx_mg_timing_ex: how long the update stream sat idle in front of a panel (chunk) that had not arrived -- EXPOSED
+    # chain time, the longest single wait, the number of waits above 20 us; rehearsal: the modelled transfer time
+    TIMING_KEYS_EX = TIMING_KEYS + ("exposed_wait", "exposed_wait_max", "exposed_waits_over_20us", "modelled_transfer",
+                                    "modelled_remote_chain")
 
     def __init__(self, n, d, dtype_id=_lib.F64, kernel_id=_lib.KERNEL_GAUSSIAN, nb=None, dist=None,
-                 backend="rccl", device=0, callbacks=None):
+                 backend="rccl", device=0, callbacks=None, rehearsal=None):
         """`callbacks` (backend="callbacks" only): an object with ctypes function pointers `.bcast` / `.allreduce`
         (gpx_mg_bcast_fn / gpx_mg_allreduce_fn of include/gpx.h), an `.error` slot and `.rank` / `.world` -- any
         transport for the host-callback data plane; default: `GlooCallbacks(dist)`."""
         self.lib = _lib.load()
         self.n, self.d = int(n), int(d)
+        if rehearsal is not None:
+            # ONE rank of a `world`-rank run in this process (gpx_mg_create_rehearsal): rehearsal = dict(rank, world, L_ptr,
+            # ldl, alpha_ptr, link_GBps, latency_us) -- the resident factor / solution stand in for what other ranks send
+            self.rank, self.world = int(rehearsal["rank"]), int(rehearsal["world"])
+            self.nb = int(nb or default_nb(n, self.world))
+            _lib.check(self.lib.gpx_set_device(int(device)))
+            self.h = ctypes.c_void_p()
+            self._cb = None
+            _lib.check(self.lib.gpx_mg_create_rehearsal(
+                ctypes.byref(self.h), dtype_id, kernel_id, self.n, self.d, self.nb, self.world, self.rank,
+                ctypes.c_void_p(rehearsal["L_ptr"]), int(rehearsal["ldl"]), ctypes.c_void_p(rehearsal["alpha_ptr"]),
+                float(rehearsal.get("link_GBps", 100.0)), float(rehearsal.get("latency_us", 20.0))))
+            self.log_lh = None
+            self.info = None
+            return
         if callbacks is not None:
             self.rank, self.world = int(callbacks.rank), int(callbacks.world)
         else:
@@ -237,10 +256,30 @@ class NativeDistributedGP(object):
         """Panel broadcast algorithm for the following fits (collective: the same on every rank)."""
         self._check(self.lib.gpx_mg_set_bcast(self.h, 1 if sag else 0))
 
-    def timing(self):
+    def set_chunks(self, chunks):
+        """Row chunks per panel broadcast for the following fits (collective: the same on every rank)."""
+        self._check(self.lib.gpx_mg_set_chunks(self.h, int(chunks)))
+
+    def set_owner_first(self, on):
+        """The owner of the next panel factors it before it starts its own trailing update (default: world >= 4)."""
+        self._check(self.lib.gpx_mg_set_owner_first(self.h, 1 if on else 0))
+
+    def timing(self, extended=False):
+        if extended:
+            ms = np.zeros(len(self.TIMING_KEYS_EX))
+            self._check(self.lib.gpx_mg_timing_ex(self.h, _lib.dptr(ms), ms.size))
+            return dict(zip(self.TIMING_KEYS_EX, [float(v) for v in ms]))
         ms = np.zeros(8)
         self._check(self.lib.gpx_mg_timing(self.h, _lib.dptr(ms)))
         return dict(zip(self.TIMING_KEYS, [float(v) for v in ms]))
+
+    def chain_by_panel(self):
+        """ms per panel of the last fit that this rank spent on the owner's chain (factor + pack + the last chunk of the
+        column update); 0 for panels it does not own."""
+        nblk = -(-self.n // self.nb)
+        ms = np.zeros(nblk)
+        self._check(self.lib.gpx_mg_chain_by_panel(self.h, _lib.dptr(ms), nblk))
+        return ms
 
     def close(self):
         if self.h:
@@ -252,6 +291,143 @@ class NativeDistributedGP(object):
             self.close()
         except Exception:
             pass
+
+
+# ---------------------------------------------------------- schedule tuning --
+def schedule_candidates(n, world, nbs=(256, 512, 1024), chunks=(2, 4, 8)):
+    """The free parameters of the multi-GPU schedule, in ONE order on every rank: block-column width, row chunks per panel
+    broadcast, broadcast form (scatter + all-gather needs more than two ranks).  Grouped by nb (a new width is a new local
+    layout, i.e. a new handle)."""
+    out = []
+    for nb in nbs:
+        if nb > n or -(-n // nb) < world:                        # (every rank should own a panel)
+            continue
+        for sag in ((0, 1) if world > 2 else (0,)):
+            for ch in chunks:
+                out.append({"nb": int(nb), "chunks": int(ch), "sag": int(sag)})
+    return out
+
+
+def tune_schedule(candidates, measure, dist=None, budget_s=60.0, clock=time.perf_counter):
+    """Measure the candidates IN ORDER while the budget lasts and pick the fastest -- together.  `measure(c)` runs one
+    untimed fit with candidate c on this rank and returns its seconds.  A candidate's time is the SLOWEST rank's (MAX
+    all-reduce over `dist`, a torch.distributed CPU group), and so is the clock the budget is checked against, so every
+    rank measures the same candidates, stops at the same one and chooses the same triple.  At least one candidate is
+    always measured.  Returns (best, table): table rows are the candidates with `fit_s` (agreed) added."""
+    t_start = clock()
+    table = []
+    for c in candidates:
+        mine = float(measure(c))
+        spent = clock() - t_start
+        if dist is not None and dist.get_world_size() > 1:
+            import torch
+            v = torch.tensor([mine, spent], dtype=torch.float64)
+            dist.all_reduce(v, op=dist.ReduceOp.MAX)
+            mine, spent = float(v[0].item()), float(v[1].item())
+        row = dict(c)
+        row["fit_s"] = round(mine, 5)
+        table.append(row)
+        if spent > budget_s:
+            break
+    best = min(table, key=lambda r: (r["fit_s"], r["nb"], r["chunks"], r["sag"]))
+    return {k: best[k] for k in ("nb", "chunks", "sag")}, table
+
+
+# ------------------------------------------------------------------ rehearsal --
+def rehearse_rank(N, d, rank, world, X, y, params, s, dtype_id=_lib.F64, nb=None, chunks=None, sag=None, fits=3,
+                  link_GBps=100.0, latency_us=20.0, device=0, owner_first=None):
+    """ONE rank's share of a `world`-rank fit at full size on ONE GPU: its own panels, packs, column
+    updates and trailing updates run exactly as they would (same kernels, same streams, same look-ahead), in situ beside
+    each other; the panels it does not own come out of a resident single-GPU factor of the same matrix; every broadcast is
+    a delay that MODELS the transfer (bytes / link rate for a ring, 2 bytes / (P link rate) for scatter + all-gather,
+    + latency per collective), and a remote panel additionally waits for what THIS rank measured as its own chain for the
+    nearest panel it owns in the fit before (symmetric ranks).  Measured compute, modelled transfer -- labelled as such in
+    the returned dict.  The owned block columns of the result are checked against the resident factor."""
+    from .gp import GP
+    from .kernels import GaussianKernel
+    lib = _lib.load()
+    dtype = "float64" if dtype_id == _lib.F64 else "float32"
+    g = GP(GaussianKernel(float(params[0]), float(params[1])), X, y, s=float(s), dtype=dtype)
+    llh_ref = float(g.log_lh)
+    st = g._fit_pd()
+    A, lda, al = ctypes.c_void_p(), ctypes.c_int64(), ctypes.c_void_p()
+    _lib.check(lib.gpx_gp_device_ptrs(st.handle, ctypes.byref(A), ctypes.byref(lda), None, None, ctypes.byref(al), None))
+    # the rider row: row n of the resident matrix <- L^-1 y (what rides through the distributed factorisation as one more
+    # row of every panel; the single-GPU fit's own work row does not survive its backward solve)
+    from .device import DeviceBuffer
+    es_ = 8 if dtype_id == _lib.F64 else 4
+    tmp = DeviceBuffer.from_host(np.ascontiguousarray(y, dtype=np.float64 if es_ == 8 else np.float32))
+    _lib.check(lib.gpx_d_trsv_lower(dtype_id, A, N, lda.value, tmp.ptr, ctypes.c_void_p(A.value + N * lda.value * es_), 0, None))
+    _lib.check(lib.gpx_stream_sync(None))
+    tmp.free()
+    reh = {"rank": rank, "world": world, "L_ptr": A.value, "ldl": lda.value, "alpha_ptr": al.value,
+           "link_GBps": link_GBps, "latency_us": latency_us}
+    mg = NativeDistributedGP(N, d, dtype_id=dtype_id, nb=nb, device=device, rehearsal=reh)
+    try:
+        if chunks is not None:
+            mg.set_chunks(chunks)
+        if sag is not None:
+            mg.set_bcast(sag)
+        if owner_first is not None:
+            mg.set_owner_first(owner_first)
+        mg.set_data(X, y)
+        runs = []
+        p = np.ascontiguousarray(params, dtype=np.float64)
+        for i in range(fits):
+            t0 = time.perf_counter()
+            mg.fit(p, s)
+            wall = time.perf_counter() - t0
+            tm = mg.timing(extended=True)
+            tm["wall_s"] = wall
+            runs.append(tm)
+        chain = mg.chain_by_panel()
+        # the owned block columns against the resident factor (both in HBM: a few sampled rows of each owned panel)
+        es = 8 if dtype_id == _lib.F64 else 4
+        npdt = np.float64 if es == 8 else np.float32
+        Aloc, ld_loc = ctypes.c_void_p(), ctypes.c_int64()
+        _lib.check(lib.gpx_mg_device_ptrs(mg.h, ctypes.byref(Aloc), ctypes.byref(ld_loc)))
+        worst = 0.0
+        nbv = mg.nb
+        owned = [j for j in range(-(-N // nbv)) if j % world == rank]
+        for j in owned[:: max(1, len(owned) // 6)]:
+            kb = min(nbv, N - j * nbv)
+            # (not the rider row: the back substitution keeps its running right-hand side there; alpha covers it)
+            for r in sorted({j * nbv, j * nbv + kb - 1, min(N - 1, j * nbv + kb + 777), N - 1}):
+                w = kb if r >= j * nbv + kb else (r - j * nbv + 1)
+                mine, ref = np.empty(w, dtype=npdt), np.empty(w, dtype=npdt)
+                _lib.check(lib.gpx_memcpy_d2h(mine.ctypes.data_as(ctypes.c_void_p),
+                                              ctypes.c_void_p(Aloc.value + (r * ld_loc.value + (j // world) * nbv) * es), w * es, None))
+                _lib.check(lib.gpx_memcpy_d2h(ref.ctypes.data_as(ctypes.c_void_p),
+                                              ctypes.c_void_p(A.value + (r * lda.value + j * nbv) * es), w * es, None))
+                _lib.check(lib.gpx_stream_sync(None))
+                scale = max(1e-300, float(np.abs(ref).max()))
+                worst = max(worst, float(np.abs(mine.astype(np.float64) - ref.astype(np.float64)).max()) / scale)
+        alpha = mg.alpha
+        alpha_ref = np.array(g.inv_Kxx_y, dtype=np.float64)
+        alpha_err = float(np.abs(alpha - alpha_ref).max() / max(1e-300, np.abs(alpha_ref).max()))
+        last = runs[-1]
+        nblk = -(-N // nbv)
+        steps = nblk
+        own = chain[chain > 0]
+        return {
+            "what": "rehearsal of rank %d of %d on one GPU: measured compute, MODELLED transfer" % (rank, world),
+            "N": N, "d": d, "dtype": dtype, "nb": nbv, "chunks": chunks, "owner_first": owner_first, "panel_bcast": "scatter+allgather" if sag else "one collective (ring)",
+            "model": {"link_GBps_sustained_assumed": link_GBps, "latency_us_per_collective_assumed": latency_us,
+                      "ring_us": "bytes / rate + latency", "scatter_allgather_us": "2 bytes / (P rate) + 2 latency",
+                      "remote_owner_chain": "this rank's own measured chain for its nearest owned panel, from the fit before"},
+            "fits": runs,
+            "rank_step_s": last["wall_s"],
+            "per_step_ms": {"update": last["chain_update"] / steps, "exposed_wait": last["exposed_wait"] / steps,
+                            "modelled_transfer": last["modelled_transfer"] / steps,
+                            "modelled_remote_chain": last["modelled_remote_chain"] / steps,
+                            "own_chain_per_owned_panel_mean": float(own.mean()) if own.size else 0.0,
+                            "own_chain_per_owned_panel_max": float(own.max()) if own.size else 0.0},
+            "owned_panels": int(own.size),
+            "single_gpu_log_lh": llh_ref,
+            "check": {"owned_columns_vs_resident_factor_max_rel_err": worst, "alpha_vs_single_gpu_max_rel_err": alpha_err},
+        }
+    finally:
+        mg.close()
 
 
 # ------------------------------------------------------------------ benchmark --
@@ -346,52 +522,86 @@ def bench_distributed(args, X, y, Xo, params, s, dtype_id, residual_check=None):
     try:
         # communicator set-up and the first fit (the first real collectives) under a watchdog: see Watchdog
         wd_s = float(os.environ.get("GPX_BENCH_WATCHDOG_S", "300"))
-        with Watchdog(wd_s, "communicator set-up (%s, world %d)" % (backend, world), rank):
-            gp = NativeDistributedGP(N, d, dtype_id=dtype_id, dist=dist, backend=backend, device=local_rank)
-        gp.set_data(X, y)
+        holder = {"gp": None}
+
+        def make(nb):
+            """A handle of block-column width nb (a new local layout: allocation, data, communicator) and its first fit --
+            the first real collectives of that communicator -- under the watchdog."""
+            if holder["gp"] is not None:
+                holder["gp"].close()
+                holder["gp"] = None
+            with Watchdog(wd_s, "communicator set-up (%s, world %d, nb %s)" % (backend, world, nb), rank):
+                g_ = NativeDistributedGP(N, d, dtype_id=dtype_id, nb=nb, dist=dist, backend=backend, device=local_rank)
+            g_.set_data(X, y)
+            holder["gp"] = g_
+            with Watchdog(wd_s, "first fit + predict (N=%d, world %d, nb %d)" % (N, world, g_.nb), rank):
+                llh0 = g_.fit(params, s)
+                mean0 = g_.mean(params, Xo)
+                dist.barrier()
+            return llh0, mean0
 
         def step():
+            gp = holder["gp"]
             llh = gp.fit(params, s)                    # synchronous: returns when this rank's streams have drained
             mean = gp.mean(params, Xo)
             return llh, mean
 
-        with Watchdog(wd_s, "first fit + predict (N=%d, world %d)" % (N, world), rank):
-            first = step()
-            dist.barrier()
+        first = make(None)
         for _ in range(max(0, args.warmup - 1)):
             step()
         # what the communicator itself says (ncclCommCount / ncclCommUserRank / ncclCommCuDevice), from every rank:
         # evidence that the data plane really spans `world` GPUs (a silent fallback would show rccl_nranks = 0)
         comm_infos = [None] * world
-        dist.all_gather_object(comm_infos, gp.comm_info())
-        # panel broadcast algorithm: measured, not guessed.  xGMI is point to point (7 links per GPU); whether RCCL's own
-        # broadcast or the scatter + all-gather form moves a panel faster depends on the node.  One untimed fit each
-        # (after the warm-up), the slower rank decides, every rank takes the same mode.
-        bcast_tune = None
-        if world > 2 and not os.environ.get("GPX_MG_BCAST") and not os.environ.get("GPX_BENCH_NO_BCAST_TUNE"):
-            times = {}
-            for mode in (0, 1):
-                gp.set_bcast(mode)
+        dist.all_gather_object(comm_infos, holder["gp"].comm_info())
+        # The schedule's free parameters are MEASURED, not guessed (round 5): block-column width x row chunks per panel
+        # broadcast x broadcast form, one untimed fit each after the warm-up, under a time budget; a candidate's time is the
+        # slowest rank's, every rank stops at the same candidate and takes the same triple (tune_schedule).  xGMI is point to
+        # point (7 links per GPU): whether RCCL's own broadcast or scatter + all-gather moves a panel faster, and whether the
+        # owner's chain or the update bounds a step at a given width, depends on the node.  Variables that pin a parameter
+        # (GPX_POTRF_NB, GPX_MG_BCAST_CHUNKS, GPX_MG_BCAST) take it out of the search.
+        sched_tune = None
+        if world > 1 and not os.environ.get("GPX_BENCH_NO_TUNE"):
+            nb0 = holder["gp"].nb
+            nbs = (nb0,) if os.environ.get("GPX_POTRF_NB") else tuple(sorted({256, 512, 1024, nb0}, key=lambda v: (v != nb0, v)))
+            chunks = (int(os.environ["GPX_MG_BCAST_CHUNKS"]),) if os.environ.get("GPX_MG_BCAST_CHUNKS") else (2, 4, 8)
+            cands = schedule_candidates(N, world, nbs=nbs, chunks=chunks)
+            if os.environ.get("GPX_MG_BCAST") or os.environ.get("GPX_BENCH_NO_BCAST_TUNE"):
+                want = 1 if os.environ.get("GPX_MG_BCAST") == "sag" else 0
+                cands = [c for c in cands if c["sag"] == want]
+
+            def measure(c):
+                if holder["gp"].nb != c["nb"]:
+                    make(c["nb"])
+                gp = holder["gp"]
+                gp.set_chunks(c["chunks"])
+                gp.set_bcast(c["sag"])
                 dist.barrier()
                 t0 = time.perf_counter()
                 gp.fit(params, s)
-                el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-                dist.all_reduce(el, op=dist.ReduceOp.MAX)
-                times[mode] = float(el.item())
-            best = 1 if times[1] < times[0] else 0
-            gp.set_bcast(best)
-            bcast_tune = {"one_collective_s": round(times[0], 4), "scatter_allgather_s": round(times[1], 4),
-                          "chosen": "scatter+allgather" if best else "one collective per chunk"}
+                return time.perf_counter() - t0
+
+            budget = float(os.environ.get("GPX_BENCH_TUNE_BUDGET_S", "90"))
+            if cands:
+                best, table = tune_schedule(cands, measure, dist=dist, budget_s=budget)
+                if holder["gp"].nb != best["nb"]:
+                    make(best["nb"])
+                holder["gp"].set_chunks(best["chunks"])
+                holder["gp"].set_bcast(best["sag"])
+                step()                                  # one untimed step with the chosen triple
+                sched_tune = {"chosen": best, "table": table, "budget_s": budget, "candidates": len(cands),
+                              "measured": len(table), "rule": "one untimed fit each; a candidate's time = the slowest rank's"}
+        gp = holder["gp"]
         dist.barrier()
         _lib.check(lib.gpx_device_sync())
         if rank == 0 and not args.no_prof:
             _lib.check(lib.gpx_prof_enable(1))         # per-launch HIP events on this rank's streams
-        chain = np.zeros(8)
+        keys = gp.TIMING_KEYS_EX[:-2]                 # (the last two are the rehearsal's modelled delays)
+        chain = np.zeros(len(keys))
         t0 = time.perf_counter()
         for _ in range(args.steps):
             llh, mean_host = step()
-            tm = gp.timing()
-            chain += np.array([tm[k] for k in gp.TIMING_KEYS])
+            tm = gp.timing(extended=True)
+            chain += np.array([tm[k] for k in keys])
         _lib.check(lib.gpx_device_sync())
         dist.barrier()
         elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
@@ -400,7 +610,7 @@ def bench_distributed(args, X, y, Xo, params, s, dtype_id, residual_check=None):
         chain /= args.steps
         assert np.isfinite(llh) and np.isfinite(mean_host).all()
         all_chain = [None] * world
-        dist.all_gather_object(all_chain, {k: round(float(v), 3) for k, v in zip(gp.TIMING_KEYS, chain)})
+        dist.all_gather_object(all_chain, {k: round(float(v), 3) for k, v in zip(keys, chain)})
         peak = 78.6 if dtype_id == _lib.F64 else 157.3
         tfl = (N ** 3 / 3.0) / sec / 1e12
         rank0_gemm = None
@@ -432,7 +642,8 @@ def bench_distributed(args, X, y, Xo, params, s, dtype_id, residual_check=None):
             "data_plane_fallback": fallback_note,
             "rccl_nranks": comm_infos[0]["rccl_nranks"],
             "comm_info_per_rank": comm_infos,
-            "panel_bcast_autotune": bcast_tune,
+            "schedule_autotune": sched_tune,
+            "bcast_chunks": (sched_tune["chosen"]["chunks"] if sched_tune else int(os.environ.get("GPX_MG_BCAST_CHUNKS", "4"))),
             "watchdog_s": wd_s,
             "first_fit_log_lh": first[0],
             "panel_bcast": gp.comm_info()["panel_bcast"],
@@ -440,7 +651,8 @@ def bench_distributed(args, X, y, Xo, params, s, dtype_id, residual_check=None):
             "whole_step_frac_of_peak_all_gpus": round(tfl / (peak * world), 4),
             # where each rank's step went (ms per step, HIP events on its own streams): the stages, and inside
             # the factorisation the owner's chain -- panels it factored, packs, broadcasts (including the wait
-            # for the root), updates
+            # for the root), updates -- and exposed_wait: how long the rank's update stream sat IDLE in front of a
+            # panel (chunk) that had not arrived (a hidden chain shows ~0 there whatever chain_* say)
             "stage_and_chain_ms_per_rank": all_chain,
             "roofline": ({"bound": "mfma",
                           "kernel": "gpx::gemm_nt_fast_kernel<T, 128, 1, 128> (trailing SYRK updates) on rank 0",

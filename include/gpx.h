@@ -463,6 +463,32 @@ int gpx_mg_scalars(gpx_mg_t *mg, double *logdet, double *yta, int *info);
  * [3] reductions, and the chain inside [1]: [4] panels it factored [5] packs [6] broadcasts (incl.
  * waiting for the root) [7] trailing / column updates */
 int gpx_mg_timing(gpx_mg_t *mg, double *ms8);
+/* The same with the classes added in round 5 (count <= 13 values): [8] EXPOSED chain time -- how long this rank's update
+ * stream sat idle in front of a panel (chunk) that had not arrived yet, summed over the fit; [9] the longest single such
+ * wait; [10] the number of waits longer than 20 us; [11] rehearsal only: the modelled transfer time the fit enqueued;
+ * [12] rehearsal only: the delays that stood for the remote owners' chains.
+ * A hidden chain shows [8] ~ 0 whatever chain_panel / chain_bcast (kernel durations on the other streams) say. */
+int gpx_mg_timing_ex(gpx_mg_t *mg, double *ms, int count);
+/* ms[j] for j < count: what the owner's chain of panel j cost this rank in the last fit (factor + pack + the last chunk of
+ * its column update), 0 for panels it does not own. */
+int gpx_mg_chain_by_panel(gpx_mg_t *mg, double *ms, int64_t count);
+/* raw device view of this rank's local matrix, (n + 1) x ld, block column j of the rank at column (j / world) nb (tests, the
+ * rehearsal's check; do not free) */
+int gpx_mg_device_ptrs(gpx_mg_t *mg, void **A, int64_t *ld);
+/* on != 0: the owner of the next panel factors it before it starts its own share of the trailing update (the panel is the
+ * serial chain of the run; default: on for world >= 2, GPX_MG_OWNER_FIRST=0 / 1 overrides). */
+int gpx_mg_set_owner_first(gpx_mg_t *mg, int on);
+/* Row chunks per panel broadcast for the following fits (1 .. 16; collective: the same on every rank). */
+int gpx_mg_set_chunks(gpx_mg_t *mg, int chunks);
+/* REHEARSAL: rank `rank` of a `world`-rank run in ONE process on one GPU, without a communicator.  The rank builds, factors,
+ * packs and updates exactly its own block columns; a panel it does not own is copied (device to device) out of L_dev -- a
+ * resident factor of the same matrix, (n + 1) x ldl with the right-hand side's row (gpx_gp_fit with the riding solve) --
+ * behind a delay that stands for its owner's chain (this rank's own measurement for its nearest panel in the fit before);
+ * every broadcast is followed by a delay that MODELS the transfer: bytes / link_GBps for one ring, 2 bytes / (world
+ * link_GBps) for scatter + all-gather, + latency_us per collective.  alpha_dev: the solution (for the back substitution's
+ * remote blocks).  Scalars of a rehearsal fit are this rank's share only.  Measured compute, modelled transfer. */
+int gpx_mg_create_rehearsal(gpx_mg_t **out, int dtype, int kernel, int64_t n, int d, int64_t nb, int world, int rank,
+                            const void *L_dev, int64_t ldl, const void *alpha_dev, double link_GBps, double latency_us);
 
 /* ------------------------------------------ host-level drop-in entry points -- */
 /* gaussian_c.K(out, x1, x2, h, w) -- gaussian_c.pyx:18 ; and the derivative

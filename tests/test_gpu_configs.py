@@ -419,15 +419,15 @@ def test_checkpoint_header_is_validated_and_writes_are_atomic(tmp_path):
 
 
 def test_bench_three_ranks_choose_the_panel_broadcast_by_measurement():
-    """`python bench.py --gpus 3` from a plain invocation, the three ranks sharing GPU 0 over host callbacks: with more
-    than two ranks the run times one untimed fit with each panel-broadcast algorithm after the warm-up, the slower
-    rank decides and every rank takes the same one; the line says what the communicator reports per rank
+    """`python bench.py --gpus 3` from a plain invocation, the three ranks sharing GPU 0 over host callbacks: the run
+    times one untimed fit per candidate of the schedule's free parameters after the warm-up (round 5: width x chunks x
+    broadcast form; the width is pinned here), the slower rank decides and every rank takes the same triple; the line says what the communicator reports per rank
     (`rccl_nranks` = 0 here: no RCCL communicator behind callbacks), which mode won, and still matches the oracle."""
     import json
     import subprocess
     import sys
     env = dict(os.environ)
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "GPX_MG_BCAST", "GPX_BENCH_NO_BCAST_TUNE"):
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "GPX_MG_BCAST", "GPX_BENCH_NO_BCAST_TUNE", "GPX_BENCH_NO_TUNE", "GPX_MG_BCAST_CHUNKS"):
         env.pop(k, None)
     env.update(GPX_DIST_BACKEND="gloo", GPX_BENCH_SINGLE_DEVICE="1", GPX_POTRF_NB="256")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -441,9 +441,11 @@ def test_bench_three_ranks_choose_the_panel_broadcast_by_measurement():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 3 and out["rccl_nranks"] == 0 and len(out["comm_info_per_rank"]) == 3
     assert [c["rank"] for c in out["comm_info_per_rank"]] == [0, 1, 2]
-    tune = out["panel_bcast_autotune"]
-    assert tune["one_collective_s"] > 0 and tune["scatter_allgather_s"] > 0
-    assert out["panel_bcast"].startswith("scatter") == (tune["chosen"] == "scatter+allgather")
+    # nb is pinned by GPX_POTRF_NB here: the search is over the broadcast form and the row chunks, six untimed fits
+    tune = out["schedule_autotune"]
+    assert tune["candidates"] == 6 and {r["nb"] for r in tune["table"]} == {256}
+    assert {r["sag"] for r in tune["table"]} == {0, 1} and {r["chunks"] for r in tune["table"]} == {2, 4, 8}
+    assert out["panel_bcast"].startswith("scatter") == bool(tune["chosen"]["sag"])
     X, y, _ = orc.synth_inputs(N, d, 64)
     o = orc.OracleGP("gaussian", (1.0, 0.5 * np.sqrt(d)), X, y, 1.0)
     np.testing.assert_allclose(out["log_lh"], o.log_lh, rtol=1e-10)

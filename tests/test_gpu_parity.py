@@ -561,39 +561,7 @@ def test_fused_mean_device_api_vs_numpy(n, m, d):
     np.testing.assert_allclose(out.to_host(), ref, rtol=1e-10, atol=1e-10 * np.abs(ref).max())
 
 
-# ------------------------------------------------ multi-process path on the real kernels --
-def test_distributed_single_rank_hip_ops_vs_oracle():
-    import _py_schedule as multi_gpu
-    N, d, m = 2300, 4, 50
-    X, y, Xo = orc.synth_inputs(N, d, m)
-    ops = multi_gpu.HipOps(_lib.F64, 0)
-    g = multi_gpu.DistributedGP(ops, multi_gpu.LocalComm(), N, d, nb=256)
-    g.set_data(X, y)
-    params = np.array([1.0, 0.5 * np.sqrt(d)])
-    llh = g.fit(params, 1.0)
-    out = ops.empty((m,))
-    g.mean(ops.from_host(Xo), m, params, out)
-    ops.sync()
-    o = orc.OracleGP("gaussian", params, X, y, 1.0)
-    assert g.info_host == 0
-    np.testing.assert_allclose(llh, o.log_lh, rtol=1e-10)
-    np.testing.assert_allclose(ops.to_host(g.alpha), o.inv_Kxx_y, rtol=1e-8, atol=1e-11)
-    np.testing.assert_allclose(ops.to_host(out), o.mean(Xo), rtol=1e-8, atol=1e-11)
-
-
-@pytest.mark.parametrize("world,N,nb", [(2, 3000, 256), (3, 2500, 128)])
-def test_distributed_world_on_one_gpu_vs_oracle(tmp_path, world, N, nb):
-    """world_size ranks share GPU 0 (gloo moves the panels): the real HIP kernels under the
-    real block-cyclic schedule, checked against the oracle."""
-    from _dist_helpers import run_world
-    d, m = 3, 40
-    res = run_world(world, "gloo", True, N, d, nb, m, str(tmp_path))
-    X, y, Xo = orc.synth_inputs(N, d, m)
-    o = orc.OracleGP("gaussian", (1.0, 0.5 * np.sqrt(d)), X, y, 1.0)
-    assert int(res["info"]) == 0
-    np.testing.assert_allclose(float(res["log_lh"]), o.log_lh, rtol=1e-10)
-    np.testing.assert_allclose(res["alpha"], o.inv_Kxx_y, rtol=1e-8, atol=1e-11)
-    np.testing.assert_allclose(res["mean"], o.mean(Xo), rtol=1e-8, atol=1e-11)
+# (the multi-process path on the real kernels: the C schedule, tests/test_gpu_configs.py and test_gpu_round4.py)
 
 
 def test_mlii_batch_matches_oracle_and_reference_conventions():

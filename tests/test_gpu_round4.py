@@ -615,7 +615,7 @@ def test_bench_four_ranks_line_schema_over_gloo():
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    env.update(GPX_DIST_BACKEND="gloo", GPX_BENCH_SINGLE_DEVICE="1")
+    env.update(GPX_DIST_BACKEND="gloo", GPX_BENCH_SINGLE_DEVICE="1", GPX_BENCH_TUNE_BUDGET_S="20")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--problem-n", "6144",
                         "--problem-d", "4", "--problem-m", "64", "--steps", "1", "--warmup", "1"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
@@ -630,9 +630,16 @@ def test_bench_four_ranks_line_schema_over_gloo():
     for row in out["stage_and_chain_ms_per_rank"]:
         assert set(row) >= {"kernel_build", "factor", "solve", "chain_panel", "chain_bcast", "chain_update"}
         assert row["factor"] > 0
-    tune = out["panel_bcast_autotune"]
-    assert tune is not None and tune["chosen"] in ("scatter+allgather", "one collective per chunk")
-    assert tune["one_collective_s"] > 0 and tune["scatter_allgather_s"] > 0
+    # (round 5) the schedule's free parameters are measured in the run: nb x chunks x broadcast form, under a budget
+    tune = out["schedule_autotune"]
+    assert tune is not None and tune["measured"] >= 1 and tune["measured"] == len(tune["table"]) <= tune["candidates"]
+    assert {r["nb"] for r in tune["table"]} <= {256, 512, 1024} and all(r["fit_s"] > 0 for r in tune["table"])
+    best = min(tune["table"], key=lambda r: (r["fit_s"], r["nb"], r["chunks"], r["sag"]))
+    assert tune["chosen"] == {k: best[k] for k in ("nb", "chunks", "sag")}
+    assert out["panel_bcast"].startswith("scatter") == bool(tune["chosen"]["sag"]) and out["bcast_chunks"] == tune["chosen"]["chunks"]
+    assert ("nb=%d" % tune["chosen"]["nb"]) in out["config"]["parallelism"]
+    for row in out["stage_and_chain_ms_per_rank"]:
+        assert row["exposed_wait"] >= 0 and row["exposed_wait_max"] >= 0 and row["exposed_waits_over_20us"] >= 0
     assert out["watchdog_s"] > 0 and out["check"]["max_abs_residual_K_alpha_minus_y_over_max_y"] < 1e-9
     X, y, _ = orc.synth_inputs(6144, 4, 64)
     o = orc.OracleGP("gaussian", (1.0, 0.5 * np.sqrt(4)), X, y, 1.0)

@@ -204,3 +204,25 @@ def test_checkpoint_file_mode_follows_the_umask(tmp_path):
         os.umask(old)
     g2 = gp.GP.load_fitted(p2)
     assert float(g2.log_lh) == float(g.log_lh)
+
+
+# ------------------------------------------------------------------------------- multi-GPU rehearsal --
+@pytest.mark.parametrize("world,rank,nb,sag", [(4, 1, 256, 0), (8, 7, 256, 1), (2, 0, 512, 0)])
+def test_rehearsal_of_one_rank_reproduces_its_block_columns(world, rank, nb, sag):
+    """gpx_mg_create_rehearsal: rank `rank` of a `world`-rank run in this one process -- its own panels, packs and updates
+    through the product's C schedule, the panels it does not own copied out of a resident single-GPU factor of the same
+    matrix behind modelled transfer delays.  What the rank computes must be its block columns of that factor (and the
+    solution the single-GPU fit's), the timing must carry the exposed-wait and modelled-transfer classes."""
+    from gaussian_processes_amd import multi_gpu
+    N, d = 6000, 3
+    X, y, _ = orc.synth_inputs(N, d, 4)
+    params, s = np.array([1.0, 0.5 * np.sqrt(d)]), 1.0
+    out = multi_gpu.rehearse_rank(N, d, rank, world, X, y, params, s, nb=nb, chunks=4, sag=sag, fits=2, link_GBps=100.0)
+    assert out["check"]["owned_columns_vs_resident_factor_max_rel_err"] < 1e-10, out["check"]
+    assert out["check"]["alpha_vs_single_gpu_max_rel_err"] < 1e-7, out["check"]
+    o = orc.OracleGP("gaussian", params, X, y, s)
+    np.testing.assert_allclose(out["single_gpu_log_lh"], o.log_lh, rtol=1e-10)
+    last = out["fits"][-1]
+    assert last["modelled_transfer"] > 0 and last["exposed_wait"] >= 0 and last["chain_update"] > 0
+    assert out["owned_panels"] == len([j for j in range(-(-N // nb)) if j % world == rank])
+    assert out["per_step_ms"]["own_chain_per_owned_panel_mean"] > 0
