@@ -46,7 +46,8 @@ def parse_args():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--cpu-sample-n", type=int, default=12288)    # 15-20 s of host work on the GPU box
     ap.add_argument("--cpu-sample-n2", type=int, default=18432)   # second sample (~30 s)
-    ap.add_argument("--cpu-sample-n3", type=int, default=24576)   # third sample (~60 s): the one `value` is scaled from
+    ap.add_argument("--cpu-sample-n3", type=int, default=0)       # optional third sample (24576: ~60 s, ~15 GiB of host memory);
+                                                                  # off by default since the full-size run was MEASURED (round 5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip per-launch HIP-event profiling")
     ap.add_argument("--no-secondary", action="store_true",
@@ -182,6 +183,33 @@ def cpu_baseline(N, d, m, sample_ns):
     out["full_size_run"] = {"host_mem_gib": None if host_gib is None else round(host_gib, 1),
                             "needed_mem_gib": round(need_gib, 1), "estimated_seconds": round(value, 1),
                             "binding_limit": ("memory" if (host_gib is not None and host_gib < need_gib) else "time")}
+    # Round 5: the workload itself was run ONCE at full size on a GPU box's host, off the timed bench
+    # (tools/cpu_baseline_full.py -> profiles/r05_cpu_baseline_n65536.json).  When that measurement is of this workload
+    # and of this CPU model it IS the baseline (`value`): one number, no spread; today's bounded samples stay beside it, and
+    # `extrapolated_over_measured` says how far the nominal-exponent scaling of the largest sample is off.
+    out["extrapolated_value"] = out["value"]
+    out["value_is"] = "EXTRAPOLATED from the largest in-run sample at nominal exponents: an UPPER estimate (see spread)"
+    try:
+        mpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r05_cpu_baseline_n%d.json" % N)
+        meas = json.load(open(mpath))
+        if meas["N"] == N and meas["d"] == d and meas.get("reference_faithful_value_s"):
+            same_cpu = meas["host"].get("cpu_model") == cpu_model and meas["host"].get("blas_threads") == blas_threads
+            out["measured_full_size"] = {
+                "file": "profiles/r05_cpu_baseline_n%d.json" % N, "seconds": meas["seconds"],
+                "reference_faithful_s": meas["reference_faithful_value_s"], "fair_s": meas["fair_value_s"],
+                "gflops": meas["gflops"], "host": {k: meas["host"].get(k) for k in ("cpu_model", "blas_threads", "mem_gib")},
+                "same_cpu_model_and_threads_as_this_run": bool(same_cpu),
+                "label": "measured offline on %s (%s BLAS threads), tools/cpu_baseline_full.py"
+                         % (meas["host"].get("cpu_model"), meas["host"].get("blas_threads"))}
+            out["extrapolated_over_measured"] = round(value / meas["reference_faithful_value_s"], 3)
+            if same_cpu:
+                out["value"] = round(meas["reference_faithful_value_s"], 3)
+                out["fair_value"] = round(meas["fair_value_s"], 3)
+                out["spread"] = {"low": out["value"], "high": out["value"],
+                                 "meaning": "measured at full size (no extrapolation); the in-run samples' extrapolation is `extrapolated_value`"}
+                out["value_is"] = "MEASURED at full size offline on this CPU model with this thread count; today's samples beside it"
+    except (OSError, ValueError, KeyError):
+        pass
     api = next((p for p in blas if p.get("user_api") == "blas"), {})
     out["sample"] = (
         "oracle stage sequence (C kernel loop 1 thread; scipy cholesky / cho_solve, numpy slogdet LU on %d threads of %s %s) at d=%d "
@@ -192,6 +220,12 @@ def cpu_baseline(N, d, m, sample_ns):
            base_n, N, need_gib, value,
            " / ".join("%.0f" % smp["gflops"]["potrf"] for smp in out["samples"]),
            " / ".join("%.0f" % smp["gflops"]["slogdet_lu"] for smp in out["samples"]), fair))
+    if "measured_full_size" in out:
+        mf = out["measured_full_size"]
+        out["sample"] += (" | MEASURED at full size offline (%s): %.1f s reference-faithful, %.1f s without the LU (potrf %s GFLOP/s, LU %s)"
+                          "; extrapolated / measured = %.2f"
+                          % (mf["label"], mf["reference_faithful_s"], mf["fair_s"], mf["gflops"]["potrf"], mf["gflops"]["slogdet_lu"],
+                             out["extrapolated_over_measured"]))
     return out
 
 
