@@ -576,7 +576,8 @@ def measure_single(args, lib, _lib, N, d, m, dtid, npdt, steps, warmup, local_ra
             try:
                 import hashlib
                 here = os.path.dirname(os.path.abspath(__file__))
-                pmc_rel = next(rel for rel in (os.path.join("profiles", "r04_pmc", "traffic_n65536.json"),
+                pmc_rel = next(rel for rel in (os.path.join("profiles", "r05_pmc", "traffic_n65536.json"),
+                                               os.path.join("profiles", "r04_pmc", "traffic_n65536.json"),
                                                os.path.join("profiles", "r03_pmc", "traffic_n65536.json"),
                                                os.path.join("profiles", "r02_pmc", "traffic_n65536.json"))
                                if os.path.exists(os.path.join(here, rel)))
