@@ -12,9 +12,9 @@ collectives -- runs in C behind the ABI (csrc/gpx_mg.hip, ``gpx_mg_*``);
 is the CONTROL plane only: rendezvous, the ncclUniqueId, agreeing that every rank's
 local allocations succeeded before anybody enters ncclCommInitRank, barriers and
 the max-over-ranks clock of the benchmark.  Nothing in this module touches
-torch.cuda.  (The same schedule written out in Python over device-op objects, which
-the CPU gloo tests use to exercise ownership maps and collective order without a
-GPU, is test infrastructure: tests/_py_schedule.py.)
+torch.cuda.  Round 5: the schedule's free parameters are measured in the run
+(`tune_schedule`), and one rank's share of a P-rank run can be rehearsed at full size
+on one GPU (`rehearse_rank`: measured compute, modelled transfer).
 """
 import ctypes
 import os

@@ -167,8 +167,9 @@ int gpx_prof_enable(int on);    /* also clears the registry */
 int gpx_prof_read(int cls, double *launches, double *total_ms, double *total_work);
 
 /* Route counters: how often each of the alternative host-side routes was taken since the last reset (counted at
- * the point of decision, always on).  Every behaviour switch of the library is an environment variable that is
- * read PER CALL at its point of use; a test that forces a route asserts it here. */
+ * the point of decision, always on).  Every behaviour switch of the library is an environment variable; each entry point
+ * takes one snapshot of them for the calling thread (csrc/gpx_tune.h); a test that forces a route
+ * asserts it here. */
 #define GPX_ROUTE_TRSV_OPS        0   /* single-rhs solve: operator form (one launch per 512-block step)      */
 #define GPX_ROUTE_TRSV_STEPS      1   /* single-rhs solve: two launches per 512-block                         */
 #define GPX_ROUTE_PANEL_RES       2   /* panel: the resident one-launch kernel                                */
