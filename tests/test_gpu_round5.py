@@ -226,3 +226,30 @@ def test_rehearsal_of_one_rank_reproduces_its_block_columns(world, rank, nb, sag
     assert last["modelled_transfer"] > 0 and last["exposed_wait"] >= 0 and last["chain_update"] > 0
     assert out["owned_panels"] == len([j for j in range(-(-N // nb)) if j % world == rank])
     assert out["per_step_ms"]["own_chain_per_owned_panel_mean"] > 0
+
+
+def test_rccl_communicator_can_be_recreated_per_width(monkeypatch):
+    """bench.py's tuning pass closes a handle and creates the next one (a new block-column width is a new local layout and a
+    new communicator) several times in ONE process: three RCCL handles in a row (one rank, every collective forced to be a
+    real RCCL call), each with its own ncclUniqueId, each fitting the same data to the oracle's log_lh, with the chunk count
+    and the broadcast form changed between fits as the tuning pass does."""
+    from gaussian_processes_amd import multi_gpu
+    monkeypatch.setenv("GPX_FORCE_COLLECTIVES", "1")
+    N, d = 3000, 3
+    X, y, Xo = orc.synth_inputs(N, d, 8)
+    params, s = np.array([1.0, 0.5 * np.sqrt(d)]), 1.0
+    o = orc.OracleGP("gaussian", params, X, y, s)
+    for nb in (256, 512, 1024):
+        mg = multi_gpu.NativeDistributedGP(N, d, nb=nb, backend="rccl", device=0)
+        try:
+            assert mg.comm_info()["rccl_nranks"] == 1
+            mg.set_data(X, y)
+            for chunks, sag in ((2, 0), (8, 1), (4, 0)):
+                mg.set_chunks(chunks)
+                mg.set_bcast(sag)
+                np.testing.assert_allclose(mg.fit(params, s), o.log_lh, rtol=1e-10)
+            tm = mg.timing(extended=True)
+            assert tm["exposed_wait"] >= 0 and tm["modelled_transfer"] == 0 and tm["factor"] > 0
+            np.testing.assert_allclose(mg.mean(params, Xo), o.mean(Xo), rtol=1e-8, atol=1e-11)
+        finally:
+            mg.close()
