@@ -146,6 +146,7 @@ _SIGNATURES = {
     "gpx_mg_timing": (c_int, [c_void_p, c_double_p]),
     "gpx_mg_timing_ex": (c_int, [c_void_p, c_double_p, c_int]),
     "gpx_mg_chain_by_panel": (c_int, [c_void_p, c_double_p, c_int64]),
+    "gpx_mg_adopt_comm": (c_int, [c_void_p, c_void_p]),
     "gpx_mg_set_chunks": (c_int, [c_void_p, c_int]),
     "gpx_mg_set_owner_first": (c_int, [c_void_p, c_int]),
     "gpx_mg_device_ptrs": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int64)]),

@@ -815,6 +815,21 @@ int gpx_mg_create(gpx_mg_t **out, int dtype, int kernel, int64_t n, int d, int64
     return rc;
 }
 
+int gpx_mg_adopt_comm(gpx_mg_t *g, gpx_mg_t *from)
+{
+    MG_ENTER(g);
+    GPX_ARG(from != nullptr && from != g, "no handle to adopt the communicator from");
+    GPX_ARG(!g->comm && !g->cb_bcast && !g->rehearse, "the handle already has a communicator");
+    GPX_ARG(from->comm != nullptr, "the other handle has no RCCL communicator");
+    GPX_ARG(from->world == g->world && from->rank == g->rank && from->device == g->device, "world / rank / device differ");
+    // everything the other handle queued on the communicator has to be done before this one issues collectives on it
+    if (from->B) GPX_HIP(hipStreamSynchronize(from->B));
+    if (from->S) GPX_HIP(hipStreamSynchronize(from->S));
+    g->comm = from->comm;
+    from->comm = nullptr;                                         // (its destroy no longer touches the communicator)
+    return GPX_OK;
+}
+
 int gpx_mg_comm_info(gpx_mg_t *g, int *nranks, int *rank, int *device, int *bcast_sag)
 {
     MG_ENTER(g);

@@ -135,7 +135,7 @@ class NativeDistributedGP(object):
                                     "modelled_remote_chain")
 
     def __init__(self, n, d, dtype_id=_lib.F64, kernel_id=_lib.KERNEL_GAUSSIAN, nb=None, dist=None,
-                 backend="rccl", device=0, callbacks=None, rehearsal=None):
+                 backend="rccl", device=0, callbacks=None, rehearsal=None, adopt_from=None):
         """`callbacks` (backend="callbacks" only): an object with ctypes function pointers `.bcast` / `.allreduce`
         (gpx_mg_bcast_fn / gpx_mg_allreduce_fn of include/gpx.h), an `.error` slot and `.rank` / `.world` -- any
         transport for the host-callback data plane; default: `GlooCallbacks(dist)`."""
@@ -171,9 +171,10 @@ class NativeDistributedGP(object):
                                               self.world, self.rank)
             err = _lib.last_error() if rc != 0 else ""
             ident = np.zeros(_lib.MG_ID_BYTES, dtype=np.uint8)
-            if rc == 0 and self.rank == 0:
+            if rc == 0 and self.rank == 0 and adopt_from is None:
                 rc = self.lib.gpx_mg_unique_id(ident.ctypes.data_as(ctypes.c_void_p))
                 err = _lib.last_error() if rc != 0 else ""
+            adopt = adopt_from is not None
             if dist is not None and self.world > 1:
                 import torch
                 from .mlii import _cpu_group
@@ -184,11 +185,17 @@ class NativeDistributedGP(object):
                     self.close()
                     raise _lib.GpxError("multi-GPU set-up failed on %s before the communicator was created%s"
                                         % ("this rank" if rc != 0 else "another rank", (": " + err) if err else ""))
-                dist.broadcast(torch.from_numpy(ident), src=0, group=cpu)    # the ncclUniqueId travels out of band
+                if not adopt:
+                    dist.broadcast(torch.from_numpy(ident), src=0, group=cpu)    # the ncclUniqueId travels out of band
             else:
                 _lib.check(rc)
             try:
-                _lib.check(self.lib.gpx_mg_connect(self.h, ident.ctypes.data_as(ctypes.c_void_p)))
+                if adopt:
+                    # ONE ncclCommInitRank per process: a handle of another width takes over the communicator (round 5: the
+                    # tuning pass tries several layouts; re-creating communicators in a running job is a risk nobody needs)
+                    _lib.check(self.lib.gpx_mg_adopt_comm(self.h, adopt_from.h))
+                else:
+                    _lib.check(self.lib.gpx_mg_connect(self.h, ident.ctypes.data_as(ctypes.c_void_p)))
             except Exception:
                 self.close()
                 raise
@@ -527,11 +534,16 @@ def bench_distributed(args, X, y, Xo, params, s, dtype_id, residual_check=None):
         def make(nb):
             """A handle of block-column width nb (a new local layout: allocation, data, communicator) and its first fit --
             the first real collectives of that communicator -- under the watchdog."""
-            if holder["gp"] is not None:
-                holder["gp"].close()
-                holder["gp"] = None
+            old_gp = holder["gp"]
+            if old_gp is not None and backend != "rccl":
+                old_gp.close()                          # (callbacks: nothing to take over)
+                old_gp = None
             with Watchdog(wd_s, "communicator set-up (%s, world %d, nb %s)" % (backend, world, nb), rank):
-                g_ = NativeDistributedGP(N, d, dtype_id=dtype_id, nb=nb, dist=dist, backend=backend, device=local_rank)
+                # a further handle takes over the first one's RCCL communicator: ONE ncclCommInitRank per process
+                g_ = NativeDistributedGP(N, d, dtype_id=dtype_id, nb=nb, dist=dist, backend=backend, device=local_rank,
+                                         adopt_from=old_gp)
+            if old_gp is not None:
+                old_gp.close()
             g_.set_data(X, y)
             holder["gp"] = g_
             with Watchdog(wd_s, "first fit + predict (N=%d, world %d, nb %d)" % (N, world, g_.nb), rank):
@@ -560,7 +572,7 @@ def bench_distributed(args, X, y, Xo, params, s, dtype_id, residual_check=None):
         # owner's chain or the update bounds a step at a given width, depends on the node.  Variables that pin a parameter
         # (GPX_POTRF_NB, GPX_MG_BCAST_CHUNKS, GPX_MG_BCAST) take it out of the search.
         sched_tune = None
-        if world > 1 and not os.environ.get("GPX_BENCH_NO_TUNE"):
+        if (world > 1 or os.environ.get("GPX_BENCH_FORCE_TUNE")) and not os.environ.get("GPX_BENCH_NO_TUNE"):
             nb0 = holder["gp"].nb
             nbs = (nb0,) if os.environ.get("GPX_POTRF_NB") else tuple(sorted({256, 512, 1024, nb0}, key=lambda v: (v != nb0, v)))
             chunks = (int(os.environ["GPX_MG_BCAST_CHUNKS"]),) if os.environ.get("GPX_MG_BCAST_CHUNKS") else (2, 4, 8)

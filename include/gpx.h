@@ -476,6 +476,10 @@ int gpx_mg_chain_by_panel(gpx_mg_t *mg, double *ms, int64_t count);
 /* raw device view of this rank's local matrix, (n + 1) x ld, block column j of the rank at column (j / world) nb (tests, the
  * rehearsal's check; do not free) */
 int gpx_mg_device_ptrs(gpx_mg_t *mg, void **A, int64_t *ld);
+/* Move the RCCL communicator of `from` (same world, rank and device; e.g. a handle of another block-column width) into `mg`,
+ * which was made with gpx_mg_create_local and has none yet: ONE ncclCommInitRank per process however many layouts a run
+ * tries.  `from` keeps working only as far as it needs no collective (world 1) and may be destroyed. */
+int gpx_mg_adopt_comm(gpx_mg_t *mg, gpx_mg_t *from);
 /* on != 0: the owner of the next panel factors it before it starts its own share of the trailing update (the panel is the
  * serial chain of the run; default: on for world >= 2, GPX_MG_OWNER_FIRST=0 / 1 overrides). */
 int gpx_mg_set_owner_first(gpx_mg_t *mg, int on);

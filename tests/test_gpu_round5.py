@@ -228,20 +228,25 @@ def test_rehearsal_of_one_rank_reproduces_its_block_columns(world, rank, nb, sag
     assert out["per_step_ms"]["own_chain_per_owned_panel_mean"] > 0
 
 
-def test_rccl_communicator_can_be_recreated_per_width(monkeypatch):
-    """bench.py's tuning pass closes a handle and creates the next one (a new block-column width is a new local layout and a
-    new communicator) several times in ONE process: three RCCL handles in a row (one rank, every collective forced to be a
-    real RCCL call), each with its own ncclUniqueId, each fitting the same data to the oracle's log_lh, with the chunk count
-    and the broadcast form changed between fits as the tuning pass does."""
+def test_one_rccl_communicator_serves_every_width(monkeypatch):
+    """bench.py's tuning pass tries several block-column widths; a new width is a new local layout, i.e. a new handle -- but
+    NOT a new communicator: the next handle takes over the previous one's (gpx_mg_adopt_comm: one ncclCommInitRank per
+    process).  Three widths in a row on one RCCL communicator (one rank, every collective forced to be a real RCCL call),
+    each fitting the same data to the oracle's log_lh, with the chunk count and the broadcast form changed between fits
+    as the tuning pass does; the handle that gave its communicator away can still be closed."""
     from gaussian_processes_amd import multi_gpu
     monkeypatch.setenv("GPX_FORCE_COLLECTIVES", "1")
     N, d = 3000, 3
     X, y, Xo = orc.synth_inputs(N, d, 8)
     params, s = np.array([1.0, 0.5 * np.sqrt(d)]), 1.0
     o = orc.OracleGP("gaussian", params, X, y, s)
-    for nb in (256, 512, 1024):
-        mg = multi_gpu.NativeDistributedGP(N, d, nb=nb, backend="rccl", device=0)
-        try:
+    prev = None
+    try:
+        for nb in (512, 256, 1024):
+            mg = multi_gpu.NativeDistributedGP(N, d, nb=nb, backend="rccl", device=0, adopt_from=prev)
+            if prev is not None:
+                prev.close()
+            prev = mg
             assert mg.comm_info()["rccl_nranks"] == 1
             mg.set_data(X, y)
             for chunks, sag in ((2, 0), (8, 1), (4, 0)):
@@ -251,5 +256,39 @@ def test_rccl_communicator_can_be_recreated_per_width(monkeypatch):
             tm = mg.timing(extended=True)
             assert tm["exposed_wait"] >= 0 and tm["modelled_transfer"] == 0 and tm["factor"] > 0
             np.testing.assert_allclose(mg.mean(params, Xo), o.mean(Xo), rtol=1e-8, atol=1e-11)
-        finally:
-            mg.close()
+    finally:
+        if prev is not None:
+            prev.close()
+
+
+def test_bench_tuning_pass_over_one_rccl_rank_adopts_the_communicator():
+    """The flow the first real multi-GPU run will take, as far as one GPU can take it: bench.py's distributed leg over a
+    real RCCL communicator (one rank, every collective forced), the tuning pass forced on: three block-column widths x
+    three chunk counts, every new width a new handle that takes over the ONE communicator; the line carries the table,
+    the chosen triple is the table's best, the result is the oracle's."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "GPX_MG_BCAST", "GPX_BENCH_NO_TUNE", "GPX_POTRF_NB",
+              "GPX_MG_BCAST_CHUNKS", "GPX_DIST_BACKEND"):
+        env.pop(k, None)
+    env.update(GPX_BENCH_FORCE_DIST="1", GPX_FORCE_COLLECTIVES="1", GPX_BENCH_FORCE_TUNE="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT="29641")
+    N, d = 6144, 4
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--problem-n", str(N), "--problem-d", str(d),
+                        "--problem-m", "64", "--steps", "1", "--warmup", "1"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")][-1])
+    assert out["rccl_nranks"] == 1
+    tune = out["schedule_autotune"]
+    assert tune["measured"] == 9 and {row["nb"] for row in tune["table"]} == {256, 512, 1024}
+    best = min(tune["table"], key=lambda row: (row["fit_s"], row["nb"], row["chunks"], row["sag"]))
+    assert tune["chosen"] == {k: best[k] for k in ("nb", "chunks", "sag")}
+    assert ("nb=%d" % tune["chosen"]["nb"]) in out["config"]["parallelism"]
+    X, y, _ = orc.synth_inputs(N, d, 64)
+    o = orc.OracleGP("gaussian", (1.0, 0.5 * np.sqrt(d)), X, y, 1.0)
+    np.testing.assert_allclose(out["log_lh"], o.log_lh, rtol=1e-10)
+    assert out["stage_and_chain_ms_per_rank"][0]["exposed_wait"] >= 0
