@@ -783,6 +783,10 @@ static int panel_res_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int
     const bool excl = !bt && idle_chip && rows <= excl_rows;
     // (panels of up to GPX_LEAF4_ROWS rows take the LV = 4 instantiation beside an update too: n = 8192 5.94 -> 5.79 ms; taller
     //  ones lose more CUs to its one-workgroup-per-CU footprint than the leaf gives back: n = 16384 27.85 -> 28.4 ms)
+    // (Several host threads factoring at once -- 4 x 128 one-per-CU workgroups wanting 256 CUs -- cannot deadlock: inside a
+    //  launch workgroups are dispatched in id order, a consumer is only ever placed after its producers (ids 0 .. 3), and a
+    //  producer waits for nothing but earlier producers of its own launch; what is not placed yet simply waits for a CU.
+    //  tests/test_gpu_round5.py::test_four_host_threads_factor_n8192_concurrently holds it: 24 fits, no -7, bit-identical.)
     const int64_t leaf_dflt = (excl || (!bt && rows <= tune().leaf4_rows[F64 ? 0 : 1])) ? 4 : 1;
     // (the asm-scheduled leaf only where it has passed its self-check on this device; the check's own launches force a level)
     const bool asm_ok = g_leaf_force != 0 || leaf_asm_ok(st);
