@@ -69,7 +69,7 @@ extern bool g_prof_on;
 int  prof_begin(int cls, double work, hipStream_t st);    // record index, -1 when nothing was recorded
 void prof_end(int rec, hipStream_t st);
 // roctx ranges (GPX_ROCTX=1; libroctx64.so by dlopen): every gpx_gp_* call and every launch class below it is a nested host
-// range, so `rocprofv3 --marker-trace --kernel-trace` shows which stage of a fit a kernel belongs to.  Off: one getenv per scope.
+// range, so `rocprofv3 --marker-trace --kernel-trace` shows which stage of a fit a kernel belongs to.  Off: one field of the snapshot per scope.
 bool roctx_push(const char *name);          // false: ranges are off (or the library is not there): nothing to pop
 void roctx_pop();
 struct RoctxRange {
