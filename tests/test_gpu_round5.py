@@ -292,3 +292,21 @@ def test_bench_tuning_pass_over_one_rccl_rank_adopts_the_communicator():
     o = orc.OracleGP("gaussian", (1.0, 0.5 * np.sqrt(d)), X, y, 1.0)
     np.testing.assert_allclose(out["log_lh"], o.log_lh, rtol=1e-10)
     assert out["stage_and_chain_ms_per_rank"][0]["exposed_wait"] >= 0
+
+
+@pytest.mark.parametrize("owner_first", ["0", "1"])
+def test_native_world3_with_and_without_owner_first(tmp_path, monkeypatch, owner_first):
+    """The owner-first schedule (the owner of the next panel factors it before its own trailing update; default on) and the
+    schedule without it: three ranks sharing GPU 0 over host callbacks, against the oracle -- the switch only moves a wait,
+    both must give the same factorisation."""
+    from _dist_helpers import run_native_world
+    monkeypatch.setenv("GPX_MG_OWNER_FIRST", owner_first)
+    N, d, m = 4100, 3, 24
+    res = run_native_world(3, N, d, 256, m, str(tmp_path))
+    X, y, Xo = orc.synth_inputs(N, d, m)
+    o = orc.OracleGP("gaussian", (1.0, 0.5 * np.sqrt(d)), X, y, 1.0)
+    assert int(res["info"]) == 0
+    np.testing.assert_allclose(float(res["log_lh"]), o.log_lh, rtol=1e-10)
+    np.testing.assert_allclose(float(res["log_lh2"]), float(res["log_lh"]), rtol=0, atol=0)
+    np.testing.assert_allclose(res["alpha"], o.inv_Kxx_y, rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(res["mean"], o.mean(Xo), rtol=1e-8, atol=1e-11)
