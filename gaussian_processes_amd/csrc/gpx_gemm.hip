@@ -177,6 +177,27 @@ __device__ __forceinline__ void store_wave_tile_atomic(typename M::acc_t (&acc)[
         }
 }
 
+// The same for a wave tile that lies wholly inside the matrix and wholly at or below the diagonal (all but the
+// edge and diagonal tiles of a trailing update): no bounds or triangle tests, one lane pointer, the row part of the
+// offset wave-uniform and the column part an immediate -- two vector instructions per atomic instead of seventeen
+// (the general form's 64-bit index arithmetic and exec masking ran on the SIMD whose other wave is in its k-loop).
+template <typename T, typename M, int NTJ>
+__device__ __forceinline__ void store_wave_tile_atomic_inner(typename M::acc_t (&acc)[64 / (M::NR == 4 ? 16 : 32)][NTJ],
+                                                             T *__restrict__ C, int64_t ldc, int64_t r_base,
+                                                             int64_t c_base, int lane, T alpha)
+{
+    constexpr int TM = M::NR == 4 ? 16 : 32, NR = M::NR, TI = 64 / TM;
+    T *p = C + (r_base + M::row(lane, 0)) * ldc + c_base + (lane & (TM - 1));
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            T *pr = p + (int64_t)(i * TM + M::row(0, r)) * ldc;
+#pragma unroll
+            for (int j = 0; j < NTJ; ++j) atomic_add_nr(pr + j * TM, alpha * acc[i][j][r]);
+        }
+}
+
 // exchange a value with the neighbouring lane (lane ^ 1) through DPP quad_perm [1,0,3,2]
 __device__ __forceinline__ double swap_pair(double v)
 {
@@ -447,7 +468,6 @@ struct GemmMap {
     // diagnostic: when non-null, wave 0 of every workgroup stores 4 s_memtime stamps
     // (start, first barrier passed, k-loop done, epilogue done) 2 s_memrealtime stamps and the hardware ids at stamps[8 * blockIdx]
     unsigned long long *stamps;
-    int ablate;   // diagnostic (GPX_GEMM_ABLATE): 1 no barrier/vmcnt, 2 no DMA in loop, 4 no LDS reads in loop
     int vec_c;    // C allows 2-element vector accesses (ldc even, aligned base, N even)
     int atomic_c; // epilogue by no-return atomic adds (GPX_GEMM_ATOMIC_C)
     // the factorisation's `info`: once a pivot has failed the factor is garbage whatever the remaining
@@ -481,7 +501,7 @@ typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
 // TAG only changes the symbol name: 1 = the block-cyclic trailing update of the
 // factorisation (gpx_d_syrk_bc), so that profilers list the dominant kernel separately
 // from the panel / covariance products that share its code.
-template <typename T, int BN, int TAG, int BM = 256>
+template <typename T, int BN, int TAG, int BM = 256, int ABL = 0>
 __global__ __launch_bounds__(BM * 2, 2) void gemm_nt_fast_kernel(int64_t M, int64_t N, int64_t K,
                                                               const T *__restrict__ A, int64_t lda,
                                                               const T *__restrict__ B, int64_t ldb,
@@ -739,13 +759,19 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_nt_fast_kernel(int64_t M, int6
                     for (int j = 0; j < TJ; ++j) acc[i][j] = MM::mfma(ha[i][ss], hb[j][ss], acc[i][j]);
                     __builtin_amdgcn_sched_barrier(0);
                     const int g = ss * TI + i;               // fp64: 8 slots of 4 MFMAs; fp32: 16 slots of 2 MFMAs
-                    if (TM == 16) { if (!(fm.ablate & 4)) GPX_SLOT_READ(g, r1a, r1b, aa1, ab1); }
-                    else if ((g & 1) == 0) { if (!(fm.ablate & 4)) GPX_SLOT_READ(g / 2, r1a, r1b, aa1, ab1); }
+                    // the reads sit in the FIRST half of the slots: the last fragment is requested >= 1024 matrix-pipe
+                    // cycles before the wait that needs it (round 6; one read per slot put the last one right in
+                    // front of that wait, and a workgroup alone on its CU -- its neighbour in its prologue or
+                    // epilogue -- paid the LDS latency twice per k-step: 0.904 -> 0.925 of peak at M = 32768, K = 1024)
+                    if (!(ABL & 4)) {
+                        if (TM == 16) { if (g < 4) { GPX_SLOT_READ(2 * g, r1a, r1b, aa1, ab1); GPX_SLOT_READ(2 * g + 1, r1a, r1b, aa1, ab1); } }
+                        else if (g < 8) GPX_SLOT_READ(g, r1a, r1b, aa1, ab1);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // R1 in: this wave is done reading the stage
-        if (!(fm.ablate & 1)) {
+        if (!(ABL & 1)) {
             WaitVm<(F_NST - 2) * PW>::go();          // slice kt+1 landed (this wave's pieces), then everybody's
             __builtin_amdgcn_s_barrier();
         }
@@ -765,12 +791,11 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_nt_fast_kernel(int64_t M, int6
                     __builtin_amdgcn_sched_barrier(0);
                     const int g = ss * TI + i;
                     if (TM == 16) {
-                        if (g < PW && !(fm.ablate & 2)) issue1(stage, g, inc);      // into the buffer just consumed
-                        if (g < 8 && !(fm.ablate & 4)) GPX_SLOT_READ(g, r0a, r0b, aa0, ab0);
-                    } else if ((g & 1) == 0) {                                       // 16 slots: reads on the even ones,
-                        if (!(fm.ablate & 4)) GPX_SLOT_READ(g / 2, r0a, r0b, aa0, ab0);
-                    } else {                                                         // DMA pieces on the odd ones
-                        if (g / 2 < PW && !(fm.ablate & 2)) issue1(stage, g / 2, inc);
+                        if (g < PW && !(ABL & 2)) issue1(stage, g, inc);            // into the buffer just consumed
+                        if (g < 4 && !(ABL & 4)) { GPX_SLOT_READ(2 * g, r0a, r0b, aa0, ab0); GPX_SLOT_READ(2 * g + 1, r0a, r0b, aa0, ab0); }
+                    } else {                                                         // 16 slots: DMA pieces on the odd ones
+                        if (g < 8 && !(ABL & 4)) GPX_SLOT_READ(g, r0a, r0b, aa0, ab0);
+                        if ((g & 1) && g / 2 < PW && !(ABL & 2)) issue1(stage, g / 2, inc);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -781,7 +806,20 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_nt_fast_kernel(int64_t M, int6
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // tail DMA / reads must not outlive the tile
 
     if (fm.stamps) { __builtin_amdgcn_s_barrier(); st2 = __builtin_amdgcn_s_memtime(); }   // all waves done
-    if (fm.atomic_c && !beta0)
+    if (ABL & 8) {                             // timing only: no epilogue (one element keeps the accumulators alive)
+        T sum = (T)0;
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                for (int r = 0; r < MM::NR; ++r) sum += acc[i][j][r];
+        if (sum == (T)123.456) C[0] = sum;
+    } else
+    if (fm.atomic_c && !beta0 && bm0 + F_BM <= M && bn0 + BN <= N &&
+        (tri != GPX_LOWER || row0 + bm0 >= col0 + bn0 + BN - 1))
+        store_wave_tile_atomic_inner<T, MM, TJ>(acc, C, ldc, bm0 + wr * 64, bn0 + wc * (BN / 2), lane, alpha);
+    else if (fm.atomic_c && !beta0)
         store_wave_tile_atomic<T, NTW, MM, TJ>(acc, C, ldc, M, N, bm0 + wr * 64, bn0 + wc * (BN / 2), lane, alpha, tri, row0,
                                        col0);
     else if (fm.vec_c)
@@ -803,14 +841,18 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_nt_fast_kernel(int64_t M, int6
 }
 #undef GPX_DSR
 
-template <typename T, int BN = 128, int TAG = 0, int BM = 256>
+// ABL: timing-only ablations of the trailing-update kernel (GPX_GEMM_ABLATE, wrong results on purpose; compile-time so
+// that the product kernel carries no branch for them): 1 no barrier / vmcnt, 2 no DMA in the loop, 4 no LDS reads in
+// the loop, 8 no epilogue
+template <typename T, int BN = 128, int TAG = 0, int BM = 256, int ABL = 0>
 static int launch_gemm_nt_fast(int64_t M, int64_t N, int64_t K, const void *A, int64_t lda,
                                const void *B, int64_t ldb, void *C, int64_t ldc, double alpha, int tri,
                                int64_t row0, int64_t col0, hipStream_t st, const GemmMap *map = nullptr,
                                double work = -1.0, int beta0 = 0, int ktri = 0, const Batch *bt = nullptr)
 {
     constexpr int F_SMEM = FGeo<BN, BM>::SMEM;
-    GPX_TRY(set_max_lds((const void *)gemm_nt_fast_kernel<T, BN, TAG, BM>, F_SMEM));
+    const int pad_lds = TAG == 1 ? (int)tune().gemm_pad_lds : 0;
+    GPX_TRY(set_max_lds((const void *)gemm_nt_fast_kernel<T, BN, TAG, BM, ABL>, TAG == 1 ? 160 * 1024 : F_SMEM));
     GemmMap fm{};
     if (map) {
         fm = *map;
@@ -869,7 +911,6 @@ static int launch_gemm_nt_fast(int64_t M, int64_t N, int64_t K, const void *A, i
     }
     {
         fm.stamps = g_gemm_stamps;
-        fm.ablate = (int)tune().gemm_ablate;      // timing-only ablations: wrong results on purpose
     }
     const int64_t ablocks = (cdiv(np, 8) * 8 * (1024 / BM)) << fm.csh;
     if (dblocks) fm.dbegin = (int)ablocks;
@@ -877,7 +918,7 @@ static int launch_gemm_nt_fast(int64_t M, int64_t N, int64_t K, const void *A, i
     if (BM == 128 && fm.exact) blocks = cdiv(fm.eT, (int64_t)8 << fm.ecl) * ((int64_t)8 << fm.ecl);
     ProfScope prof(TAG == 1 ? (BN == 64 ? PC_GEMM_N64 : PC_GEMM) : (BN == 128 ? PC_GEMM_PANEL : PC_GEMM_SKINNY),
                    (work >= 0 ? work : 2.0 * (double)K * updated_elements(M, N, tri, row0, col0)) * nbatch * nbatch2, st);
-    hipLaunchKernelGGL((gemm_nt_fast_kernel<T, BN, TAG, BM>), dim3((unsigned)blocks, (unsigned)nbatch, (unsigned)nbatch2), dim3(BM * 2), F_SMEM, st, M, N, K,
+    hipLaunchKernelGGL((gemm_nt_fast_kernel<T, BN, TAG, BM, ABL>), dim3((unsigned)blocks, (unsigned)nbatch, (unsigned)nbatch2), dim3(BM * 2), F_SMEM + pad_lds, st, M, N, K,
                        (const T *)A, lda, (const T *)B, ldb, (T *)C, ldc, (T)alpha, tri, row0, col0, fm, beta0);
     GPX_LAUNCH_CHECK();
     return GPX_OK;
@@ -999,7 +1040,7 @@ int syrk_bc(int dtype, int64_t n, int64_t row_begin, void *Cloc, int64_t ldc, in
             np += cnt;
         }
         fm.np = (int)np;
-        fm.stamps = nullptr; fm.ablate = 0;
+        fm.stamps = nullptr;
         fm.abort_flag = abort_flag; fm.sflag = bt ? 1 : 0;
         fm.exact = 0; fm.ecs = 0;
         bool bn64 = false;
@@ -1066,6 +1107,13 @@ int syrk_bc(int dtype, int64_t n, int64_t row_begin, void *Cloc, int64_t ldc, in
                                                           row_begin, cl0 + (int64_t)rank * nb, st, &fm, work, 0, 0, bt);
         }
         if (fast_bm() == 128) {
+            if (dtype == GPX_F64 && tune().gemm_ablate) {
+#define GPX_ABL_CASE(V)                                                                                                \
+    case V: return launch_gemm_nt_fast<double, 128, 1, 128, V>(M, Ncols, kb, A, ldp, Pb, ldp, C, ldc, -1.0, GPX_LOWER, \
+                                                               row_begin, cl0 + (int64_t)rank * nb, st, &fm, work, 0, 0, bt)
+                switch ((int)tune().gemm_ablate) { GPX_ABL_CASE(1); GPX_ABL_CASE(2); GPX_ABL_CASE(4); GPX_ABL_CASE(7); GPX_ABL_CASE(8); GPX_ABL_CASE(15); default: break; }
+#undef GPX_ABL_CASE
+            }
             if (dtype == GPX_F64)
                 return launch_gemm_nt_fast<double, 128, 1, 128>(M, Ncols, kb, A, ldp, Pb, ldp, C, ldc, -1.0, GPX_LOWER,
                                                                 row_begin, cl0 + (int64_t)rank * nb, st, &fm, work, 0, 0, bt);

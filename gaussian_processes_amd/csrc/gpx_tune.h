@@ -25,6 +25,7 @@ namespace gpx {
     X(gemm_atomic_c, "GPX_GEMM_ATOMIC_C", 1)                                                                           \
     X(gemm_ablate, "GPX_GEMM_ABLATE", 0)                                                                               \
     X(gemm_bm, "GPX_GEMM_BM", 128)                                                                                     \
+    X(gemm_pad_lds, "GPX_GEMM_PAD_LDS", 0)                                                                             \
     X(gemm_bn64_tiles, "GPX_GEMM_BN64_TILES", 256)                                                                     \
     X(gemm_exact, "GPX_GEMM_EXACT", 1)                                                                                 \
     X(gemm_fine_tiles, "GPX_GEMM_FINE_TILES", 16384)                                                                   \
