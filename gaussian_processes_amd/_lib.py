@@ -114,6 +114,7 @@ _SIGNATURES = {
     "gpx_gp_dlh_d2lh": (c_int, [c_void_p, c_double_p, c_double_p, c_double_p]),
     "gpx_gp_dm_dtheta": (c_int, [c_void_p, c_double_p, c_int64, c_double_p]),
     "gpx_gp_fit_batch": (c_int, [c_void_p, c_double_p, c_int64, c_double_p, c_int_p]),
+    "gpx_gp_fit_batch_grad": (c_int, [c_void_p, c_double_p, c_int64, c_double_p, c_double_p, c_double_p, c_int_p]),
     "gpx_gp_save": (c_int, [c_void_p, c_char_p]),
     "gpx_gp_load": (c_int, [POINTER(c_void_p), c_char_p]),
     "gpx_gp_describe": (c_int, [c_void_p, c_int_p, c_int_p, POINTER(c_int64), c_int_p, c_double_p, c_double_p]),

@@ -451,6 +451,7 @@ __device__ __forceinline__ int f_swz(int r) { return (0x64753120u >> (4 * ((r >>
 //    columns map to global block columns P apart.
 //  * enumeration: 1024 x 1024 patches, column-major staircase -- patch column pc
 //    holds patch rows [b + a * pc, PBR); R = PBR - b; np patches in total.
+constexpr int G_MAX_BANDS = 192;
 struct GemmMap {
     int64_t boff, cbase, nb, pm1nb, brows;
     int np, a, b, R;
@@ -490,7 +491,9 @@ struct GemmMap {
     // tile columns per block column, epm1t = (P - 1) * etpb); the triangle is tested in global columns
     int etpb, epm1t;
     int ecs;           // 1: tile columns are 64 wide (BN = 64; etpb, epm1t, eTC and j count 64-column units, eD / rows stay in 128s)
-    int epre[66];
+    // up to G_MAX_BANDS bands of 1024 rows: trailing updates of up to 196,608 rows, beyond what one GPU's HBM holds in fp64
+    // (round 6: 64 bands until then, so that above N = 65536 the first updates fell back to the patch map)
+    int epre[G_MAX_BANDS + 2];
 };
 static unsigned long long *g_gemm_stamps = nullptr;
 
@@ -1048,7 +1051,7 @@ int syrk_bc(int dtype, int64_t n, int64_t row_begin, void *Cloc, int64_t ldc, in
             // single rank, triangle aligned to the 128 x 128 tiles: enumerate exactly the tiles that exist
             const int64_t exact_env = tune().gemm_exact;
             const int64_t off = row_begin - G0;                       // row origin minus column origin (global)
-            if (exact_env && fast_bm() == 128 && off % 128 == 0 && cdiv(M, 1024) <= 64 && cl0 % nb == 0) {
+            if (exact_env && fast_bm() == 128 && off % 128 == 0 && cdiv(M, 1024) <= G_MAX_BANDS && cl0 % nb == 0) {
                 // Short updates take 128 x 64 tiles: twice the tiles at little more than half the time each, so the
                 // last, partly filled round of workgroups costs half as much and the 2 - 5 rounds of an n <= 8192 step
                 // lose less to it (full products of these shapes, K = 256: 7680 x 3840 46 -> 55 TF/s, 5632 x 2816

@@ -225,7 +225,7 @@ int gpx_gp_destroy(gpx_gp_t *g)
     stream_epoch_bump();                                       // (StreamTurn: a later stream at this one's address is a different stream)
     if (g->st_ops) { (void)hipStreamSynchronize(g->st_ops); (void)hipStreamDestroy(g->st_ops); }
     if (g->ev_ops) (void)hipEventDestroy(g->ev_ops);
-    void *bufs[] = {g->x, g->y, g->A, g->alpha, g->t0, g->t1, g->scal, g->bw, g->ops.buf};
+    void *bufs[] = {g->x, g->y, g->A, g->alpha, g->t0, g->t1, g->scal, g->bw, g->ops.buf, g->gw, g->bops.buf};
     for (void *b : bufs) if (b) (void)hipFree(b);
     for (int i = 0; i < 6; ++i) if (g->ev[i]) (void)hipEventDestroy(g->ev[i]);
     if (g->st) (void)hipStreamDestroy(g->st);
@@ -581,6 +581,34 @@ int gpx_gp_get_inv_Kxx(gpx_gp_t *g, double *out, int64_t ld)
     return download_f64(g->dtype, out, ld, C.p, lda, n, n, 0, g->st);
 }
 
+// d log_lh / d(kernel params..., s) from a factor L (n x n, lower, in HBM) and alpha = K^-1 y: X = L^-T by the blocked
+// right-looking TRSM, W = K^-1 = X X^T (lower triangle, triangular k-loop) on the MFMA kernel, then ONE fused pass
+// reduces (alpha alpha^T - W) against the kernel derivatives evaluated on the fly.  X, W: n x lda scratch; part:
+// 1024 * 4 + 8 doubles; ops: the block operators of THIS factor (completed here).  Synchronises `g->st`.
+static int grad_from_factor(gpx_gp *g, const void *L, int64_t lda, const void *alpha, const double *params, double s_noise,
+                            void *X, void *W, double *part, TrsvOps *ops, double *out)
+{
+    const size_t es = esize(g->dtype);
+    const int64_t n = g->n;
+    dim3 grid((unsigned)cdiv(lda, 256), (unsigned)std::min<int64_t>(n, 32768)), block(256);
+    if (g->dtype == GPX_F64) hipLaunchKernelGGL((eye_kernel<double>), grid, block, 0, g->st, (double *)X, n, lda);
+    else hipLaunchKernelGGL((eye_kernel<float>), grid, block, 0, g->st, (float *)X, n, lda);
+    GPX_LAUNCH_CHECK();
+    GPX_HIP(hipMemsetAsync(W, 0, (size_t)n * lda * es, g->st));
+    GPX_TRY(trsm_right_lt(g->dtype, L, n, lda, X, n, lda, g->st, 1, ops));
+    GPX_TRY(gemm_nt(g->dtype, n, n, n, X, lda, X, lda, W, lda, 1.0, GPX_LOWER, 0, 0, g->st, 0, 1));
+    double *aa = part + 1024 * 4;
+    GPX_TRY(dot(g->dtype, alpha, alpha, n, aa, g->st));
+    double p4[4];
+    GPX_TRY(dloglh_reduce(g->dtype, g->kernel, g->x, n, g->d, params, alpha, W, lda, part, p4, g->st));
+    double ata = 0.0;
+    GPX_HIP(hipMemcpyAsync(&ata, aa, sizeof(double), hipMemcpyDeviceToHost, g->st));
+    GPX_HIP(hipStreamSynchronize(g->st));
+    for (int i = 0; i < g->nparams; ++i) out[i] = 0.5 * p4[i];
+    out[g->nparams] = s_noise * (ata - p4[3]);         // dK/ds = 2 s I  (gp_c.pyx:46)
+    return GPX_OK;
+}
+
 // Gradient of the log marginal likelihood w.r.t. (kernel params..., s), RW06 eq. 5.9
 // (gp/gp.py:398-433 + gp_c.pyx:34-49): K^-1 is formed on the device (X = L^-T by the blocked
 // right-looking TRSM, W = X X^T lower triangle on the MFMA kernel), then ONE fused pass
@@ -602,28 +630,11 @@ int gpx_gp_dloglh_dtheta(gpx_gp_t *g, double *out)
         for (int i = 0; i <= g->nparams; ++i) out[i] = NAN;
         return GPX_OK;
     }
-    DevBuf X, W, part, aa;
+    DevBuf X, W, part;
     GPX_TRY(X.alloc((size_t)n * lda * es));
     GPX_TRY(W.alloc((size_t)n * lda * es));
-    GPX_TRY(part.alloc((size_t)1024 * 4 * sizeof(double)));
-    GPX_TRY(aa.alloc(sizeof(double)));
-    dim3 grid((unsigned)cdiv(lda, 256), (unsigned)std::min<int64_t>(n, 32768)), block(256);
-    if (g->dtype == GPX_F64) hipLaunchKernelGGL((eye_kernel<double>), grid, block, 0, g->st, (double *)X.p, n, lda);
-    else hipLaunchKernelGGL((eye_kernel<float>), grid, block, 0, g->st, (float *)X.p, n, lda);
-    GPX_LAUNCH_CHECK();
-    GPX_HIP(hipMemsetAsync(W.p, 0, (size_t)n * lda * es, g->st));
-    GPX_TRY(trsm_right_lt(g->dtype, g->A, n, lda, X.p, n, lda, g->st, 1, &g->ops));
-    GPX_TRY(gemm_nt(g->dtype, n, n, n, X.p, lda, X.p, lda, W.p, lda, 1.0, GPX_LOWER, 0, 0, g->st, 0, 1));
-    double p4[4];
-    GPX_TRY(dloglh_reduce(g->dtype, g->kernel, g->x, n, g->d, g->params, g->alpha, W.p, lda, (double *)part.p,
-                          p4, g->st));
-    GPX_TRY(dot(g->dtype, g->alpha, g->alpha, n, (double *)aa.p, g->st));
-    double ata = 0.0;
-    GPX_HIP(hipMemcpyAsync(&ata, aa.p, sizeof(double), hipMemcpyDeviceToHost, g->st));
-    GPX_HIP(hipStreamSynchronize(g->st));
-    for (int i = 0; i < g->nparams; ++i) out[i] = 0.5 * p4[i];
-    out[g->nparams] = g->s * (ata - p4[3]);            // dK/ds = 2 s I  (gp_c.pyx:46)
-    return GPX_OK;
+    GPX_TRY(part.alloc((size_t)1024 * 4 * sizeof(double) + 64));
+    return grad_from_factor(g, g->A, lda, g->alpha, g->params, g->s, X.p, W.p, (double *)part.p, &g->ops, out);
 }
 
 // Batched ML-II step (BASELINE config 5; the reference's inner step "set params -> read log_lh",
@@ -632,12 +643,22 @@ int gpx_gp_dloglh_dtheta(gpx_gp_t *g, double *out)
 // of the solves covers all of them (grid dimension y / x = matrix index), so the chain of small
 // dependent launches that bounds ONE n = 8192 factorisation is paid once per batch and the chip stays
 // filled by the trailing updates of all matrices.  Chunked when B matrices do not fit in free HBM.
-int gpx_gp_fit_batch(gpx_gp_t *g, const double *thetas, int64_t B, double *log_lh, int *info)
+static int fit_batch_impl(gpx_gp_t *g, const double *thetas, int64_t B, double *log_lh, double *dloglh, double *logdet_yta,
+                          int *info)
 {
-    GP_ENTER(g);
     GPX_ARG(g->have_data, "set_data must be called before fit_batch");
     GPX_ARG(B >= 0 && (B == 0 || (thetas && log_lh)), "bad arguments");
     if (B == 0) return GPX_OK;
+    if (dloglh) {
+        if (g->kernel == GPX_KERNEL_PERIODIC && g->d != 1) { set_error("periodic gradient needs d == 1"); return GPX_ERR_UNSUPPORTED; }
+        // gradient scratch BEFORE the chunk size is taken from what is free: X = L^-T and W = K^-1 of ONE matrix at a time
+        const size_t gneed = 2 * (size_t)g->n * g->lda * esize(g->dtype) + (size_t)(1024 * 4 + 8) * sizeof(double);
+        if (g->gw_bytes < gneed) {
+            if (g->gw) { GPX_HIP(hipStreamSynchronize(g->st)); (void)hipFree(g->gw); g->gw = nullptr; g->gw_bytes = 0; }
+            GPX_HIP(hipMalloc(&g->gw, gneed));
+            g->gw_bytes = gneed;
+        }
+    }
     if (!g->x_finite || !g->y_finite) { set_error("%s (%s)", NONFINITE_MSG, g->x_finite ? "y" : "x"); return GPX_ERR_ARG; }
     const int64_t n = g->n, lda = g->lda;
     const size_t es = esize(g->dtype);
@@ -715,9 +736,47 @@ int gpx_gp_fit_batch(gpx_gp_t *g, const double *thetas, int64_t B, double *log_l
             else v = -0.5 * yta - 0.5 * logdet - 0.5 * (double)n * log(2 * M_PI);
             log_lh[b0 + i] = v;
             if (info) info[b0 + i] = valid[i] ? hi[i] : -1;
+            if (logdet_yta) { logdet_yta[2 * (b0 + i)] = valid[i] && hi[i] == 0 ? logdet : NAN; logdet_yta[2 * (b0 + i) + 1] = valid[i] && hi[i] == 0 ? yta : NAN; }
+        }
+        if (dloglh) {
+            // gp/gp.py:398-433 per row, on the row's factor and alpha where the lock-step pass left them.  The reference
+            // computes the gradient whenever the factorisation succeeds (no logdet < MIN test there); NaN for a row that
+            // is not positive definite (gp/gp.py:424-428) or that the reference would have refused (ValueError).
+            const size_t nl = (size_t)n * lda * es;
+            char *Xs = (char *)g->gw, *Ws = Xs + nl;
+            double *part = (double *)(Ws + nl);
+            for (int i = 0; i < cnt; ++i) {
+                double *o = dloglh + (b0 + i) * (np + 1);
+                if (!valid[i] || hi[i] != 0) { for (int k = 0; k <= np; ++k) o[k] = NAN; continue; }
+                const double *th = thetas + (b0 + i) * (np + 1);
+                g->bops.invalidate();
+                GPX_TRY(grad_from_factor(g, (char *)Ab.p + (size_t)i * per, lda, (char *)al.p + (size_t)i * vec, th, th[np],
+                                         Xs, Ws, part, &g->bops, o));
+            }
         }
     }
     return GPX_OK;
+}
+
+int gpx_gp_fit_batch(gpx_gp_t *g, const double *thetas, int64_t B, double *log_lh, int *info)
+{
+    GP_ENTER(g);
+    return fit_batch_impl(g, thetas, B, log_lh, nullptr, nullptr, info);
+}
+
+// The batched ML-II step WITH its gradient (what turns config 5 from grid / restart evaluation into
+// optimisation; gp/gp.py:398-433, gp_c.pyx:34-49 for every row of the table): the lock-step factorisation of
+// gpx_gp_fit_batch, then per row K^-1 from the row's factor and the fused trace / quadratic-form pass of
+// gpx_gp_dloglh_dtheta.  dloglh: HOST (B, n_params + 1) row-major, order (kernel params..., s).  logdet_yta (may be
+// NULL): HOST (B, 2) = (log det K, y^T K^-1 y) per row, NaN where the factorisation failed -- from them a caller forms
+// the UNCLAMPED log marginal likelihood where the reference's logdet < MIN clamp (gp_c.pyx:22-29) returns -inf.
+int gpx_gp_fit_batch_grad(gpx_gp_t *g, const double *thetas, int64_t B, double *log_lh, double *dloglh, double *logdet_yta,
+                          int *info)
+{
+    GP_ENTER(g);
+    GPX_ARG(B == 0 || dloglh, "dloglh is NULL");
+    GP_NEED_FINITE_Y(g);
+    return fit_batch_impl(g, thetas, B, log_lh, dloglh, logdet_yta, info);
 }
 
 int gpx_gp_last_timing(gpx_gp_t *g, float *ms5)

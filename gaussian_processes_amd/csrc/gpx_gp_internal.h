@@ -19,6 +19,10 @@ struct gpx_gp {
     void *bw; size_t bw_bytes; int64_t bw_cap;
     // block operators of the triangular solves (built once per factor, reused by every later solve)
     gpx::TrsvOps ops;
+    // fit_batch_grad: X = L^-T and W = K^-1 of one matrix at a time + the reduction's partial sums (grow-only), and
+    // the block operators of the row being differentiated
+    void *gw; size_t gw_bytes;
+    gpx::TrsvOps bops;
     hipStream_t st_ops;   // lazily created: where gpx_gp_fit builds `ops` while the factorisation is still running
     hipEvent_t ev_ops;
 };

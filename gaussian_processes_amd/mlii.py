@@ -17,7 +17,7 @@ import numpy as np
 
 from . import _lib
 
-__all__ = ["log_lh_batch", "best_restart", "BatchEvaluator"]
+__all__ = ["log_lh_batch", "best_restart", "BatchEvaluator", "optimize"]
 
 _KERNEL_IDS = {"gaussian": (_lib.KERNEL_GAUSSIAN, 2), "periodic": (_lib.KERNEL_PERIODIC, 3)}
 
@@ -40,6 +40,7 @@ class BatchEvaluator(object):
             _lib.check(self.lib.gpx_set_device(int(device)))
         dt = _lib.F64 if dtype in ("float64", "f64") else _lib.F32
         self.h = ctypes.c_void_p()
+        self.n = n
         _lib.check(self.lib.gpx_gp_create(ctypes.byref(self.h), dt, self.kid, n, d))
         try:
             _lib.check(self.lib.gpx_gp_set_data(self.h, _lib.dptr(x), _lib.dptr(y)))
@@ -55,6 +56,28 @@ class BatchEvaluator(object):
         if th.shape[0]:
             _lib.check(self.lib.gpx_gp_fit_batch(self.h, _lib.dptr(th), th.shape[0], _lib.dptr(res), None))
         return res
+
+    def value_and_grad(self, thetas, clamp=True):
+        """(log_lh, dloglh_dtheta) of every row: one ``gpx_gp_fit_batch_grad`` call -- the lock-step factorisation,
+        then per row the reference's ``dloglh_dtheta`` (gp/gp.py:398-433, gp_c.pyx:34-49) from the row's own factor.
+        ``clamp=False`` returns the log marginal likelihood WITHOUT the reference's ``logdet < MIN -> -inf`` clamp
+        (gp_c.pyx:22-29) wherever the matrix is positive definite: -1/2 y^T a - 1/2 logdet - n/2 log 2 pi from the
+        row's (logdet, y^T a) -- what an optimiser needs at n beyond a few thousand, where the clamped value is
+        -inf on most of the parameter space (an extension; the gradient is the reference's either way)."""
+        th = np.ascontiguousarray(np.atleast_2d(np.asarray(thetas, dtype=np.float64)))
+        if th.shape[1] != self.nkp + 1:
+            raise ValueError("thetas must have %d columns (kernel params + s)" % (self.nkp + 1))
+        B = th.shape[0]
+        val = np.empty(B, dtype=np.float64)
+        grad = np.empty((B, self.nkp + 1), dtype=np.float64)
+        ldy = np.empty((B, 2), dtype=np.float64)
+        if B:
+            _lib.check(self.lib.gpx_gp_fit_batch_grad(self.h, _lib.dptr(th), B, _lib.dptr(val), _lib.dptr(grad), _lib.dptr(ldy), None))
+            if not clamp:
+                ok = np.isfinite(ldy).all(axis=1)
+                raw = -0.5 * ldy[:, 1] - 0.5 * ldy[:, 0] - 0.5 * self.n * np.log(2 * np.pi)
+                val = np.where(ok, raw, val)
+        return val, grad
 
     def close(self):
         if self.h:
@@ -184,3 +207,144 @@ def best_restart(x, y, thetas, **kw):
     ok = np.where(np.isnan(llh), -np.inf, llh)
     i = int(np.argmax(ok))
     return i, np.asarray(thetas)[i], llh[i]
+
+
+class _LockStep(object):
+    """Rendezvous of R optimiser threads with ONE serving thread: every optimiser thread hands in its current point and
+    sleeps; when all optimisers that are still running have done so, the serving thread (the caller of `optimize`: the
+    only thread that ever touches the GPU handle, so the library's per-thread streams and scratch exist once) evaluates
+    the whole table in a single batched call and wakes them.  An optimiser that has finished leaves; the batch shrinks."""
+
+    def __init__(self, evaluate, count):
+        import threading
+        self.evaluate, self.active = evaluate, count
+        self.cv = threading.Condition()
+        self.pending, self.results, self.generation, self.calls, self.error = {}, {}, 0, 0, None
+
+    def request(self, i, theta):
+        with self.cv:
+            gen = self.generation
+            self.pending[i] = np.array(theta, dtype=np.float64)
+            self.cv.notify_all()
+            while self.generation == gen and self.error is None:
+                self.cv.wait()
+            if self.error is not None:
+                raise RuntimeError("batched evaluation failed: %r" % (self.error,))
+            return self.results[i]
+
+    def leave(self):
+        with self.cv:
+            self.active -= 1
+            self.cv.notify_all()
+
+    def serve(self):
+        """Run on the serving thread until every optimiser has left."""
+        while True:
+            with self.cv:
+                while self.active > 0 and len(self.pending) < self.active:
+                    self.cv.wait()
+                if self.active <= 0:
+                    return
+                idx = sorted(self.pending)
+                table = np.array([self.pending[i] for i in idx])
+            try:
+                vals, grads = self.evaluate(table)               # outside the lock: the optimisers are all asleep
+                res = {i: (vals[k], grads[k]) for k, i in enumerate(idx)}
+                err = None
+            except BaseException as exc:                         # noqa: BLE001 -- every sleeper must wake and see it
+                res, err = {}, exc
+            with self.cv:
+                self.results, self.pending, self.error = res, {}, err
+                self.generation += 1
+                self.calls += 1
+                self.cv.notify_all()
+            if err is not None:
+                raise err
+
+
+def optimize(x, y, thetas0, kernel="gaussian", dtype="float64", device=None, bounds=None, maxiter=50, clamp=False,
+             options=None, evaluator=None):
+    """ML-II by L-BFGS-B from every row of `thetas0` at once, all restarts in LOCK-STEP (what the reference's
+    ``fit_MLII`` did one restart at a time before it was removed, CHANGELOG.md:19; its objective and gradient are
+    ``GP.log_lh`` / ``GP.dloglh_dtheta``, gp/gp.py:337-367, 398-433).
+
+    One optimiser (scipy's L-BFGS-B, bounded) per restart, each on its own host thread; a function evaluation does
+    not run by itself: it joins a rendezvous, and when every restart that is still running has asked, ONE
+    ``gpx_gp_fit_batch_grad`` call (made by the calling thread) evaluates value and gradient of all of them -- the
+    lock-step factorisation the value-only sweep uses, plus K^-1 per row.  The optimisers work in log(theta) (every
+    parameter is positive: gp/kernels/gaussian.py:62-69, gp/gp.py:192-193), minimising -log_lh with gradient
+    -theta * dloglh/dtheta.
+
+    thetas0: (R, n_params + 1) rows (kernel params..., s).  bounds: (n_params + 1, 2) on theta (default: each start value
+    / 100 ... x 100 over all restarts, never below 1e-6).  clamp=False (default) follows the unclamped log marginal
+    likelihood (`BatchEvaluator.value_and_grad`); clamp=True keeps the reference's -inf plateau, on which an
+    optimiser cannot move.  `evaluator`: an object with ``value_and_grad(thetas, clamp=...)`` to use instead of a new
+    `BatchEvaluator` (tests; a caller that keeps its data set resident).  Returns a dict: theta (R, n_params + 1),
+    log_lh (R,), log_lh0 (R,), nit, nfev (R,), batched_calls, best (index of the largest final log_lh), messages."""
+    import threading
+    from scipy.optimize import minimize
+    th0 = np.atleast_2d(np.asarray(thetas0, dtype=np.float64))
+    R = th0.shape[0]
+    if bounds is None:
+        lo = np.maximum(th0.min(0) / 100.0, 1e-6)
+        hi = th0.max(0) * 100.0
+    else:
+        bounds = np.asarray(bounds, dtype=np.float64)
+        lo, hi = bounds[:, 0], bounds[:, 1]
+    lb = list(zip(np.log(lo), np.log(hi)))
+    big = 1e300
+    ev = evaluator if evaluator is not None else BatchEvaluator(x, y, kernel=kernel, dtype=dtype, device=device)
+    try:
+        v0, _ = ev.value_and_grad(th0, clamp=clamp)
+        ls = _LockStep(lambda table: ev.value_and_grad(table, clamp=clamp), R)
+        out = [None] * R
+
+        def run(i):
+            try:
+                last = [None, None]                               # the last finite point this optimiser saw, and its value
+
+                def f(u):
+                    th = np.exp(u)
+                    val, grad = ls.request(i, th)
+                    if not np.isfinite(val) or not np.isfinite(grad).all():
+                        # not positive definite (or clamped): a wall.  The line search needs something it can
+                        # interpolate: a value well above the last finite one, rising with the distance from it
+                        if last[0] is None:
+                            return big, np.zeros_like(u)
+                        du = u - last[0]
+                        pen = 1e3 * (1.0 + abs(last[1]))
+                        return last[1] + pen * (1.0 + float(du @ du)), 2.0 * pen * du
+                    last[0], last[1] = np.array(u), -float(val)
+                    return -val, -(grad * th)
+                opts = {"maxiter": int(maxiter)}
+                opts.update(options or {})
+                out[i] = minimize(f, np.log(np.clip(th0[i], lo, hi)), jac=True, method="L-BFGS-B", bounds=lb, options=opts)
+            except BaseException as exc:      # noqa: BLE001 -- reported below; the other restarts go on
+                out[i] = exc
+            finally:
+                ls.leave()
+
+        threads = [threading.Thread(target=run, args=(i,), daemon=True) for i in range(R)]
+        for t in threads:
+            t.start()
+        try:
+            ls.serve()
+        finally:
+            for t in threads:
+                t.join()
+        for o in out:
+            if isinstance(o, BaseException):
+                raise o
+        theta = np.exp(np.array([o.x for o in out]))
+        final, _ = ev.value_and_grad(theta, clamp=clamp)
+    finally:
+        if evaluator is None:
+            ev.close()
+    # a restart never ends below where it started (a start on the wall stays there)
+    keep = ~(final >= v0) | ~np.isfinite(v0)
+    theta[keep] = th0[keep]
+    final = np.where(keep, v0, final)
+    ok = np.where(np.isfinite(final), final, -np.inf)
+    return {"theta": theta, "log_lh": final, "log_lh0": v0, "nit": np.array([o.nit for o in out]),
+            "nfev": np.array([o.nfev for o in out]), "batched_calls": ls.calls + 2, "best": int(np.argmax(ok)),
+            "messages": [str(o.message) for o in out]}

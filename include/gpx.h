@@ -378,6 +378,16 @@ int gpx_gp_dm_dtheta(gpx_gp_t *gp, const double *xo, int64_t m, double *out);
  * launch covers all of them); chunked by free memory (cap: environment GPX_BATCH_MAX).
  * Leaves the handle's own fitted state untouched. */
 int gpx_gp_fit_batch(gpx_gp_t *gp, const double *thetas, int64_t B, double *log_lh, int *info);
+/* The same step WITH the gradient of every row (gp/gp.py:398-433 `dloglh_dtheta`, gp_c.pyx:34-49 -- the quantity the
+ * reference's removed `fit_MLII` optimised, CHANGELOG.md:19): the lock-step factorisation above, then per row
+ * K^-1 = L^-T L^-1 from the row's own factor and the fused trace / quadratic-form pass of gpx_gp_dloglh_dtheta.
+ * dloglh: HOST (B, n_params + 1) row-major, order (kernel params..., s); all NaN for a row that is not positive
+ * definite (gp/gp.py:424-428) or has invalid parameters.  logdet_yta (may be NULL): HOST (B, 2) = (log det K,
+ * y^T K^-1 y), NaN where the factorisation failed: from them a caller forms the log marginal likelihood WITHOUT the
+ * reference's logdet < MIN clamp (gp_c.pyx:22-29), which returns -inf for any well-conditioned n beyond a few
+ * thousand and leaves an optimiser nothing to follow (an extension; `log_lh` itself keeps the clamp). */
+int gpx_gp_fit_batch_grad(gpx_gp_t *gp, const double *thetas, int64_t B, double *log_lh, double *dloglh,
+                          double *logdet_yta, int *info);
 /* Checkpoint of a fitted handle (the reference persists by pickling its memoised host arrays,
  * gp/gp.py:78-92; a 32 GiB factor cannot go that way).  File: header (dtype, kernel, n, d, params, s,
  * logdet, y^T alpha, info), x, y, alpha as float64, then the LOWER trapezoid of L in row blocks

@@ -8,6 +8,7 @@ import sys
 import threading
 import time
 
+import numpy as np
 import pytest
 
 from gaussian_processes_amd import _lib, multi_gpu
@@ -50,6 +51,28 @@ def test_mg_panel_broadcast_plan_alignment_and_coverage(n, nb, world):
             assert done == rows, (j, plan)                          # coverage, rider row included
             if len(plan) > 1:
                 assert plan[0][1] >= min(rows, max(2 * nb, 1024))   # the next panel's B-operand rows travel first
+
+
+@pytest.mark.parametrize("nb", [512, 1024])
+def test_mg_panel_broadcast_plan_at_n262144_world8(nb):
+    """The same walk at N = 262144, P = 8 (round 6): north_star's "N where K + factor exceed one GPU's HBM" -- 550 GB in
+    fp64, 69 GB a rank.  A panel is up to 262145 x 1024 elements = 2.1 GB: every count and offset is checked as a 64-bit
+    quantity (a 32-bit BYTE offset would wrap in the first panel's second chunk)."""
+    n, world = 262144, 8
+    nblk = -(-n // nb)
+    for chunks in (4, 16):
+        for j in list(range(0, nblk, 7)) + [nblk - 2, nblk - 1]:
+            rows = n + 1 - j * nb
+            plan = _plan(n, nb, world, chunks, j)
+            done = 0
+            for (b, e, count, piece, last, sag) in plan:
+                assert b == done and e > b and b % 128 == 0
+                assert count == (e - b) * nb and count * 8 < 2 ** 40
+                assert piece % 32 == 0 and piece * (world - 1) + last == count and last >= piece
+                done = e
+            assert done == rows, (j, plan)
+    j0 = _plan(n, nb, world, 4, 0)
+    assert sum(c[2] for c in j0) * 8 >= 2 ** 30      # a panel of 1 - 2 GB: the later chunks' byte offsets do not fit 30 bits
 
 
 def test_mg_plan_rejects_bad_arguments():
@@ -106,3 +129,52 @@ def test_hazard_and_leaf_probes_still_build_for_gfx950(tmp_path):
         r = subprocess.run([hipcc, "--offload-arch=gfx950", "-Wno-unused-value", "-Wno-unused-result", "-c", src, "-o", out] + extra,
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_mlii_optimize_lock_step_rendezvous_with_a_host_evaluator():
+    """mlii.optimize's rendezvous (round 6) without a GPU: R L-BFGS-B optimisers, each on its own thread, are served by
+    ONE batched evaluation per step made on the calling thread; optimisers that finish early leave and the batch
+    shrinks; a failing evaluation reaches the caller instead of hanging the threads.  The evaluator is a host stand-in
+    with a known maximum; the walls (non-finite rows) behave as the -inf rows of a real table do."""
+    import threading
+    from gaussian_processes_amd import mlii
+    centre = np.array([1.3, 2.0, 0.7])
+
+    class Fake(object):
+        def __init__(self):
+            self.sizes, self.threads = [], set()
+
+        def value_and_grad(self, thetas, clamp=True):
+            t = np.atleast_2d(thetas)
+            self.sizes.append(t.shape[0])
+            self.threads.add(threading.get_ident())
+            u = np.log(t) - np.log(centre)
+            val = -(u ** 2).sum(1) * np.array([1.0, 3.0, 0.5]).sum()
+            grad = -2.0 * u / t * np.array([1.0, 3.0, 0.5]).sum()
+            wall = t[:, 2] > 50.0                                  # a region that "is not positive definite"
+            val = np.where(wall, -np.inf, val)
+            grad[wall] = np.nan
+            return val, grad
+
+    rs = np.random.RandomState(3)
+    th0 = np.exp(rs.uniform(-1.5, 1.5, (7, 3)))
+    th0[5, 2] = 80.0                                               # starts on the wall: stays where it is
+    ev = Fake()
+    res = mlii.optimize(None, None, th0, evaluator=ev, maxiter=40)
+    assert ev.threads == {threading.get_ident()}                   # only the caller ever evaluates
+    assert ev.sizes[0] == 7 and ev.sizes[-1] == 7 and max(ev.sizes) == 7 and min(ev.sizes) >= 1
+    assert sorted(set(ev.sizes[1:-1]), reverse=True)[0] <= 7 and len(ev.sizes) == res["batched_calls"]
+    fin = np.isfinite(res["log_lh0"])
+    assert (res["log_lh"][fin] >= res["log_lh0"][fin]).all()
+    np.testing.assert_allclose(res["theta"][fin], np.tile(centre, (fin.sum(), 1)), rtol=1e-4)
+    np.testing.assert_array_equal(res["theta"][5], th0[5])
+    assert res["best"] in np.nonzero(fin)[0]
+
+    class Broken(Fake):
+        def value_and_grad(self, thetas, clamp=True):
+            if len(self.sizes) >= 2:
+                raise MemoryError("out of HBM (test)")
+            return Fake.value_and_grad(self, thetas, clamp)
+
+    with pytest.raises((MemoryError, RuntimeError)):
+        mlii.optimize(None, None, th0[:3], evaluator=Broken(), maxiter=10)
