@@ -106,13 +106,13 @@ __device__ __forceinline__ Chunk16 load_chunk(const T *__restrict__ base, int64_
 // `beta0`) for one wave's 64 x (16 * NTW) tile.  The 32 loads of two MFMA tile rows
 // are issued before the first use (clamped addresses keep them unconditional), so a
 // lane pays 2 memory round trips per tile instead of 64.
-template <typename T, int NTW, typename M = MF<T>, int NTJ = NTW>
+template <typename T, int NTW, typename M = MF<T>, int NTJ = NTW, int IBS = 0>
 __device__ __forceinline__ void store_wave_tile(typename M::acc_t (&acc)[64 / (M::NR == 4 ? 16 : 32)][NTJ], T *__restrict__ C,
                                                 int64_t ldc, int64_t Mr, int64_t N, int64_t r_base,
                                                 int64_t c_base, int lane, T alpha, int tri,
                                                 int64_t row0, int64_t col0, int beta0)
 {
-    constexpr int TM = M::NR == 4 ? 16 : 32, NR = M::NR, TI = 64 / TM, IB = TM == 16 ? 2 : 1;
+    constexpr int TM = M::NR == 4 ? 16 : 32, NR = M::NR, TI = 64 / TM, IB = IBS ? IBS : (TM == 16 ? 2 : 1);
     const int ccol = lane & (TM - 1);
 #pragma unroll
     for (int ib = 0; ib < TI; ib += IB) {
@@ -295,31 +295,28 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(int64_t M, int64_t N, i
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar registers
     const int wr = wave >> 1, wc = wave & 1;
 
     // global -> LDS staging map: 8 threads cover one 128-B row, 32 rows per pass
     const int s_row = tid >> 3;          // 0..31
     const int s_chk = tid & 7;           // 16-B chunk within the row
-    Chunk16 ra[4], rb[4];
+    // ONE set of four staging registers per thread: the next k-step's A rows travel under the first half of this
+    // step's MFMAs, its B rows under the second half (round 6: both at once were 32 registers beside the accumulators)
+    Chunk16 rs[4];
 
-    auto load_tiles = [&](int64_t kbase) {
+    auto load_op = [&](int op, int64_t kbase) {
         const int64_t k = kbase + (int64_t)s_chk * CH;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            ra[p] = load_chunk<T>(A, lda, bm0 + s_row + 32 * p, M, k, K);
-            rb[p] = load_chunk<T>(B, ldb, bn0 + s_row + 32 * p, N, k, K);
-        }
+        for (int p = 0; p < 4; ++p)
+            rs[p] = op == 0 ? load_chunk<T>(A, lda, bm0 + s_row + 32 * p, M, k, K)
+                            : load_chunk<T>(B, ldb, bn0 + s_row + 32 * p, N, k, K);
     };
-    auto store_tiles = [&](int buf) {
-        unsigned char *ta = smem + (size_t)buf * 2 * G_TILE_BYTES;
-        unsigned char *tb = ta + G_TILE_BYTES;
+    auto store_op = [&](int op, int buf) {
+        unsigned char *t = smem + (size_t)buf * 2 * G_TILE_BYTES + (size_t)op * G_TILE_BYTES;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int off = (s_row + 32 * p) * G_PITCH + s_chk * 16;
-            *reinterpret_cast<Chunk16 *>(ta + off) = ra[p];
-            *reinterpret_cast<Chunk16 *>(tb + off) = rb[p];
-        }
+        for (int p = 0; p < 4; ++p)
+            *reinterpret_cast<Chunk16 *>(t + (s_row + 32 * p) * G_PITCH + s_chk * 16) = rs[p];
     };
 
     acc_t acc[4][4];
@@ -331,8 +328,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(int64_t M, int64_t N, i
             for (int r = 0; r < 4; ++r) acc[i][j][r] = (T)0;
 
     const int nk = (int)((K + EPK - 1) / EPK);
-    load_tiles(0);
-    store_tiles(0);
+    load_op(0, 0); store_op(0, 0);
+    load_op(1, 0); store_op(1, 0);
     __syncthreads();
 
     // per-lane fragment address: row (l & 15) of the MFMA tile, bytes [32*q, 32*q + 32)
@@ -340,38 +337,44 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(int64_t M, int64_t N, i
 
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) load_tiles((int64_t)(kt + 1) * EPK);
+        const bool more = kt + 1 < nk;
 
         const unsigned char *ta = smem + (size_t)cur * 2 * G_TILE_BYTES;
         const unsigned char *tb = ta + G_TILE_BYTES;
-        T fa[4][SUB], fb[4][SUB];
+        // fragments in two halves of 16 bytes per row (round 6: all 32 bytes of the 8 rows at once were 64 live registers
+        // beside the 128 accumulators and the 32 staging registers -- 34 VGPRs spilled in fp64)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const unsigned char *pa = ta + (wr * 64 + i * 16) * G_PITCH + f_off;
-            const unsigned char *pb = tb + (wc * 64 + i * 16) * G_PITCH + f_off;
-            Chunk16 a0 = *reinterpret_cast<const Chunk16 *>(pa);
-            Chunk16 a1 = *reinterpret_cast<const Chunk16 *>(pa + 16);
-            Chunk16 b0 = *reinterpret_cast<const Chunk16 *>(pb);
-            Chunk16 b1 = *reinterpret_cast<const Chunk16 *>(pb + 16);
-            memcpy(&fa[i][0], &a0, 16);
-            memcpy(&fa[i][SUB / 2], &a1, 16);
-            memcpy(&fb[i][0], &b0, 16);
-            memcpy(&fb[i][SUB / 2], &b1, 16);
+        for (int hf = 0; hf < 2; ++hf) {
+            if (more) load_op(hf, (int64_t)(kt + 1) * EPK);
+            T fa[4][SUB / 2], fb[4][SUB / 2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned char *pa = ta + (wr * 64 + i * 16) * G_PITCH + f_off + hf * 16;
+                const unsigned char *pb = tb + (wc * 64 + i * 16) * G_PITCH + f_off + hf * 16;
+                Chunk16 a0 = *reinterpret_cast<const Chunk16 *>(pa);
+                Chunk16 b0 = *reinterpret_cast<const Chunk16 *>(pb);
+                memcpy(&fa[i][0], &a0, 16);
+                memcpy(&fb[i][0], &b0, 16);
+            }
+#pragma unroll
+            for (int s = 0; s < SUB / 2; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = MF<T>::mfma(fa[i][s], fb[j][s], acc[i][j]);
+            if (more) store_op(hf, cur ^ 1);         // the other buffer: nobody reads it during this k-step
+            __builtin_amdgcn_sched_barrier(0);       // keep the second half's reads behind the first half's MFMAs
         }
-#pragma unroll
-        for (int s = 0; s < SUB; ++s)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = MF<T>::mfma(fa[i][s], fb[j][s], acc[i][j]);
-
-        if (kt + 1 < nk) store_tiles(cur ^ 1);
         __syncthreads();
     }
 
     // epilogue: C += alpha * acc  (16 lanes = 16 consecutive columns = one 128-B / 64-B segment)
-    store_wave_tile<T, 4>(acc, C, ldc, M, N, bm0 + wr * 64, bn0 + wc * 64, lane, alpha, tri, row0, col0, 0);
+    // (one MFMA tile row per round trip: 16 loads in flight beside the 128 accumulators.  The lane index is taken again
+    // behind an opaque asm: the epilogue's per-lane indices were computed before the k-loop and spilled across it)
+    int lane_e = (int)(threadIdx.x & 63);
+    asm volatile("" : "+v"(lane_e));
+    store_wave_tile<T, 4, MF<T>, 4, 1>(acc, C, ldc, M, N, bm0 + wr * 64, bn0 + wc * 64, lane_e, alpha, tri, row0, col0, 0);
 }
 
 // number of C elements a launch updates (all of M x N, or those with row0+i >= col0+j)
