@@ -410,14 +410,11 @@ int launch_gemm_nt(int64_t M, int64_t N, int64_t K, const void *A, int64_t lda, 
 
 // ===========================================================================
 // Fast path: K % (128 B) == 0, 16-B aligned operands.
-//   wave tile 64 x 64 (4 x 4 MFMA tiles); block tile BM x BN with BM / 64 x 2 waves:
-//     BM = 128 (default): 128 x 128 (128 x 64 for the skinny panel products), 4 waves,
-//       2 LDS stages of 32 KiB, TWO workgroups per CU -- one's prologue, epilogue and
-//       barrier stalls fall under the other's k-loop;
-//     BM = 256 (GPX_GEMM_BM=256): 256 x 128, 8 waves, 3 stages of 48 KiB, one workgroup
-//       per CU, two k-steps in flight;
+//   wave tile 64 x 64 (4 x 4 MFMA tiles); block tile 128 x 128 (128 x 64 for the skinny panel products and
+//   short updates), 4 waves (2 x 2), 2 LDS stages of 32 KiB, TWO workgroups per CU -- one's prologue,
+//   epilogue and barrier stalls fall under the other's k-loop;
 //   operands go HBM/L2 -> LDS directly (global_load_lds_dwordx4, no VGPR staging), one
-//   raw s_barrier per k-step with a counted vmcnt;
+//   raw s_barrier per k-step;
 //   LDS rows are unpadded (the DMA writes 1 KiB = 8 rows contiguously), bank conflicts
 //   of the ds_read_b128 fragment reads are removed by an XOR swizzle applied to the
 //   per-lane GLOBAL source chunk and again on the read;
@@ -426,15 +423,17 @@ int launch_gemm_nt(int64_t M, int64_t N, int64_t K, const void *A, int64_t lda, 
 //   together on one XCD (2 per CU) are one patch and share 8 A- and 8 B-slices in that
 //   XCD's L2.
 // ===========================================================================
-template <int BN, int BM = 256> struct FGeo {
-    static constexpr int NW = BM / 32;              // waves: (BM / 64) x 2
-    static constexpr int NST = BM == 256 ? 3 : 2;   // LDS stages
-    static constexpr int ROWS = BM + BN;            // tile rows per stage: 384 / 320 / 256
-    static constexpr int STAGE = ROWS * G_ROWB;     // 49,152 / 40,960 / 32,768 B
-    static constexpr int SMEM = NST * STAGE;        // 147,456 / 122,880 / 65,536 B
-    static constexpr int PW = ROWS / (8 * NW);      // DMA pieces (1 KiB) per wave and stage: 6 / 5 / 8
+constexpr int F_BM = 128;                           // tile rows of the fast kernel (the 256 x 128 / 8-wave / 3-stage /
+                                                    // one-workgroup-per-CU form of rounds 1 - 5 was measured slower with
+                                                    // every schedule, last in profiles/r06_gemm_bm256_dropped.log, and removed)
+template <int BN> struct FGeo {
+    static constexpr int NW = F_BM / 32;            // waves: 2 x 2
+    static constexpr int NST = 2;                   // LDS stages
+    static constexpr int ROWS = F_BM + BN;          // tile rows per stage: 256 / 192
+    static constexpr int STAGE = ROWS * G_ROWB;     // 32,768 / 24,576 B
+    static constexpr int SMEM = NST * STAGE;        // 65,536 / 49,152 B
+    static constexpr int PW = ROWS / (8 * NW);      // DMA pieces (1 KiB) per wave and stage: 8 / 6
     static constexpr int NTW = BN / 32;             // 16-column MFMA tiles per wave: 4 / 2
-    static constexpr int TPP = (1024 / BM) * 8;     // tiles per 1024 x 1024 patch: 32 / 64
 };
 template <int N> struct WaitVm;
 #define GPX_WAITVM(N) template <> struct WaitVm<N> { static __device__ __forceinline__ void go() { asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); } }
@@ -458,7 +457,7 @@ constexpr int G_MAX_BANDS = 192;
 struct GemmMap {
     int64_t boff, cbase, nb, pm1nb, brows;
     int np, a, b, R;
-    // diagonal split (BM = 128, exactly aligned lower-triangular maps): blocks >= dbegin enumerate
+    // diagonal split (exactly aligned lower-triangular maps): blocks >= dbegin enumerate
     // ONLY the 36 tiles at or below the diagonal of the ndiag diagonal patches (patch column pc,
     // patch row bdiag + pc); the staircase above then starts one patch below the diagonal.  Without
     // it 28 of the 64 workgroups of every diagonal patch return at once -- and still pass, in order,
@@ -482,7 +481,7 @@ struct GemmMap {
     int64_t sA, sB, sC;
     int64_t tA, tB, tC;   // second batch dimension (blockIdx.z)
     int sflag;    // stride of abort_flag (one info word per matrix)
-    // EXACT enumeration (BM = 128, lower-triangular trailing updates whose triangle is tile aligned): the
+    // EXACT enumeration (lower-triangular trailing updates whose triangle is tile aligned): the
     // grid holds only tiles that exist -- tile (i, j) with j <= min(eTC - 1, i + eD), i < eTR.  Order: bands
     // of 8 tile rows, column-major inside a band, so that 64 consecutive tiles are an 8 x 8 patch (8 A- and
     // 8 B-slices); chunks of 2^ecl consecutive tiles go to one XCD (chunk c -> blocks with blockIdx % 8 ==
@@ -507,8 +506,8 @@ typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
 // TAG only changes the symbol name: 1 = the block-cyclic trailing update of the
 // factorisation (gpx_d_syrk_bc), so that profilers list the dominant kernel separately
 // from the panel / covariance products that share its code.
-template <typename T, int BN, int TAG, int BM = 256, int ABL = 0>
-__global__ __launch_bounds__(BM * 2, 2) void gemm_nt_fast_kernel(int64_t M, int64_t N, int64_t K,
+template <typename T, int BN, int TAG, int ABL = 0>
+__global__ __launch_bounds__(F_BM * 2, 2) void gemm_nt_fast_kernel(int64_t M, int64_t N, int64_t K,
                                                               const T *__restrict__ A, int64_t lda,
                                                               const T *__restrict__ B, int64_t ldb,
                                                               T *__restrict__ C, int64_t ldc, T alpha,
@@ -524,9 +523,8 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_nt_fast_kernel(int64_t M, int6
     constexpr int SUB = EPK / KG;                        // MFMA sub-steps per k-step = elements per lane and row
     constexpr int CPL = SUB * (int)sizeof(T) / 16;       // 16-byte chunks per lane and row per k-step: 2 / 4
     constexpr int UH = CPL / 2;                          // chunks per lane, row and HALF k-step: 1 / 2
-    typedef FGeo<BN, BM> Geo;
+    typedef FGeo<BN> Geo;
     constexpr int F_STAGE = Geo::STAGE, PW = Geo::PW, NTW = Geo::NTW, F_NST = Geo::NST;
-    constexpr int F_BM = BM;
     (void)NTW;
     // requested now, looked at after the prologue's DMA is under way (its latency hides there)
     const int aborted = fm.abort_flag ? fm.abort_flag[(int64_t)blockIdx.y * fm.sflag] : 0;
@@ -538,11 +536,11 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_nt_fast_kernel(int64_t M, int6
     // matrix would send its first patch / chunk to the same XCD -- a batch of small products (one patch each)
     // then runs on an eighth of the chip -- so the logical XCD is rotated by the matrix index.
     const int xcd = (bid - (int)blockIdx.y - 3 * (int)blockIdx.z) & 7, loc = bid >> 3;
-    constexpr int RSH = BM == 256 ? 2 : 3;                          // log2 of the tile rows per patch
+    constexpr int RSH = 3;                                          // log2 of the tile rows per patch
     const int tsh = RSH + fm.csh;
     int patch = (loc >> tsh) * 8 + xcd, within = loc & ((1 << tsh) - 1);
     int pb_r, pb_c;
-    if (BM == 128 && fm.exact) {
+    if (fm.exact) {
         const int chunk = ((loc >> fm.ecl) << 3) + xcd;
         const int t = (chunk << fm.ecl) + (loc & ((1 << fm.ecl) - 1));
         if (t >= fm.eT) return;
@@ -571,7 +569,7 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_nt_fast_kernel(int64_t M, int6
             }
         }
         pb_r = lo; pb_c = j >> 3; within = (r << 3) | (j & 7);
-    } else if (BM == 128 && bid >= fm.dbegin) {
+    } else if (bid >= fm.dbegin) {
         const int b2 = bid - fm.dbegin;
         const int loc2 = b2 >> 3, dp = (loc2 / 36) * 8 + (b2 & 7), t = loc2 % 36;
         if (dp >= fm.ndiag) return;
@@ -594,7 +592,7 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_nt_fast_kernel(int64_t M, int6
         while (pc > 0 && cum(pc) > patch) --pc;
         pb_c = pc; pb_r = fm.b + fm.a * pc + (patch - cum(pc));
     }
-    const int64_t bm0 = ((int64_t)pb_r * (1024 / BM) + (within >> fm.csh)) * F_BM;
+    const int64_t bm0 = ((int64_t)pb_r * (1024 / F_BM) + (within >> fm.csh)) * F_BM;
     const int64_t bn0 = (((int64_t)pb_c << fm.csh) + (within & ((1 << fm.csh) - 1))) * BN;
     if (bm0 >= M || bn0 >= N) return;
     const int64_t cshift = ((fm.cbase + bn0) / fm.nb) * fm.pm1nb;   // same for the tile's 128 columns
@@ -850,15 +848,15 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_nt_fast_kernel(int64_t M, int6
 // ABL: timing-only ablations of the trailing-update kernel (GPX_GEMM_ABLATE, wrong results on purpose; compile-time so
 // that the product kernel carries no branch for them): 1 no barrier / vmcnt, 2 no DMA in the loop, 4 no LDS reads in
 // the loop, 8 no epilogue
-template <typename T, int BN = 128, int TAG = 0, int BM = 256, int ABL = 0>
+template <typename T, int BN = 128, int TAG = 0, int ABL = 0>
 static int launch_gemm_nt_fast(int64_t M, int64_t N, int64_t K, const void *A, int64_t lda,
                                const void *B, int64_t ldb, void *C, int64_t ldc, double alpha, int tri,
                                int64_t row0, int64_t col0, hipStream_t st, const GemmMap *map = nullptr,
                                double work = -1.0, int beta0 = 0, int ktri = 0, const Batch *bt = nullptr)
 {
-    constexpr int F_SMEM = FGeo<BN, BM>::SMEM;
+    constexpr int F_SMEM = FGeo<BN>::SMEM;
     const int pad_lds = TAG == 1 ? (int)tune().gemm_pad_lds : 0;
-    GPX_TRY(set_max_lds((const void *)gemm_nt_fast_kernel<T, BN, TAG, BM, ABL>, TAG == 1 ? 160 * 1024 : F_SMEM));
+    GPX_TRY(set_max_lds((const void *)gemm_nt_fast_kernel<T, BN, TAG, ABL>, TAG == 1 ? 160 * 1024 : F_SMEM));
     GemmMap fm{};
     if (map) {
         fm = *map;
@@ -889,8 +887,7 @@ static int launch_gemm_nt_fast(int64_t M, int64_t N, int64_t K, const void *A, i
     fm.ktri = (ktri == 1 && M == N && N == K) ? 1 : ((ktri == 2 && N == K) ? 2 : 0);
     int64_t dblocks = 0;
     {
-        const bool no_split = tune().gemm_no_dsplit;
-        if (!no_split && !fm.exact && BM == 128 && BN == 128 && tri == GPX_LOWER && fm.a == 1 && fm.csh == 3 && fm.pm1nb == 0 &&
+        if (!fm.exact && BN == 128 && tri == GPX_LOWER && fm.a == 1 && fm.csh == 3 && fm.pm1nb == 0 &&
             col0 - row0 == (int64_t)fm.b * 1024 && fm.np > 0) {
             const int64_t pbc = cdiv(N, 1024);
             fm.bdiag = fm.b;
@@ -907,35 +904,26 @@ static int launch_gemm_nt_fast(int64_t M, int64_t N, int64_t K, const void *A, i
         }
     }
     const int64_t np = fm.np;
-    if (BM == 128 && fm.exact) { if (fm.eT <= 0) return GPX_OK; }
+    if (fm.exact) { if (fm.eT <= 0) return GPX_OK; }
     else if (np <= 0 && dblocks == 0) return GPX_OK;
     {
-        const bool no_vec = tune().gemm_no_vec_c;
-        fm.vec_c = (!no_vec && ldc % 2 == 0 && N % 2 == 0 && N >= 2 && ((uintptr_t)C) % (2 * sizeof(T)) == 0) ? 1 : 0;
+        fm.vec_c = (ldc % 2 == 0 && N % 2 == 0 && N >= 2 && ((uintptr_t)C) % (2 * sizeof(T)) == 0) ? 1 : 0;
         // default on: measured epilogue 20 k -> 11.7 k cycles per tile, whole fit 1.59 -> 1.54 s
-        fm.atomic_c = (int)tune().gemm_atomic_c;
+        fm.atomic_c = 1;
     }
     {
         fm.stamps = g_gemm_stamps;
     }
-    const int64_t ablocks = (cdiv(np, 8) * 8 * (1024 / BM)) << fm.csh;
+    const int64_t ablocks = (cdiv(np, 8) * 8 * (1024 / F_BM)) << fm.csh;
     if (dblocks) fm.dbegin = (int)ablocks;
     int64_t blocks = ablocks + dblocks;
-    if (BM == 128 && fm.exact) blocks = cdiv(fm.eT, (int64_t)8 << fm.ecl) * ((int64_t)8 << fm.ecl);
+    if (fm.exact) blocks = cdiv(fm.eT, (int64_t)8 << fm.ecl) * ((int64_t)8 << fm.ecl);
     ProfScope prof(TAG == 1 ? (BN == 64 ? PC_GEMM_N64 : PC_GEMM) : (BN == 128 ? PC_GEMM_PANEL : PC_GEMM_SKINNY),
                    (work >= 0 ? work : 2.0 * (double)K * updated_elements(M, N, tri, row0, col0)) * nbatch * nbatch2, st);
-    hipLaunchKernelGGL((gemm_nt_fast_kernel<T, BN, TAG, BM, ABL>), dim3((unsigned)blocks, (unsigned)nbatch, (unsigned)nbatch2), dim3(BM * 2), F_SMEM + pad_lds, st, M, N, K,
+    hipLaunchKernelGGL((gemm_nt_fast_kernel<T, BN, TAG, ABL>), dim3((unsigned)blocks, (unsigned)nbatch, (unsigned)nbatch2), dim3(F_BM * 2), F_SMEM + pad_lds, st, M, N, K,
                        (const T *)A, lda, (const T *)B, ldb, (T *)C, ldc, (T)alpha, tri, row0, col0, fm, beta0);
     GPX_LAUNCH_CHECK();
     return GPX_OK;
-}
-
-// block-tile height of the fast kernel (GPX_GEMM_BM = 128 | 256).  Default 128: two 4-wave
-// workgroups per CU -- measured at n = 65536 f64: trailing update 64.9 -> 66.4 TF/s in situ, fit
-// 1.466 -> 1.435 s; n = 32768 f32: 131 -> 128.5 ms; n = 8192: 19.2 -> 18.1 ms.
-static int fast_bm()
-{
-    return tune().gemm_bm == 256 ? 256 : 128;
 }
 
 int gemm_nt(int dtype, int64_t M, int64_t N, int64_t K, const void *A, int64_t lda, const void *B,
@@ -953,32 +941,18 @@ int gemm_nt(int dtype, int64_t M, int64_t N, int64_t K, const void *A, int64_t l
         // there is -- the posterior covariance's in-block products, 1024 x 512 x 512: 32 tiles
         const int64_t t128 = cdiv(M, 128) * cdiv(N, 128) * (bt ? (int64_t)bt->count * std::max(1, bt->count2) : 1);
         const bool few = !wide_tiles && !ktri && tri == GPX_FULL && t128 <= tune().gemm_bn64_tiles;
-        if ((N <= 64 || few) && fast_bm() == 128) {
+        if (N <= 64 || few) {
             if (dtype == GPX_F64)
-                return launch_gemm_nt_fast<double, 64, 0, 128>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0, col0,
+                return launch_gemm_nt_fast<double, 64, 0>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0, col0,
                                                                st, nullptr, -1.0, beta0, 0, bt);
-            return launch_gemm_nt_fast<float, 64, 0, 128>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0, col0, st,
+            return launch_gemm_nt_fast<float, 64, 0>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0, col0, st,
                                                           nullptr, -1.0, beta0, 0, bt);
         }
-        if (N <= 64) {
-            if (dtype == GPX_F64)
-                return launch_gemm_nt_fast<double, 64>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0, col0,
-                                                       st, nullptr, -1.0, beta0, 0, bt);
-            return launch_gemm_nt_fast<float, 64>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0, col0, st,
-                                                  nullptr, -1.0, beta0, 0, bt);
-        }
-        if (fast_bm() == 128) {
-            if (dtype == GPX_F64)
-                return launch_gemm_nt_fast<double, 128, 0, 128>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0,
-                                                                col0, st, nullptr, -1.0, beta0, ktri, bt);
-            return launch_gemm_nt_fast<float, 128, 0, 128>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0, col0,
-                                                           st, nullptr, -1.0, beta0, ktri, bt);
-        }
         if (dtype == GPX_F64)
-            return launch_gemm_nt_fast<double>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0, col0, st,
-                                               nullptr, -1.0, beta0, 0, bt);
-        return launch_gemm_nt_fast<float>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0, col0, st, nullptr,
-                                          -1.0, beta0, 0, bt);
+            return launch_gemm_nt_fast<double, 128, 0>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0,
+                                                            col0, st, nullptr, -1.0, beta0, ktri, bt);
+        return launch_gemm_nt_fast<float, 128, 0>(M, N, K, A, lda, B, ldb, C, ldc, alpha, tri, row0, col0,
+                                                       st, nullptr, -1.0, beta0, ktri, bt);
     }
     if (beta0) { set_error("gemm_nt: beta = 0 needs the aligned fast path"); return GPX_ERR_UNSUPPORTED; }
     if (bt && bt->count2 > 1) { set_error("gemm_nt: a two-dimensional batch needs the aligned fast path"); return GPX_ERR_UNSUPPORTED; }
@@ -1054,7 +1028,7 @@ int syrk_bc(int dtype, int64_t n, int64_t row_begin, void *Cloc, int64_t ldc, in
             // single rank, triangle aligned to the 128 x 128 tiles: enumerate exactly the tiles that exist
             const int64_t exact_env = tune().gemm_exact;
             const int64_t off = row_begin - G0;                       // row origin minus column origin (global)
-            if (exact_env && fast_bm() == 128 && off % 128 == 0 && cdiv(M, 1024) <= G_MAX_BANDS && cl0 % nb == 0) {
+            if (exact_env && off % 128 == 0 && cdiv(M, 1024) <= G_MAX_BANDS && cl0 % nb == 0) {
                 // Short updates take 128 x 64 tiles: twice the tiles at little more than half the time each, so the
                 // last, partly filled round of workgroups costs half as much and the 2 - 5 rounds of an n <= 8192 step
                 // lose less to it (full products of these shapes, K = 256: 7680 x 3840 46 -> 55 TF/s, 5632 x 2816
@@ -1107,30 +1081,23 @@ int syrk_bc(int dtype, int64_t n, int64_t row_begin, void *Cloc, int64_t ldc, in
         route_hit(fm.exact ? RT_SYRK_EXACT : RT_SYRK_PATCH);
         if (fm.exact && bn64) {
             if (dtype == GPX_F64)
-                return launch_gemm_nt_fast<double, 64, 1, 128>(M, Ncols, kb, A, ldp, Pb, ldp, C, ldc, -1.0, GPX_LOWER,
+                return launch_gemm_nt_fast<double, 64, 1>(M, Ncols, kb, A, ldp, Pb, ldp, C, ldc, -1.0, GPX_LOWER,
                                                                row_begin, cl0 + (int64_t)rank * nb, st, &fm, work, 0, 0, bt);
-            return launch_gemm_nt_fast<float, 64, 1, 128>(M, Ncols, kb, A, ldp, Pb, ldp, C, ldc, -1.0, GPX_LOWER,
+            return launch_gemm_nt_fast<float, 64, 1>(M, Ncols, kb, A, ldp, Pb, ldp, C, ldc, -1.0, GPX_LOWER,
                                                           row_begin, cl0 + (int64_t)rank * nb, st, &fm, work, 0, 0, bt);
         }
-        if (fast_bm() == 128) {
-            if (dtype == GPX_F64 && tune().gemm_ablate) {
-#define GPX_ABL_CASE(V)                                                                                                \
-    case V: return launch_gemm_nt_fast<double, 128, 1, 128, V>(M, Ncols, kb, A, ldp, Pb, ldp, C, ldc, -1.0, GPX_LOWER, \
+        if (dtype == GPX_F64 && tune().gemm_ablate) {
+#define GPX_ABL_CASE(V)                                                                                            \
+    case V: return launch_gemm_nt_fast<double, 128, 1, V>(M, Ncols, kb, A, ldp, Pb, ldp, C, ldc, -1.0, GPX_LOWER, \
                                                                row_begin, cl0 + (int64_t)rank * nb, st, &fm, work, 0, 0, bt)
-                switch ((int)tune().gemm_ablate) { GPX_ABL_CASE(1); GPX_ABL_CASE(2); GPX_ABL_CASE(4); GPX_ABL_CASE(7); GPX_ABL_CASE(8); GPX_ABL_CASE(15); default: break; }
+            switch ((int)tune().gemm_ablate) { GPX_ABL_CASE(1); GPX_ABL_CASE(2); GPX_ABL_CASE(4); GPX_ABL_CASE(7); GPX_ABL_CASE(8); GPX_ABL_CASE(15); default: break; }
 #undef GPX_ABL_CASE
-            }
-            if (dtype == GPX_F64)
-                return launch_gemm_nt_fast<double, 128, 1, 128>(M, Ncols, kb, A, ldp, Pb, ldp, C, ldc, -1.0, GPX_LOWER,
-                                                                row_begin, cl0 + (int64_t)rank * nb, st, &fm, work, 0, 0, bt);
-            return launch_gemm_nt_fast<float, 128, 1, 128>(M, Ncols, kb, A, ldp, Pb, ldp, C, ldc, -1.0, GPX_LOWER,
-                                                           row_begin, cl0 + (int64_t)rank * nb, st, &fm, work, 0, 0, bt);
         }
         if (dtype == GPX_F64)
             return launch_gemm_nt_fast<double, 128, 1>(M, Ncols, kb, A, ldp, Pb, ldp, C, ldc, -1.0, GPX_LOWER,
-                                                       row_begin, cl0 + (int64_t)rank * nb, st, &fm, work, 0, 0, bt);
+                                                            row_begin, cl0 + (int64_t)rank * nb, st, &fm, work, 0, 0, bt);
         return launch_gemm_nt_fast<float, 128, 1>(M, Ncols, kb, A, ldp, Pb, ldp, C, ldc, -1.0, GPX_LOWER,
-                                                  row_begin, cl0 + (int64_t)rank * nb, st, &fm, work, 0, 0, bt);
+                                                       row_begin, cl0 + (int64_t)rank * nb, st, &fm, work, 0, 0, bt);
     }
     // generic route: one launch per local block column
     for (int64_t c = cl0; c < cl1;) {

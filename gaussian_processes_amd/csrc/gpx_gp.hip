@@ -345,7 +345,7 @@ int gpx_gp_fit(gpx_gp_t *g, int *info)
     // (n = 8192: fit 6.71 -> 6.73 ms with groups of 4, 6.62 with one; n = 12288: 15.57 -> 15.04; n = 4096: no gain), and
     // the last blocks' operators would only be waited for: the backward sweep takes those blocks by steps
     const int64_t nfull = g->n / 512, tail = tune().fit_ops_tail;
-    const int64_t group = std::max<int64_t>(1, std::min(tune().fit_ops_group_set ? tune().fit_ops_group : nfull, nfull - tail));
+    const int64_t group = std::max<int64_t>(1, std::min(nfull, nfull - tail));
     OpsAhead oa = {g, group, std::max<int64_t>(0, nfull - tail)};
     PotrfHook hook = {ops_ahead_step, &oa};
     if (ahead) {

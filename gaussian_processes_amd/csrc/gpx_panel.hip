@@ -558,81 +558,6 @@ __global__ __launch_bounds__(256, LV == 4 ? 1 : 2) void panel_res_kernel(T *__re
 }
 
 
-// ---- TALL panels: the rows below the diagonal block as ONE product on the GEMM kernel ------------------------------------
-// In the resident kernel every 64 rows of a panel are a workgroup of 254 VGPRs and 74 KB of LDS that does ten 64^3 block
-// products between LDS round trips and barriers (~5 TF/s) -- at N = 65536 187 ms of such workgroups per fit sat on the CUs
-// beside the trailing update, which IS the critical path there.  For a panel of 256 columns with many rows the launch
-// therefore keeps only the four diagonal workgroups (the chain of leaves: L of the 256 x 256 diagonal block, the inverses
-// W_j of its four 64 x 64 diagonal blocks); winv256_kernel completes them to W = inv(L_256) -- block column j by
-// workgroup j:  V_jj = W_j,  V_cj = -W_c sum_{k=j}^{c-1} L_ck V_kj  -- and the rows below are
-//     X = P W^T      (M = rows, N = K = 256)
-// on gemm_nt_fast_kernel, IN PLACE, as two launches that each own whole rows of their output columns (128 x 128 tiles,
-// one tile column: a tile has read its rows of P before it stores them): columns 128 .. 255 first (they need all of P),
-// then columns 0 .. 127 (which need only themselves; the upper blocks of W are zero).
-// All products are C = A B^T with B's rows in LDS, so the kernel works with the TRANSPOSES VT_kj = V_kj^T:
-//     ST    = sum_k VT_kj L_ck^T     (= (sum_k L_ck V_kj)^T)
-//     VT_cj = -ST W_c^T
-// Two LDS blocks only (68 KB in fp64): the launch runs beside a trailing update whose workgroups hold 64 KB each, two to a
-// CU, and a workgroup that needed more than ONE of them to retire would wait for the update to drain (the first version
-// kept the live VT_kj in four blocks, 135 KB: N = 65536 +40 ms).  The V_kj of earlier block rows are read back, transposed,
-// from the output itself (written and read by this workgroup only: agent-scope accesses, drained before the barrier).
-template <typename T>
-__global__ __launch_bounds__(256) void winv256_kernel(const T *__restrict__ D, int64_t lda, const T *__restrict__ pub,
-                                                      T *__restrict__ Wout, const int *__restrict__ info)
-{
-    typedef PM<T> M;
-    typedef typename M::v4 v4;
-    constexpr int PT = ResPitch<T>::v, NB = RES_MAXSTEPS, LDW = RES_MAXSTEPS * IB;
-    __shared__ __attribute__((aligned(16))) T sA[IB][PT];
-    __shared__ __attribute__((aligned(16))) T sB[IB][PT];
-    if (*info != 0) return;                                     // (the factor is garbage from there on; W stays what it was)
-    __builtin_amdgcn_s_setprio(2);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lq = lane >> 4;
-    const int j = blockIdx.x;
-    const T *Wj = pub + (int64_t)j * (IB * IB);
-    // V_jj = W_j (the tiles above its diagonal are zero since the buffer was cleared)
-    for (int idx = tid; idx < IB * IB; idx += 256) Wout[(int64_t)(IB * j + idx / IB) * LDW + IB * j + idx % IB] = Wj[idx];
-    for (int c = j + 1; c < NB; ++c) {
-        v4 acc[4];
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[jj][r] = (T)0;
-        for (int k = j; k < c; ++k) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (this workgroup's V_kj of the block row before is on its way)
-            __syncthreads();                                    // ... and the blocks in LDS have been read
-            for (int idx = tid; idx < IB * IB; idx += 256) {
-                const int r = idx / IB, cc = idx % IB;
-                sB[r][cc] = D[(int64_t)(IB * c + r) * lda + IB * k + cc];
-                // VT_kj[cc][r] = V_kj[r][cc]
-                sA[cc][r] = k == j ? Wj[idx] : pub_load(Wout + (int64_t)(IB * k + r) * LDW + IB * j + cc);
-            }
-            __syncthreads();
-            res_prod<T, PT, false>(sA, sB, acc, wave, li, lq);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sA[16 * wave + M::row(lane, r)][16 * jj + li] = acc[jj][r];
-        const T *Wc = pub + (int64_t)c * (IB * IB);
-        for (int idx = tid; idx < IB * IB; idx += 256) sB[idx / IB][idx % IB] = Wc[idx];
-        __syncthreads();
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[jj][r] = (T)0;
-        res_prod<T, PT, true>(sA, sB, acc, wave, li, lq);
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = 16 * wave + M::row(lane, r), m = 16 * jj + li;      // VT_cj[i][m] = V_cj[m][i]
-                pub_store(Wout + (int64_t)(IB * c + m) * LDW + IB * j + i, acc[jj][r]);
-            }
-    }
-}
-
 static unsigned long long *g_res_stamps = nullptr;             // diagnostic: the launch `g_res_stamp_at` launches from now records
 static int g_res_stamp_at = -1;
 
@@ -650,8 +575,7 @@ struct ResScratch {
 constexpr int RES_MAXDEV = 16;
 static thread_local ResScratch g_res_dev[RES_MAXDEV];       // one per device: a thread that alternates between GPUs keeps both
 #define RES_TRACE(...) do { if (tune().trace) { fprintf(stderr, "[gpx] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
-constexpr size_t RES_W256 = (size_t)(RES_MAXSTEPS * IB) * (RES_MAXSTEPS * IB);      // elements of inv(L_256) (tall panels, single matrices)
-static int res_scratch(int nbatch, size_t es, void **pub, int **flags, ResScratch **out, void **w256 = nullptr)
+static int res_scratch(int nbatch, size_t es, void **pub, int **flags, ResScratch **out)
 {
     int dev = 0;
     GPX_HIP(hipGetDevice(&dev));
@@ -663,7 +587,7 @@ static int res_scratch(int nbatch, size_t es, void **pub, int **flags, ResScratc
         g.p = nullptr; g.bytes = 0; g.nbatch = 0;
         const size_t fbytes = ((size_t)nbatch * RES_FLAGS * sizeof(int) + 255) / 256 * 256;
         const size_t region = (size_t)nbatch * RES_SLOTS * IB * IB * 8;
-        const size_t need = fbytes + region + region / 2 + RES_W256 * (8 + 4);     // (W256: the blocks above its diagonal stay zero)
+        const size_t need = fbytes + region + region / 2;
         GPX_HIP(hipMalloc(&g.p, need));
         GPX_HIP(hipMemset(g.p, 0, need));
         GPX_HIP(hipDeviceSynchronize());
@@ -687,7 +611,6 @@ static int res_scratch(int nbatch, size_t es, void **pub, int **flags, ResScratc
     }
     *flags = (int *)g.p;
     *pub = (char *)g.p + fbytes + (es == 8 ? 0 : region);
-    if (w256) *w256 = (char *)g.p + fbytes + region + region / 2 + (es == 8 ? 0 : RES_W256 * 8);
     *out = &g;
     return GPX_OK;
 }
@@ -732,9 +655,9 @@ static int panel_res_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int
                        const Batch *bt, int64_t kpre, hipEvent_t done)
 {
     const int nbatch = bt ? bt->count : 1;
-    void *pub = nullptr, *w256 = nullptr; int *flags = nullptr;
+    void *pub = nullptr; int *flags = nullptr;
     ResScratch *scr = nullptr;
-    GPX_TRY(res_scratch(nbatch, sizeof(T), &pub, &flags, &scr, &w256));
+    GPX_TRY(res_scratch(nbatch, sizeof(T), &pub, &flags, &scr));
     const int64_t rows = n - r0;
     dim3 grid((unsigned)cdiv(rows, IB), (unsigned)nbatch);
     const double kd = (double)kb;
@@ -816,44 +739,13 @@ static int panel_res_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int
     // two workgroups a CU like the round-3 kernel (a 10 KB ring of operand slots instead of 40 KB, no operand prefetch)
     // (fp32 panels hand their diagonal blocks to the same fp64 leaf wherever they used the fp32 MFMA leaf: GPX_LEAF=1 keeps that one)
     const bool v5 = asm_ok && !v4 && (leaf_want >= 0 ? leaf_want : 5) == 5;
-    // TALL panels of single matrices (256 columns, more than GPX_POTRF_TALL_ROWS rows): only the diagonal workgroups stay on the
-    // resident kernel; the rows below are products on the GEMM kernel (winv256_kernel above has the why)
-    // MEASURED (round 5, profiles/r05_ab_tall_*.log, r05_timeline_n65536_*.txt, r05_panel_alone_tall_vs_resident.log) and OFF by
-    // default: N = 65536 fp64 1.3662 vs 1.3668 s, N = 32768 fp32 94.97 vs 94.38 ms, a 65536 x 256 panel alone 0.319 vs
-    // 0.296 ms.  The row workgroups' 188 ms of kernel time per fit become 95 ms of products + 40 ms of inverses, and the
-    // trailing update beside them runs exactly as fast as before (0.872 of peak): what the update loses in situ is the
-    // panel stream's FLOPS on the same matrix pipes -- ~2.3 TF per fit, which cost it ~38 ms, i.e. they already run at the
-    // equivalent of 60 TF/s -- not the shape of the kernels that carry them.  (With the first inverse kernel, whose 135 KB
-    // of LDS starved it behind the update, the update ran at 0.898 and the fit took 40 ms LONGER.)
-    const bool tall = !bt && nsteps == RES_MAXSTEPS && (int64_t)grid.x > nsteps && rows > tune().tall_rows &&
-                      lda % (16 / (int64_t)sizeof(T)) == 0 && ((uintptr_t)A) % 16 == 0 && c0 % 16 == 0 && !tune().gemm_no_fast;
-    // (the profiling class of the resident launches; the tall route's products are counted by their own classes)
-    const double res_rows = tall ? (double)kb : (double)rows;
+    // (Round 5's "tall" route -- only the diagonal workgroups on the resident kernel, the rows below as products with
+    // inv(L_256) on the GEMM kernel -- was measured neutral at every size (N = 65536 fp64 1.3662 vs 1.3668 s, N = 32768 fp32
+    // 94.97 vs 94.38 ms: what the update loses in situ is the panel stream's FLOPS on the same matrix pipes, not the shape
+    // of the kernels that carry them; profiles/r05_ab_tall_*.log) and removed in round 6 with its inverse kernel.)
+    const double res_rows = (double)rows;
     std::optional<ProfScope> prof;
     prof.emplace(PC_POTRF_DIAG, (kd * kd * kd / 3.0 + (res_rows - (double)kb) * kd * kd + 2.0 * res_rows * kd * (double)kpre) * nbatch, st);
-    if (tall) {
-        route_hit(RT_PANEL_TALL);
-        const bool mfma_chain = F64 || tune().leaf_mfma_f32_rows > 0;
-        const dim3 gdiag((unsigned)nsteps, 1);
-        if (v4) GPX_PANEL_LAUNCH_LDS((panel_res_kernel<T, true, 4>), gdiag, 0, pad_lds);
-        else if (v5 && mfma_chain) GPX_PANEL_LAUNCH((panel_res_kernel<T, true, 5>), gdiag, 0);
-        else if (mfma_chain) GPX_PANEL_LAUNCH((panel_res_kernel<T, true>), gdiag, 0);
-        else GPX_PANEL_LAUNCH((panel_res_kernel<T, F64>), gdiag, 0);
-        GPX_LAUNCH_CHECK();
-        hipLaunchKernelGGL((winv256_kernel<T>), dim3(RES_MAXSTEPS), dim3(256), 0, st, (const T *)(A + r0 * lda + c0), lda, (const T *)pub,
-                           (T *)w256, (const int *)info_dev);
-        GPX_LAUNCH_CHECK();
-        prof.reset();
-        const int dtype = F64 ? GPX_F64 : GPX_F32;
-        const int64_t below = n - (r0 + kb), LDW = RES_MAXSTEPS * IB, H = LDW / 2;
-        T *P = A + (r0 + kb) * lda + c0;
-        // the update by the kpre columns to the left that a short panel's row workgroups fold in (forced routes: by default a
-        // tall panel is never folded)
-        if (kpre > 0)
-            GPX_TRY(gemm_nt(dtype, below, kb, kpre, P - kpre, lda, A + r0 * lda + (c0 - kpre), lda, P, lda, -1.0, GPX_FULL, 0, 0, st));
-        GPX_TRY(gemm_nt(dtype, below, H, LDW, P, lda, (const T *)w256 + H * LDW, LDW, P + H, lda, 1.0, GPX_FULL, 0, 0, st, 1, 0, nullptr, 1));
-        GPX_TRY(gemm_nt(dtype, below, H, H, P, lda, (const T *)w256, LDW, P, lda, 1.0, GPX_FULL, 0, 0, st, 1, 0, nullptr, 1));
-    } else
     if (two_part && (int64_t)grid.x > nsteps) {
         const bool mfma_chain = F64 || tune().leaf_mfma_f32_rows > 0;
         const dim3 gdiag((unsigned)nsteps, grid.y), grows(grid.x - (unsigned)nsteps, grid.y);

@@ -86,52 +86,6 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(T *__restrict__ blk, in
         }
 }
 
-static thread_local bool g_leaf_pipe = false;            // set by potrf(): CUs are reserved for the panel stream
-static unsigned long long *g_leaf_stamps = nullptr;     // diagnostic (gpx_debug_leaf_stamps): 5 waves x 16 steps x 4 stamps
-// the leaf with the pivot wave (gpx_leaf.h): 320 threads
-template <typename T, bool INV>
-__global__ __launch_bounds__(320) void potrf_diag_pipe_kernel(T *__restrict__ blk, int64_t lda, int64_t j0, int jb,
-                                                              int *__restrict__ info, T *__restrict__ inv, int64_t sblk,
-                                                              int nsteps, unsigned long long *stamps)
-{
-    blk += (int64_t)blockIdx.x * sblk;
-    info += blockIdx.x;
-    if (INV) inv += (int64_t)blockIdx.x * (IB * IB);
-    __builtin_amdgcn_s_setprio(3);
-    const int tid = threadIdx.x;
-    __shared__ int s_abort;
-    if (tid == 0) s_abort = *info;
-    __syncthreads();
-    if (s_abort != 0) return;
-    const bool pivot = tid >= 256;
-    // tile coordinates: waves 0-3 own (tr, tc); wave 4 lane t owns (t, t) (lanes >= 16 idle)
-    const int tr = pivot ? (tid - 256) : (tid >> 4), tc = pivot ? (tid - 256) : (tid & 15);
-    const bool live = !pivot || (tid - 256) < IB / 4;
-    T a[4][4], x[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int row = 4 * tr + r, col = 4 * tc + c;
-            T v = (row == col) ? (T)1 : (T)0;
-            if (live && row < jb && col <= row) v = blk[(int64_t)row * lda + col];
-            a[r][c] = v;
-            x[r][c] = (row == col) ? (T)1 : (T)0;
-        }
-    factor64_pipe<T, INV>(a, x, jb, j0, info, leaf_role_320(tid), nsteps, stamps);
-    if (!live) return;
-    const bool own_a = pivot || tc < tr;              // waves 0-3 own the strictly-lower tiles, wave 4 the diagonal ones
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int row = 4 * tr + r, col = 4 * tc + c;
-            if (own_a && row < jb && col <= row) blk[(int64_t)row * lda + col] = a[r][c];
-            if (INV && !pivot) inv[row * IB + col] = (col <= row) ? x[r][c] : (T)0;
-        }
-}
-
-
 // ---- (c) X[r, 0:jb] <- X[r, 0:jb] * Ljj^-T : one lane per row --------------
 // Forward substitution along the row: x_c = (a_c - sum_{t<c} x_t L[c,t]) / L[c,c].
 template <typename T, bool FULL64>
@@ -282,11 +236,6 @@ static int leaf_scratch(size_t bytes, void **out)
 // Three further panel routes were built, measured slower and removed again in round 3 (DESIGN section 3.2 keeps the
 // measurements): "tall" (diagonal block first, inv(L11) by recursive doubling, one product for all rows below),
 // "fused" (one launch per 64 columns, left-looking) and "lean" (leaf + one row kernel per 64 columns).
-// the wide panel as a blocked factorisation of its own (defined below, after the look-ahead state it uses)
-static bool panel_nested_ok(int64_t rows, int64_t r0, int64_t c0, int64_t kb, int64_t kpre, size_t es, int64_t lda, const void *base);
-static int potrf_panel_nested(int dtype, void *A, int64_t lda, int64_t n, int64_t r0, int64_t kb, int *info_dev, hipStream_t q,
-                              const Batch *bt, hipEvent_t done);
-
 template <typename T>
 static int potrf_panel_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, int64_t kb, int *info_dev,
                          hipStream_t st, int dtype, const Batch *bt, int64_t kpre = 0, hipEvent_t done = nullptr)
@@ -317,20 +266,8 @@ static int potrf_panel_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, i
         }
         {
             ProfScope prof(PC_POTRF_DIAG, (double)jb * jb * jb / 3.0 * nbatch, st);
-            // the 320-thread pivot-wave leaf wins where CUs are set aside for the panel stream (n <= 12288: 30.4 -> 27 us)
-            // and loses where it has to wait for a slot among the trailing update's workgroups (fp64 n = 16384:
-            // potrf 37.2 -> 40.2 ms, n = 24576: 94.4 -> 98.1): GPX_LEAF_PIPE = 1 always, 0 never, default by reservation
-            const int64_t pipe_env = tune().leaf_pipe;
-            const bool pipe = pipe_env < 0 ? g_leaf_pipe : pipe_env != 0;
-            const int nsteps = (int)tune().leaf_ablate;   // timing only
-            if (pipe) {
-                if (inv)
-                    hipLaunchKernelGGL((potrf_diag_pipe_kernel<T, true>), dim3(nbatch), dim3(320), 0, st, D, lda, r0, jb,
-                                       info_dev, inv, sM, nsteps, g_leaf_stamps);
-                else
-                    hipLaunchKernelGGL((potrf_diag_pipe_kernel<T, false>), dim3(nbatch), dim3(320), 0, st, D, lda, r0, jb,
-                                       info_dev, inv, sM, nsteps, g_leaf_stamps);
-            } else if (inv)
+            // (the 320-thread pivot-wave form of this leaf only paid with CUs set aside for the panel stream; both went in round 6)
+            if (inv)
                 hipLaunchKernelGGL((potrf_diag_kernel<T, true>), dim3(nbatch), dim3(256), 0, st, D, lda, r0, jb,
                                    info_dev, inv, sM);
             else
@@ -353,10 +290,6 @@ static int potrf_panel_t(T *A, int64_t lda, int64_t n, int64_t r0, int64_t c0, i
         return GPX_OK;
     }
     // wide panels of short matrices: a blocked factorisation of their own, with its own look-ahead (round 4)
-    if (panel_nested_ok(n - r0, r0, c0, kb, kpre, sizeof(T), lda, A)) {
-        route_hit(RT_PANEL_NESTED);
-        return potrf_panel_nested(dtype, A, lda, n, r0, kb, info_dev, st, bt, done);
-    }
     const int64_t h = ((kb / IB + 1) / 2) * IB;          // left half, a multiple of 64
     GPX_TRY(potrf_panel_t<T>(A, lda, n, r0, c0, h, info_dev, st, dtype, bt));
     T *R = A + (r0 + h) * lda + c0;                       // rows below the left half's diagonal block
@@ -379,23 +312,6 @@ int potrf_panel(int dtype, void *A, int64_t lda, int64_t n, int64_t r0, int64_t 
 struct LookAhead {
     int device = -1;
     hipStream_t q = nullptr;
-    hipStream_t u = nullptr;        // the in-panel updates of a nested wide panel (potrf_panel_nested), created on first use
-    // trailing-update streams that leave `reserved` CUs to the panel stream, one per reservation ever asked for.
-    // They live until the owning thread ends: pooled events keep referring to the stream they were last recorded
-    // on, and a factorisation that alternates between reservations (single fits: 32, small lock-step batches: 16)
-    // must not destroy a stream under them (seen as an intermittent hang of the next fit).  At thread end they are
-    // given back -- a CU-masked stream that is still alive at process teardown crashes rocprofv3's finaliser.
-    static constexpr int MAXT = 8;
-    hipStream_t t[MAXT] = {};
-    int reserved[MAXT] = {};
-    int nt = 0;
-    void drop_streams()
-    {
-        for (int i = 0; i < nt; ++i)
-            if (t[i]) { (void)hipStreamSynchronize(t[i]); (void)hipStreamDestroy(t[i]); t[i] = nullptr; }
-        nt = 0;
-    }
-    ~LookAhead() { drop_streams(); }
     std::vector<hipEvent_t> ev;
     size_t next = 0;
     int get(hipEvent_t *e)
@@ -427,8 +343,7 @@ static int lookahead_setup()
     int dev = 0;
     GPX_HIP(hipGetDevice(&dev));
     if (g_la.device != dev) {
-        g_la.drop_streams();
-        g_la.q = nullptr; g_la.u = nullptr; g_la.ev.clear();
+        g_la.q = nullptr; g_la.ev.clear();
         g_la.device = dev;
         // the panel is on the critical path of the NEXT step: give its stream the highest
         // priority so that its workgroups get the CUs that trailing-update workgroups free up
@@ -440,130 +355,12 @@ static int lookahead_setup()
     return GPX_OK;
 }
 
-// ---- the wide panel as a blocked factorisation of its own ------------------------------------------------------------
-// A panel of 768 / 1024 columns used to halve recursively: left half, ONE product, right half -- a chain without any
-// overlap inside the panel, which is why a wide outer block only paid above 12288 rows.  Here the wide panel (rows
-// [r0, n) x columns [r0, r0 + kb), sub-panels of `sub` = 256 columns) runs the factorisation's own schedule one level
-// down:
-//     sub-panel j on the panel stream q: ONE resident launch that first applies sub-panel j - 1 to its own columns (kpre)
-//     in-panel update U(j) on stream u:  sub-panel j applied to the panel's columns BEYOND sub-panel j + 1, K = 256
-//     sub-panel j + 1 waits for sub-panel j (stream order) and for U(j - 1) (event), U(j) for sub-panel j and U(j - 1)
-// -- the resident kernels of consecutive sub-panels follow each other directly, the small in-panel products run beside them.
-// With it the OUTER block can be 1024 wide while many rows are left, so that the bulk of the trailing update runs at
-// K = 1024 (the MFMA kernel: 62 - 64 TF/s) instead of K = 256 (37 - 55 TF/s: C re-read and re-written every 256
-// columns, a tile as long as its own prologue + epilogue) -- the two-level scheme: near updates per sub-panel inside the
-// 1024-column window, the far trailing matrix once per four sub-panels.  The outer loop of potrf() needs no change: its
-// one-panel look-ahead already updates the NEXT block column first (the far update's first 1024 columns), starts this
-// panel, and applies the rest underneath it.
-static thread_local bool g_in_potrf = false;    // potrf() is running on this thread: its look-ahead state (streams, event pool) is set up
 // potrf()'s loop sets this right before a panel whose FIRST launch will find the chip idle (it is ordered behind the update
 // before it and ahead of the one that runs beside it); the resident panel launch that takes the hint may claim whole CUs
 // (gpx_panel.hip, GPX_PANEL_EXCL_ROWS).  Later launches of the same panel (the right half of a wide one) start on a chip that
 // the update has filled meanwhile: they must not wait for empty CUs.
 static thread_local bool g_idle_chip = false;
 bool potrf_take_idle_chip_hint() { const bool v = g_idle_chip; g_idle_chip = false; return v; }
-static bool panel_nested_ok(int64_t rows, int64_t r0, int64_t c0, int64_t kb, int64_t kpre, size_t es, int64_t lda, const void *base)
-{
-    const int64_t sub = panel_res_max();
-    if (!g_in_potrf || tune().potrf_nested == 0) return false;
-    // (r0 != c0: a rank's local block column of the multi-GPU schedule -- the in-panel updates' tile map assumes global columns)
-    return r0 == c0 && kpre == 0 && sub == 256 && kb % sub == 0 && kb / sub >= 3 && rows <= tune().potrf_nested_rows &&
-           panel_res_fold(rows, sub, sub, es, lda, base);
-}
-
-static int potrf_panel_nested(int dtype, void *A, int64_t lda, int64_t n, int64_t r0, int64_t kb, int *info_dev, hipStream_t q,
-                              const Batch *bt, hipEvent_t done)
-{
-    const int64_t sub = panel_res_max(), ns = kb / sub, cend = r0 + kb;
-    const size_t es = esize(dtype);
-    auto at = [&](int64_t r, int64_t c) { return (char *)A + (r * lda + c) * es; };
-    if (!g_la.u) {
-        int least = 0, greatest = 0;
-        GPX_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        GPX_HIP(hipStreamCreateWithPriority(&g_la.u, hipStreamNonBlocking, greatest));
-    }
-    hipStream_t u = g_la.u;
-    hipEvent_t eu_prev = nullptr;                                 // U(j - 1) done
-    for (int64_t j = 0; j < ns; ++j) {
-        const int64_t rj = r0 + j * sub;
-        // sub-panel j: needs sub-panel j - 1 (stream order; its update of these columns is folded into this launch) and
-        // U(j - 2) -- the last in-panel update that touched these columns (U(j - 1) starts beyond them)
-        hipEvent_t ep;
-        GPX_TRY(g_la.get(&ep));
-        GPX_TRY(potrf_panel_res(dtype, A, lda, n, rj, rj, sub, info_dev, q, bt, j > 0 ? sub : 0, j + 1 == ns ? done : ep));
-        route_hit(RT_PANEL_RES);
-        if (j + 1 == ns) break;
-        // U(j): columns [rj + 2 sub, cend), rows from rj + sub
-        if (rj + 2 * sub < cend) {
-            GPX_HIP(hipStreamWaitEvent(u, ep, 0));
-            GPX_TRY(syrk_bc(dtype, n, rj + sub, A, lda, rj + 2 * sub, cend, at(rj, rj), lda, rj, sub, sub, 1, 0, u, info_dev, bt));
-            hipEvent_t eu;
-            GPX_TRY(g_la.get(&eu));
-            GPX_HIP(hipEventRecord(eu, u));
-            // sub-panel j + 2 is the first to need U(j); sub-panel j + 1 needs U(j - 1)
-            if (eu_prev) GPX_HIP(hipStreamWaitEvent(q, eu_prev, 0));
-            eu_prev = eu;
-        } else if (eu_prev) {
-            GPX_HIP(hipStreamWaitEvent(q, eu_prev, 0));
-            eu_prev = nullptr;
-        }
-    }
-    return GPX_OK;
-}
-
-// Small matrices: the panel chain (a dozen dependent, mostly tiny kernels) is as long as the
-// trailing update it should hide under, and every one of its kernels would wait for a
-// trailing-update workgroup to retire before it finds room on a CU (measured at n = 8192:
-// the 64 x 64 leaf 33 us alone, 105 us beside the update).  The update therefore runs on
-// a stream whose CU mask leaves `reserve` CUs (mask bits interleave over the 8 XCDs) free;
-// the panel stream keeps the whole chip.
-static int trailing_stream(int reserve, hipStream_t *out)
-{
-    for (int i = 0; i < g_la.nt; ++i)
-        if (g_la.reserved[i] == reserve) { *out = g_la.t[i]; return GPX_OK; }
-    *out = nullptr;
-    if (g_la.nt == LookAhead::MAXT) return GPX_OK;              // (more distinct reservations than anyone asks for: share the chip)
-    hipDeviceProp_t prop;
-    GPX_HIP(hipGetDeviceProperties(&prop, g_la.device));
-    const int ncu = prop.multiProcessorCount;
-    std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
-    for (int i = reserve; i < ncu; ++i) mask[i / 32] |= 1u << (i % 32);
-    hipStream_t t = nullptr;
-    if (hipExtStreamCreateWithCUMask(&t, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
-        (void)hipGetLastError();                                // masks unsupported here: share the chip as for large n
-        return GPX_OK;
-    }
-    g_la.t[g_la.nt] = t; g_la.reserved[g_la.nt] = reserve; ++g_la.nt;
-    *out = t;
-    return GPX_OK;
-}
-
-static int reserve_cus(int64_t n)
-{
-    const int64_t env = tune().reserve_cus;
-    if (env >= 0) return (int)std::min<int64_t>(128, env);
-    // Round 1 (a panel = a dozen small launches): 32 CUs for n <= 12288, n = 8192 13.3 -> 12.3 ms.  With one resident
-    // launch per panel the reservation no longer pays -- round 3, 32 vs 0 reserved: n = 2048 0.965 / 0.957 ms, 4096
-    // 2.084 / 2.086, 8192 6.209 / 6.169 (fp32 4.633 / 4.604), 12288 14.42 / 14.38 -- and no CU-masked stream is created
-    // at all by default (they have no priority, must outlive every pooled event, and two of them slow each other down).
-    (void)n;
-    return 0;
-}
-
-// Lock-step batches: no reservation.  (Rounds 1-2 set 16 CUs aside for batches of up to 16 matrices: with the chain of
-// small launches a panel then was, its first kernel was not dispatched until the update of all matrices had drained.
-// With one resident launch per panel 0 / 16 / 32 reserved CUs are within 1 % of each other for 8, 16 and 64 matrices
-// (tools/r3_batch8.py) -- and a SECOND CU-masked stream beside the single fits' one costs a later batch 6 % whenever a
-// single-matrix factorisation ran earlier on the thread (tools/r3_batch_after_fit.py: 29.3 -> 31.0 ms for 8 x 8192;
-// 29.4 either way with one masked stream).  GPX_POTRF_RESERVE_CUS_BATCH still forces a value.)
-static int reserve_cus_batch(int64_t n, int count)
-{
-    const int64_t env = tune().reserve_cus_batch;
-    if (env >= 0) return (int)std::min<int64_t>(128, env);
-    (void)n; (void)count;
-    return 0;
-}
-
 // Right-looking blocked Cholesky with one-panel look-ahead: while the main stream
 // applies panel k to the block columns beyond k + 1, the side stream already
 // factors panel k + 1 (whose block column was updated first).
@@ -579,7 +376,6 @@ int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t
     const int64_t nblk = cdiv(n, nb);
     const size_t es = esize(dtype);
     const bool no_la = tune().no_lookahead;
-    g_leaf_pipe = false;
     if (nblk <= 1) return potrf_panel(dtype, A, lda, N, 0, 0, n, info_dev, st, bt);
     auto at = [&](int64_t r, int64_t c) { return (char *)A + (r * lda + c) * es; };
     if (no_la) {
@@ -591,33 +387,11 @@ int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t
         return GPX_OK;
     }
     GPX_TRY(lookahead_setup());
-    struct InPotrf { InPotrf() { g_in_potrf = true; } ~InPotrf() { g_in_potrf = false; } } in_potrf__;
     hipStream_t q = g_la.q;
     hipEvent_t e, ep;
     GPX_TRY(g_la.get(&e));
     GPX_HIP(hipEventRecord(e, st));
     GPX_HIP(hipStreamWaitEvent(q, e, 0));
-    hipStream_t user = st;
-    const int reserve = bt ? reserve_cus_batch(n, bt->count) : reserve_cus(n);
-    hipStream_t masked = nullptr;
-    if (reserve > 0) {
-        GPX_TRY(trailing_stream(reserve, &masked));             // the updates go to the masked stream ...
-        if (masked) g_leaf_pipe = true;
-    }
-    // ... once the step is bound by the panel chain: while the trailing update is the longer of the two (many
-    // rows left) it keeps the whole chip
-    // (round 3, with the XCD-balanced tile map: 8192 -> 4096: n = 8192 potrf 6.37 -> 6.27 ms, tools/r3_ab.sh)
-    const int64_t reserve_below = tune().reserve_below;
-    auto switch_to = [&](hipStream_t want) -> int {
-        if (want == st) return GPX_OK;
-        hipEvent_t es;
-        GPX_TRY(g_la.get(&es));
-        GPX_HIP(hipEventRecord(es, st));
-        GPX_HIP(hipStreamWaitEvent(want, es, 0));
-        st = want;
-        return GPX_OK;
-    };
-    if (masked && n <= reserve_below) GPX_TRY(switch_to(masked));
     // Tapered outer block: the width that suits a factorisation of the rows that are LEFT (wide while the trailing
     // update is the longer of the two, narrow once the step is bound by the panel chain); widths only ever shrink
     // and each divides the one before, so every panel stays aligned to its own width.  Lock-step batches and a
@@ -641,12 +415,11 @@ int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t
     bool host_paced = may_block && !bt && n <= tune().host_paced;
     if (host_paced) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(user, &cs) != hipSuccess) (void)hipGetLastError();
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess) (void)hipGetLastError();
         else if (cs != hipStreamCaptureStatusNone) host_paced = false;
     }
     while (true) {
         const int64_t r = k0 + kb;
-        if (masked && n - r <= reserve_below) GPX_TRY(switch_to(masked));
         GPX_HIP(hipStreamWaitEvent(st, ep, 0));                 // panel k is factored
         if (r >= n) {
             if (g_hook && !bt) GPX_TRY(g_hook->fn(g_hook->user, n, ep));
@@ -668,7 +441,7 @@ int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t
             // every CU slot taken and ran for as long as the update did (n = 8192 with 512-wide blocks: the left half 504 us
             // beside a 441 us update, the right half 107 us after it; profiles/r04_timeline_n8192_nb512_before_gate.txt).
             // An event recorded on the panel's stream right behind its wait gates the rest of the update.
-            if ((bt ? tune().gate_batch != 0 : true) && N - r <= tune().gate_rows) {
+            if (!bt && N - r <= tune().gate_rows) {
                 GPX_TRY(g_la.get(&e_gate));
                 GPX_HIP(hipEventRecord(e_gate, q));
             }
@@ -702,24 +475,12 @@ int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t
         if (g_hook && !bt) GPX_TRY(g_hook->fn(g_hook->user, r, ep_k));
         k0 = r; kb = kb1;
     }
-    if (st != user) {
-        GPX_TRY(g_la.get(&e));
-        GPX_HIP(hipEventRecord(e, st));
-        GPX_HIP(hipStreamWaitEvent(user, e, 0));
-    }
-    g_leaf_pipe = false;
     return GPX_OK;
 }
 
 }  // namespace gpx
 
 using namespace gpx;
-
-extern "C" int gpx_debug_leaf_stamps(void *dev_buffer)
-{
-    gpx::g_leaf_stamps = (unsigned long long *)dev_buffer;
-    return GPX_OK;
-}
 
 extern "C" {
 

@@ -645,7 +645,7 @@ static int trsv_t(const T *L, int64_t n, int64_t ldl, T *b, T *x, int transpose,
     GPX_TRY(scratch((size_t)nbt * sLinv * sizeof(T), &scr));
     T *Linv = (T *)scr;
     const int aligned = (((uintptr_t)L) % (2 * sizeof(T)) == 0) && (ldl % 2 == 0);
-    const int ablate = (int)tune().trsv_ablate;   // timing diagnostics only
+    const int ablate = 0;                          // (timing-only ablations of the step kernels: compile-time edits now)
     const int64_t nb = cdiv(ncols, TB);
     auto width = [&](int64_t blk) { return (int)std::min<int64_t>(TB, ncols - blk * TB); };
     // operator form: square systems of at least two full blocks, aligned rows, one system
@@ -677,18 +677,12 @@ static int trsv_t(const T *L, int64_t n, int64_t ldl, T *b, T *x, int transpose,
         if (fresh) GPX_TRY(trsv_ops_prepare<T>(L, n, ldl, buf, st, dtype, ops ? std::min(ops->built, nfull) : 0, nfull));
         if (ops) { ops->valid = true; ops->built = nfull; }
         const T *W = (const T *)buf, *Wt = W + nfull * BS, *Tf = Wt + 2 * nfull * BS, *Tb = Tf + nfull * BS;
-        const bool wide = tune().trsv_op_parts == 32;
-        const int NCH = wide ? OB / (TBT / 32) : OB / (TBT / 8);
+        const int NCH = OB / (TBT / 32);        // 32 lanes per row (the 8-lane form was measured slower and went in round 6)
         if (!transpose) {
             for (int64_t k = 0; k < nfull; ++k) {
                 const int64_t k0 = k * OB, far0 = k0 + OB;
                 const int64_t nfar = k > 0 ? cdiv(n - far0, 64) : 0;
-                if (wide)
-                    hipLaunchKernelGGL((trsv_op_kernel<T, true, 32>), dim3((unsigned)(NCH + nfar)), dim3(TBT), 0, st, W + k * BS,
-                                       k > 0 ? Tf + k * BS : (const T *)nullptr, L, ldl, b, x, n, k0, k0 - OB, k > 0 ? OB : 0, far0, n,
-                                       NCH, aligned);
-                else
-                    hipLaunchKernelGGL((trsv_op_kernel<T, true, 8>), dim3((unsigned)(NCH + nfar)), dim3(TBT), 0, st, W + k * BS,
+                hipLaunchKernelGGL((trsv_op_kernel<T, true, 32>), dim3((unsigned)(NCH + nfar)), dim3(TBT), 0, st, W + k * BS,
                                        k > 0 ? Tf + k * BS : (const T *)nullptr, L, ldl, b, x, n, k0, k0 - OB, k > 0 ? OB : 0, far0, n,
                                        NCH, aligned);
             }
@@ -713,12 +707,7 @@ static int trsv_t(const T *L, int64_t n, int64_t ldl, T *b, T *x, int transpose,
                 const int64_t k0 = k * OB, q0 = k0 + OB;
                 const int qjb = (k + 1 < nfull) ? OB : (int)rag;
                 const int64_t nfar = qjb > 0 ? cdiv(k0, 128) : 0;
-                if (wide)
-                    hipLaunchKernelGGL((trsv_op_kernel<T, false, 32>), dim3((unsigned)(NCH + nfar)), dim3(TBT), 0, st, Wt + k * BS,
-                                       qjb > 0 ? Tb + k * BS : (const T *)nullptr, L, ldl, b, x, n, k0, q0, qjb, (int64_t)0, k0, NCH,
-                                       aligned);
-                else
-                    hipLaunchKernelGGL((trsv_op_kernel<T, false, 8>), dim3((unsigned)(NCH + nfar)), dim3(TBT), 0, st, Wt + k * BS,
+                hipLaunchKernelGGL((trsv_op_kernel<T, false, 32>), dim3((unsigned)(NCH + nfar)), dim3(TBT), 0, st, Wt + k * BS,
                                        qjb > 0 ? Tb + k * BS : (const T *)nullptr, L, ldl, b, x, n, k0, q0, qjb, (int64_t)0, k0, NCH,
                                        aligned);
             }
@@ -766,15 +755,10 @@ static int trsv_t(const T *L, int64_t n, int64_t ldl, T *b, T *x, int transpose,
             route_hit(RT_TRSV_OPS);
             const int64_t nfull = n / OB, BS = (int64_t)OB * OB;
             const T *W = (const T *)ops->buf, *Wt = W + nfull * BS, *Tb = Wt + 3 * nfull * BS;
-            const bool wide = tune().trsv_op_parts == 32;
-            const int NCH = wide ? OB / (TBT / 32) : OB / (TBT / 8);
+            const int NCH = OB / (TBT / 32);
             for (int64_t k = kpart - 1; k >= 0; --k) {
                 const int64_t k0 = k * OB, q0 = k0 + OB;
-                if (wide)
-                    hipLaunchKernelGGL((trsv_op_kernel<T, false, 32>), dim3((unsigned)(NCH + cdiv(k0, 128))), dim3(TBT), 0, st, Wt + k * BS,
-                                       Tb + k * BS, L, ldl, b, x, n, k0, q0, OB, (int64_t)0, k0, NCH, aligned);
-                else
-                    hipLaunchKernelGGL((trsv_op_kernel<T, false, 8>), dim3((unsigned)(NCH + cdiv(k0, 128))), dim3(TBT), 0, st, Wt + k * BS,
+                hipLaunchKernelGGL((trsv_op_kernel<T, false, 32>), dim3((unsigned)(NCH + cdiv(k0, 128))), dim3(TBT), 0, st, Wt + k * BS,
                                        Tb + k * BS, L, ldl, b, x, n, k0, q0, OB, (int64_t)0, k0, NCH, aligned);
             }
         }
@@ -960,8 +944,7 @@ int trsm_right_lt(int dtype, const void *L, int64_t n, int64_t ldl, void *X, int
             return GPX_OK;
         }
     }
-    const int64_t nb_env = tune().trsm_nb;
-    const int64_t NB = nb_env > 0 ? nb_env : (n >= 8192 ? 512 : 256);
+    const int64_t NB = n >= 8192 ? 512 : 256;
     auto Lp = [&](int64_t r, int64_t c) { return (const char *)L + (r * ldl + c) * es; };
     auto Xp = [&](int64_t c) { return (char *)X + c * es; };
     for (int64_t k0 = 0; k0 < n; k0 += NB) {

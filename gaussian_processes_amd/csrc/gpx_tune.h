@@ -19,12 +19,8 @@ namespace gpx {
 //   X2(field, "ENV", dflt_f64, dflt_f32) int64 value per dtype: field[dtype]; the variable overrides both
 #define GPX_TUNE_LIST(X, XF, XS, X2)                                                                                   \
     /* ---- MFMA GEMM (gpx_gemm.hip) ---- */                                                                           \
-    XF(gemm_no_dsplit, "GPX_GEMM_NO_DSPLIT")                                                                           \
-    XF(gemm_no_vec_c, "GPX_GEMM_NO_VEC_C")                                                                             \
     XF(gemm_no_fast, "GPX_GEMM_NO_FAST")                                                                               \
-    X(gemm_atomic_c, "GPX_GEMM_ATOMIC_C", 1)                                                                           \
     X(gemm_ablate, "GPX_GEMM_ABLATE", 0)                                                                               \
-    X(gemm_bm, "GPX_GEMM_BM", 128)                                                                                     \
     X(gemm_pad_lds, "GPX_GEMM_PAD_LDS", 0)                                                                             \
     X(gemm_bn64_tiles, "GPX_GEMM_BN64_TILES", 256)                                                                     \
     X(gemm_exact, "GPX_GEMM_EXACT", 1)                                                                                 \
@@ -35,7 +31,6 @@ namespace gpx {
     X(fit_ops_ahead, "GPX_FIT_OPS_AHEAD", 1)                                                                           \
     X(fit_ops_ahead_min, "GPX_FIT_OPS_AHEAD_MIN", 8192)                                                                \
     X(fit_ops_tail, "GPX_FIT_OPS_TAIL", 4)                                                                             \
-    XS(fit_ops_group, "GPX_FIT_OPS_GROUP", 0)                                                                          \
     XS(batch_max, "GPX_BATCH_MAX", 1)                                                                                  \
     X(io_block_bytes, "GPX_IO_BLOCK_BYTES", (int64_t)64 << 20)                                                         \
     X(kmat_panel_bytes, "GPX_KMAT_PANEL_BYTES", (int64_t)256 << 20)                                                    \
@@ -55,32 +50,20 @@ namespace gpx {
     XS(leaf, "GPX_LEAF", 0)                                                                                            \
     X2(leaf4_rows, "GPX_LEAF4_ROWS", 8192, 5120)                                                                       \
     X2(panel_pad_lds, "GPX_PANEL_PAD_LDS", 8 * 1024, 40 * 1024)                                                        \
-    X(tall_rows, "GPX_POTRF_TALL_ROWS", (int64_t)1 << 40)                                                              \
     X(fold_rows, "GPX_POTRF_FOLD_ROWS", 16384)                                                                         \
     X(fold_k, "GPX_POTRF_FOLD_K", 256)                                                                                 \
     /* ---- blocked factorisation (gpx_potrf.hip) ---- */                                                              \
     XS(potrf_nb, "GPX_POTRF_NB", 0)                                                                                    \
     XF(potrf_trsm_rows, "GPX_POTRF_TRSM_ROWS")                                                                         \
     X(potrf_inv_max, "GPX_POTRF_INV_MAX", 16384)                                                                       \
-    X(leaf_pipe, "GPX_LEAF_PIPE", -1)                                                                                  \
-    X(leaf_ablate, "GPX_LEAF_ABLATE", 16)                                                                              \
-    X(potrf_nested, "GPX_POTRF_NESTED", 0)                                                                             \
-    X(potrf_nested_rows, "GPX_POTRF_NESTED_ROWS", 16384)                                                               \
-    X(reserve_cus, "GPX_POTRF_RESERVE_CUS", -1)                                                                        \
-    X(reserve_cus_batch, "GPX_POTRF_RESERVE_CUS_BATCH", -1)                                                            \
-    X(reserve_below, "GPX_POTRF_RESERVE_BELOW", 4096)                                                                  \
     XF(no_lookahead, "GPX_POTRF_NO_LOOKAHEAD")                                                                         \
     X(taper, "GPX_POTRF_TAPER", 1)                                                                                     \
     X(host_paced, "GPX_POTRF_HOST_PACED", 16384)                                                                       \
-    X(gate_batch, "GPX_POTRF_GATE_BATCH", 0)                                                                           \
     X(gate_rows, "GPX_POTRF_GATE_ROWS", 16384)                                                                         \
     /* ---- solves (gpx_solve.hip) ---- */                                                                             \
     X(trsv_ops, "GPX_TRSV_OPS", 1)                                                                                     \
     X(trsv_ops_min, "GPX_TRSV_OPS_MIN", 10240)                                                                         \
-    X(trsv_ablate, "GPX_TRSV_ABLATE", 0)                                                                               \
-    X(trsv_op_parts, "GPX_TRSV_OP_PARTS", 32)                                                                          \
     X(trsm_ops, "GPX_TRSM_OPS", 1)                                                                                     \
-    X(trsm_nb, "GPX_TRSM_NB", 0)                                                                                       \
     /* ---- diagnostics (gpx_runtime.hip) ---- */                                                                      \
     XF(roctx, "GPX_ROCTX")
 

@@ -184,8 +184,6 @@ int gpx_prof_read(int cls, double *launches, double *total_ms, double *total_wor
 #define GPX_ROUTE_MG_BCAST_SAG   11   /* multi-GPU panel broadcast: scatter + all-gather (point to point)     */
 #define GPX_ROUTE_FIT_OPS_AHEAD  12   /* gpx_gp_fit: block operators of the solves built beside the factorisation */
 #define GPX_ROUTE_TRSM_OPS       13   /* X L^-T (posterior covariance, inverse): in-block step as one product with inv(L_kk) */
-#define GPX_ROUTE_PANEL_NESTED   14   /* a 768 / 1024-wide panel factored as a blocked factorisation of its own (in-panel look-ahead) */
-#define GPX_ROUTE_PANEL_TALL     15   /* a tall 256-column panel: diagonal block on the resident kernel, the rows below as products with inv(L_256) */
 int gpx_debug_route_count(int route, int64_t *count);
 /* roctx ranges pushed so far (GPX_ROCTX=1: every gpx_gp_* call and every launch class below it is a nested host range for
  * `rocprofv3 --marker-trace`; libroctx64.so is loaded on first use; 0 while the switch is off) */

@@ -18,115 +18,6 @@ from oracle import gp_oracle as orc
 
 pytestmark = pytest.mark.gpu
 
-TALL_ENVS = ("GPX_POTRF_TALL_ROWS", "GPX_POTRF_FOLD_ROWS", "GPX_POTRF_NB", "GPX_POTRF_TWO_PART_ROWS")
-
-
-def _clear(monkeypatch):
-    for k in TALL_ENVS:
-        monkeypatch.delenv(k, raising=False)
-
-
-@pytest.mark.parametrize("dtype", ["float64", "float32"])
-@pytest.mark.parametrize("N,d", [(2048, 3), (1990, 3), (4171, 5), (1024, 2)])
-def test_tall_panel_route_vs_oracle(monkeypatch, dtype, N, d):
-    """Every 256-column panel with rows below it takes the tall route (GPX_POTRF_TALL_ROWS=0): once with the update by the
-    panel to its left folded into the panel (a product of the tall route's own), once with that update left to the
-    trailing update; the right-hand side rides along as one more row of every panel.  Factor, alpha, log_lh and mean
-    against the oracle; the resident route must agree to round-off."""
-    X, y, Xo = orc.synth_inputs(N, d, 16)
-    h, w, s = 1.1, 0.6 * np.sqrt(d), 0.8
-    o = orc.OracleGP("gaussian", (h, w), X, y, s)
-    f64 = dtype == "float64"
-    out = {}
-    for label, env in (("resident", {}),
-                       ("tall_fold", {"GPX_POTRF_TALL_ROWS": "0"}),
-                       ("tall_nofold", {"GPX_POTRF_TALL_ROWS": "0", "GPX_POTRF_FOLD_ROWS": "0"})):
-        _clear(monkeypatch)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        _lib.route_reset()
-        g = gp.GP(gp.GaussianKernel(h, w), X, y, s=s, dtype=dtype)
-        llh = float(g.log_lh)
-        tall = _lib.route_count(_lib.ROUTE_PANEL_TALL)
-        if label == "resident":
-            assert tall == 0
-        else:
-            assert tall >= N // 256 - 1, (label, tall)
-        out[label] = (llh, np.tril(np.array(g.Lxx, dtype=np.float64)), np.array(g.inv_Kxx_y, dtype=np.float64),
-                      np.array(g.mean(Xo), dtype=np.float64))
-        np.testing.assert_allclose(llh, o.log_lh, rtol=1e-10 if f64 else 1e-4, err_msg=label)
-        np.testing.assert_allclose(out[label][1], o.Lxx, rtol=1e-9 if f64 else 2e-3, atol=1e-11 if f64 else 2e-4, err_msg=label)
-        np.testing.assert_allclose(out[label][2], o.inv_Kxx_y, rtol=1e-8 if f64 else 2e-3, atol=1e-10 if f64 else 2e-3, err_msg=label)
-        np.testing.assert_allclose(out[label][3], o.mean(Xo), rtol=1e-8 if f64 else 1e-3, atol=1e-10 if f64 else 1e-3, err_msg=label)
-    for label in ("tall_fold", "tall_nofold"):
-        np.testing.assert_allclose(out[label][0], out["resident"][0], rtol=1e-12 if f64 else 1e-5)
-        np.testing.assert_allclose(out[label][1], out["resident"][1], rtol=1e-10 if f64 else 1e-3, atol=1e-12 if f64 else 1e-4)
-
-
-def test_tall_panel_route_raw_potrf_and_failing_minor():
-    """gpx_d_potrf (no rider row, caller's stream) with the tall route forced: the factor against numpy's, and a pivot
-    <= 0 in any of the four diagonal workgroups still reports LAPACK's first failing minor (the products that follow the
-    failed chain run on garbage and must not hang or fault)."""
-    N = 1104
-    rng = np.random.RandomState(5)
-    B = rng.randn(N, N)
-    A0 = B @ B.T + N * np.eye(N)
-    lib = _lib.load()
-    from gaussian_processes_amd.device import DeviceBuffer, sync
-    os.environ["GPX_POTRF_TALL_ROWS"] = "0"
-    try:
-        dA = DeviceBuffer.from_host(A0)
-        info = DeviceBuffer((4,), np.int32).zero()
-        _lib.route_reset()
-        _lib.check(lib.gpx_d_potrf(_lib.F64, dA.ptr, N, N, info.ptr, None))
-        sync()
-        assert _lib.route_count(_lib.ROUTE_PANEL_TALL) > 0
-        assert int(info.to_host()[0]) == 0
-        np.testing.assert_allclose(np.tril(dA.to_host()), np.linalg.cholesky(A0), rtol=1e-10, atol=1e-10)
-        dA.free()
-        for bad in (0, 70, 130, 200, 255, 256, 300, 700, 1103):
-            A = A0.copy()
-            A[bad, bad] = -1.0
-            dA = DeviceBuffer.from_host(A)
-            info.zero()
-            _lib.check(lib.gpx_d_potrf(_lib.F64, dA.ptr, N, N, info.ptr, None))
-            sync()
-            assert int(info.to_host()[0]) == bad + 1, (bad, int(info.to_host()[0]))
-            dA.free()
-        info.free()
-    finally:
-        del os.environ["GPX_POTRF_TALL_ROWS"]
-
-
-@pytest.mark.parametrize("dtype", ["float64", "float32"])
-def test_tall_panel_route_above_16384_rows(monkeypatch, dtype):
-    """N = 20480 with GPX_POTRF_TALL_ROWS=16384 (the route is opt-in: measured neutral at N = 65536, see gpx_panel.hip): only
-    the panels with more than 16384 rows take it, un-folded, without a rider row.  Against the resident route and against
-    sampled oracle kernel rows: K[rows] alpha = y[rows]."""
-    N, d = 20480, 8
-    X, y, _ = orc.synth_inputs(N, d, 8)
-    h, w, s = 1.0, 0.5 * np.sqrt(d), 1.0
-    f64 = dtype == "float64"
-    out = {}
-    for label, env in (("tall", {"GPX_POTRF_TALL_ROWS": "16384"}), ("resident", {})):
-        _clear(monkeypatch)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        _lib.route_reset()
-        g = gp.GP(gp.GaussianKernel(h, w), X, y, s=s, dtype=dtype)
-        llh = float(g.log_lh)
-        tall = _lib.route_count(_lib.ROUTE_PANEL_TALL)
-        assert (tall > 0) == (label == "tall"), (label, tall)
-        out[label] = (llh, np.array(g.inv_Kxx_y, dtype=np.float64))
-    np.testing.assert_allclose(out["tall"][0], out["resident"][0], rtol=1e-12 if f64 else 1e-5)
-    np.testing.assert_allclose(out["tall"][1], out["resident"][1], rtol=1e-8 if f64 else 5e-3, atol=1e-10 if f64 else 5e-3)
-    rows = np.random.RandomState(0).choice(N, 12, replace=False)
-    Kr = orc.kernel_matrix("gaussian", "K", X[rows], X, (h, w))
-    Kr[np.arange(len(rows)), rows] += s * s
-    res = np.abs(Kr @ out["tall"][1] - y[rows]).max() / np.abs(y).max()
-    assert res < (1e-9 if f64 else 2e-3), res
-
-
 # ------------------------------------------------------------------------- the asm leaf's self-check --
 def test_asm_leaf_self_check_passes_on_this_device(monkeypatch):
     """The asm-scheduled leaf (csrc/gpx_leaf.h: wait states MEASURED on gfx950) is compared, on the device the process

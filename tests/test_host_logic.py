@@ -49,7 +49,7 @@ def test_library_never_calls_getenv():
     csrc = os.path.join(ROOT, "gaussian_processes_amd", "csrc")
     table = open(os.path.join(csrc, "gpx_tune.h")).read()
     names = set(re.findall(r'"(GPX_[A-Z0-9_]+)"', table)) | {"GPX_POTRF_WIDTHS", "GPX_MG_BCAST", "GPX_RCCL_LIB"}
-    assert len(names) >= 55
+    assert 30 <= len(names) <= 45, len(names)       # round 6: pruned from 61 (the routes two rounds of measurement left neutral or slower)
     design = open(os.path.join(ROOT, "DESIGN.md")).read()
     missing = [n for n in sorted(names) if ("`%s`" % n) not in design and ("`%s=" % n) not in design]
     assert not missing, missing

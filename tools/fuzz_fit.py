@@ -11,7 +11,7 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 SW = [{}, {"GPX_FIT_OPS_AHEAD_MIN": "1024", "GPX_FIT_OPS_TAIL": "1"}, {"GPX_POTRF_TWO_PART_ROWS": "0", "GPX_POTRF_TWO_PART_BATCH": "0"},
       {"GPX_FIT_RIDE_MAX": "0", "GPX_TRSV_OPS_MIN": "1024"}, {"GPX_POTRF_NB": "512"}, {"GPX_POTRF_HOST_PACED": "0"},
-      {"GPX_POTRF_TALL_ROWS": "0"}, {"GPX_POTRF_TALL_ROWS": "0", "GPX_POTRF_FOLD_ROWS": "0"}, {"GPX_LEAF": "1"}, {"GPX_LEAF": "5"}]
+      {"GPX_POTRF_FOLD_ROWS": "0"}, {"GPX_LEAF": "1"}, {"GPX_LEAF": "5"}]
 bad = 0
 for c in range(cases):
     n = int(rng.choice([rng.randint(1, 300), rng.randint(300, 2200), 512 * rng.randint(1, 9), rng.randint(2200, 5200)]))

@@ -17,7 +17,6 @@ cd $ROOT
 python3 tools/mlii_bench.py > $OUT/mlii_bench.log 2>&1 || exit 1
 echo "mlii done"
 ( python3 tools/panel_stamps.py 8192 24; python3 tools/panel_stamps.py 8192 4 ) > $OUT/panel_stamps.log 2>&1 || exit 1
-GPX_POTRF_RES=0 GPX_LEAF_PIPE=1 python3 tools/leaf_time.py > $OUT/leaf_stamps.log 2>&1 || exit 1
 python3 tools/syrk_bench.py > $OUT/syrk_bench_standalone.log 2>&1 || exit 1
 ( for r in 0 256; do echo "GPX_POTRF_RES=$r"; GPX_POTRF_RES=$r python3 tools/panel_bench.py 8192 64 128 256; GPX_POTRF_RES=$r python3 tools/panel_bench.py 65536 256 512 1024; done ) > $OUT/panel_bench.log 2>&1 || exit 1
 tools/res_ab.sh $OUT/res_ab > $OUT/res_ab.log 2>&1 || exit 1
