@@ -49,6 +49,7 @@ _SIGNATURES = {
     "gpx_device_info": (c_int, [c_int, c_char_p, c_size_t, c_int_p, c_int_p, POINTER(c_uint64)]),
     "gpx_malloc": (c_int, [POINTER(c_void_p), c_size_t]),
     "gpx_free": (c_int, [c_void_p]),
+    "gpx_mem_info": (c_int, [ctypes.POINTER(c_size_t), ctypes.POINTER(c_size_t)]),
     "gpx_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "gpx_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "gpx_memcpy_d2d": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -150,6 +151,8 @@ _SIGNATURES = {
     "gpx_mg_adopt_comm": (c_int, [c_void_p, c_void_p]),
     "gpx_mg_set_chunks": (c_int, [c_void_p, c_int]),
     "gpx_mg_set_owner_first": (c_int, [c_void_p, c_int]),
+    "gpx_mg_set_wait_timing": (c_int, [c_void_p, c_int]),
+    "gpx_mg_schedule_info": (c_int, [c_void_p, c_int_p, c_int_p, c_int_p, c_int_p]),
     "gpx_mg_device_ptrs": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int64)]),
     "gpx_mg_create_rehearsal": (c_int, [POINTER(c_void_p), c_int, c_int, c_int64, c_int, c_int64, c_int, c_int, c_void_p, c_int64,
                                         c_void_p, c_double, c_double]),
@@ -248,6 +251,13 @@ def device_info(device=0):
                                  ctypes.byref(mem)))
     return {"name": name.value.decode(), "cus": cus.value, "clock_mhz": mhz.value,
             "hbm_bytes": mem.value}
+
+
+def mem_free():
+    """Free HBM on the current device, bytes."""
+    f, t = c_size_t(0), c_size_t(0)
+    check(load().gpx_mem_info(ctypes.byref(f), ctypes.byref(t)))
+    return int(f.value)
 
 
 def route_count(route):

@@ -79,9 +79,12 @@ struct RoctxRange {
 };
 const char *prof_class_name(int cls);
 
+// launches the calling thread makes while this is > 0 are not recorded (the asm leaf's self-check: its nested launches
+// are no part of anybody's fit)
+extern thread_local int g_prof_mute;
 struct ProfScope {
     hipStream_t st; int rec; RoctxRange range;
-    ProfScope(int cls, double work, hipStream_t s) : st(s), rec(g_prof_on ? prof_begin(cls, work, s) : -1), range(prof_class_name(cls)) {}
+    ProfScope(int cls, double work, hipStream_t s) : st(s), rec(g_prof_on && g_prof_mute == 0 ? prof_begin(cls, work, s) : -1), range(prof_class_name(cls)) {}
     ~ProfScope() { if (rec >= 0) prof_end(rec, st); }
 };
 

@@ -15,6 +15,9 @@
 #include <string>
 #include <unistd.h>
 #include <fcntl.h>
+#include <errno.h>
+#include <time.h>
+#include <atomic>
 #include <stdlib.h>
 #include <sys/stat.h>
 #include <cmath>
@@ -146,20 +149,31 @@ int gpx_gp_save(gpx_gp_t *g, const char *path)
     hd.s = g->s; hd.logdet = h4[0]; hd.yta = h4[1];
     // written under a temporary name and renamed when complete: a failure never leaves a truncated checkpoint
     // under the final name
-    // (a UNIQUE temporary in the target's directory -- mkstemp -- so that two saves to the same path, e.g. every rank of
-    //  a multi-rank job checkpointing, never write or unlink each other's file; the last rename wins, each is complete)
-    std::string tmp_path = std::string(path) + ".XXXXXX";
-    const int tfd = mkstemp(&tmp_path[0]);
+    // (a UNIQUE temporary in the target's directory so that two saves to the same path, e.g. every rank of a multi-rank
+    //  job checkpointing, never write or unlink each other's file; the last rename wins, each is complete.  Created with
+    //  open(O_CREAT | O_EXCL, 0666) under a random name: the KERNEL applies the caller's umask, as fopen would -- round 5
+    //  read the umask with umask(0) / umask(old) to fix up mkstemp's 0600, which is process-wide and not thread-safe)
+    std::string tmp_path;
+    int tfd = -1;
+    {
+        static std::atomic<unsigned> seq{0};
+        struct timespec ts;
+        (void)clock_gettime(CLOCK_MONOTONIC, &ts);
+        unsigned long long r = (unsigned long long)ts.tv_nsec ^ ((unsigned long long)getpid() << 20) ^ (unsigned long long)(uintptr_t)g;
+        for (int attempt = 0; attempt < 64 && tfd < 0; ++attempt) {
+            r = r * 6364136223846793005ull + 1442695040888963407ull + seq.fetch_add(1);
+            char suffix[24];
+            snprintf(suffix, sizeof(suffix), ".%012llx.tmp", r >> 16);
+            tmp_path = std::string(path) + suffix;
+            tfd = open(tmp_path.c_str(), O_CREAT | O_EXCL | O_WRONLY | O_CLOEXEC, 0666);
+            if (tfd < 0 && errno != EEXIST) break;
+        }
+    }
     if (tfd < 0) { set_error("gpx_gp_save: cannot create a temporary file beside %s", path); return GPX_ERR_ARG; }
     struct Unlink { const std::string &p; bool armed = true; ~Unlink() { if (armed) (void)unlink(p.c_str()); } } cleanup{tmp_path};
     File fp;
     fp.f = fdopen(tfd, "wb");
     if (!fp.f) { (void)close(tfd); set_error("gpx_gp_save: cannot open %s for writing", tmp_path.c_str()); return GPX_ERR_ARG; }
-    {   // mkstemp creates 0600; a checkpoint is an ordinary file: what fopen would have given it under the caller's umask
-        const mode_t um = umask(0);
-        (void)umask(um);
-        (void)fchmod(tfd, 0666 & ~um);
-    }
     bool ok = fwrite(&hd, sizeof(hd), 1, fp.f) == 1;
     std::vector<double> v;
     GPX_TRY(vec_d2h_f64(g, g->x, n * g->d, v)); ok = ok && fwrite(v.data(), 8, v.size(), fp.f) == v.size();

@@ -73,8 +73,11 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(256) void kmat_kernel(const T *__restrict__ x1, int64_t n,
                                                    const T *__restrict__ x2, int64_t m, int d,
                                                    KParams kp, int tri, int aligned,
-                                                   T *__restrict__ out, int64_t ld)
+                                                   T *__restrict__ out, int64_t ld, int rblk)
 {
+    // rblk: row blocks of KM_ROWS per workgroup.  The column points are staged (transposed) ONCE and serve rblk row
+    // blocks (round 6: one block per workgroup paid the 32 KB staging pass and its barrier per 64 rows, and half of
+    // the 524 k workgroups of a lower-only N = 65536 build existed only to find themselves above the diagonal)
     constexpr int VEC = Vec<T>::N;
     constexpr int TN = 64 * VEC;
     constexpr int TNP = TN + VEC;                     // padded row of s2: the transposing stores below
@@ -84,16 +87,16 @@ __global__ __launch_bounds__(256) void kmat_kernel(const T *__restrict__ x1, int
     T *s1 = reinterpret_cast<T *>(smem_raw);          // [KM_ROWS][d]
     T *s2 = s1 + (MODE == 4 ? (size_t)KM_ROWS * d : (size_t)0);   // [d][TNP]  (transposed: lanes contiguous)
 
-    const int64_t row0 = (int64_t)blockIdx.y * KM_ROWS;
+    const int64_t row00 = (int64_t)blockIdx.y * KM_ROWS * rblk;
     const int64_t col0 = (int64_t)blockIdx.x * TN;
-    if (tri == GPX_LOWER && col0 > row0 + KM_ROWS - 1) return;   // strictly above the diagonal
+    if (tri == GPX_LOWER && col0 > row00 + (int64_t)KM_ROWS * rblk - 1) return;   // every row block strictly above the diagonal
 
     const int tid = threadIdx.x;
     // stage the two point sets (coalesced: consecutive threads -> consecutive elements)
     // (the tile's points are contiguous in memory: element idx of the tile is x[row0 * d + idx])
     {
-        const int64_t lim1 = (n - row0) * d;
-        const T *g1 = x1 + row0 * d;
+        const int64_t lim1 = (n - row00) * d;           // (MODE 4 is launched with rblk = 1)
+        const T *g1 = x1 + row00 * d;
         if (MODE == 4)
             for (int idx = tid; idx < KM_ROWS * d; idx += 256) s1[idx] = (idx < lim1) ? g1[idx] : (T)0;
         const int64_t lim2 = (m - col0) * d;
@@ -113,6 +116,11 @@ __global__ __launch_bounds__(256) void kmat_kernel(const T *__restrict__ x1, int
     const int cbase = lane * VEC;
     const T c1 = (T)kp.c[0], c2 = (T)kp.c[1], c3 = (T)kp.c[2], c4 = (T)kp.c[3];
     const T dadd = (T)kp.diag_add;
+#pragma unroll 1
+  for (int q = 0; q < rblk; ++q) {
+    const int64_t row0 = row00 + (int64_t)q * KM_ROWS;
+    if (row0 >= n) break;
+    if (tri == GPX_LOWER && col0 > row0 + KM_ROWS - 1) continue;  // this row block is strictly above the diagonal
     // workgroup-uniform: all 64 x TN entries exist, stores are 16-byte aligned, the diagonal (where diag_add
     // goes) does not cross the tile
     const bool interior = aligned && row0 + KM_ROWS <= n && col0 + TN <= m &&
@@ -141,6 +149,7 @@ __global__ __launch_bounds__(256) void kmat_kernel(const T *__restrict__ x1, int
 #pragma unroll
             for (int r = 0; r < KM_RB; ++r)
                 arow[r] = x1 + min(row0 + wave_u * 16 + rb + r, n - 1) * d;
+#pragma unroll 8
             for (int k = 0; k < d; ++k) {
                 T b[VEC];
 #pragma unroll
@@ -216,6 +225,7 @@ __global__ __launch_bounds__(256) void kmat_kernel(const T *__restrict__ x1, int
             }
         }
     }
+  }
 }
 
 template <typename T>
@@ -237,7 +247,9 @@ static int launch_kmat(const void *x1, int64_t n, const void *x2, int64_t m, int
         return GPX_ERR_UNSUPPORTED;
     }
     const int aligned = (ld % VEC == 0) && (((uintptr_t)out) % 16 == 0);
-    dim3 grid((unsigned)cdiv(m, TN), (unsigned)cdiv(n, KM_ROWS));
+    // four row blocks per workgroup once that still leaves several workgroups per CU
+    const int rblk = (mode != 4 && cdiv(m, TN) * cdiv(n, 4 * KM_ROWS) >= 2048) ? 4 : 1;
+    dim3 grid((unsigned)cdiv(m, TN), (unsigned)cdiv(n, (int64_t)KM_ROWS * rblk));
     dim3 block(256);
     const T *a = (const T *)x1;
     const T *b = (const T *)x2;
@@ -259,7 +271,7 @@ static int launch_kmat(const void *x1, int64_t n, const void *x2, int64_t m, int
             GPX_HIP(hipFuncSetAttribute((const void *)kmat_kernel<T, MODE>,                   \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
         hipLaunchKernelGGL((kmat_kernel<T, MODE>), grid, block, smem, st, a, n, b, m, d, kp,  \
-                           tri, aligned, o, ld);                                              \
+                           tri, aligned, o, ld, rblk);                                        \
     } while (0)
     switch (mode) {
     case 0: GPX_KM_LAUNCH(0); break;

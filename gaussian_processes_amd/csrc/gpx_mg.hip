@@ -215,6 +215,7 @@ struct gpx_mg {
     int info_host = 0;
     double ms[GPX_MG_TIMING_N] = {0};            // 0 .. 7: stages and chain (gpx_mg_timing); 8 .. 10: exposed waits (gpx_mg_timing_ex)
     bool timing = true;
+    bool wait_timing = false;                     // T_WAIT pairs around the update stream's waits (gpx_mg_set_wait_timing): opt-in
     // REHEARSAL of one rank's share of a `world`-rank run in ONE process (gpx_mg_create_rehearsal): no communicator; a
     // panel this rank does not own is copied out of a resident factor of the same matrix (reh_L: n + 1 rows, the rider row
     // included), and every broadcast is followed by a delay that models the transfer at reh_GBps per xGMI link
@@ -265,7 +266,9 @@ static int mg_order(gpx_mg *g, hipStream_t from, hipStream_t to)
 
 struct MgTimer {
     gpx_mg *g; hipStream_t st; size_t idx; bool on;
-    MgTimer(gpx_mg *g_, int cls, hipStream_t s, int64_t panel = -1) : g(g_), st(s), idx(0), on(g_->timing)
+    // T_WAIT: two timing-enabled records around every hipStreamWaitEvent of the update stream -- 2 (chunks + 1) marker packets
+    // per owned panel on the stream that bounds the step -- only when the caller asked for the exposed-wait figures
+    MgTimer(gpx_mg *g_, int cls, hipStream_t s, int64_t panel = -1) : g(g_), st(s), idx(0), on(g_->timing && (cls != T_WAIT || g_->wait_timing))
     {
         if (!on) return;
         if (g->tev_next + 2 > g->tev.size()) {
@@ -324,6 +327,7 @@ static int mg_bcast(gpx_mg *g, void *dev_ptr, size_t count, int root, hipStream_
         return GPX_OK;
     }
     if (g->world == 1 && !tune().force_collectives) return GPX_OK;
+    if (!g->comm) { set_error("this handle has no communicator (it was handed to another handle by gpx_mg_adopt_comm, or never connected)"); return GPX_ERR_ARG; }
     GPX_NCCL(g_rccl.Broadcast(dev_ptr, dev_ptr, count, nccl_type(g->dtype), root, g->comm, st));
     return GPX_OK;
 }
@@ -340,6 +344,7 @@ static int mg_allreduce(gpx_mg *g, void *dev_ptr, size_t count, int dtype, int o
         return GPX_OK;
     }
     if (g->world == 1 && !tune().force_collectives) return GPX_OK;
+    if (!g->comm) { set_error("this handle has no communicator (it was handed to another handle by gpx_mg_adopt_comm, or never connected)"); return GPX_ERR_ARG; }
     const ncclDataType_t t = dtype == GPX_F64 ? ncclFloat64 : (dtype == GPX_F32 ? ncclFloat32 : ncclInt32);
     GPX_NCCL(g_rccl.AllReduce(dev_ptr, dev_ptr, count, t, op == 0 ? ncclSum : ncclMax, g->comm, st));
     return GPX_OK;
@@ -858,6 +863,23 @@ int gpx_mg_set_owner_first(gpx_mg_t *g, int on)
 {
     MG_ENTER(g);
     g->owner_first = on ? 1 : 0;                                  // (local scheduling only: ranks need not agree, but a run should)
+    return GPX_OK;
+}
+
+int gpx_mg_set_wait_timing(gpx_mg_t *g, int on)
+{
+    MG_ENTER(g);
+    g->wait_timing = on != 0;
+    return GPX_OK;
+}
+
+int gpx_mg_schedule_info(gpx_mg_t *g, int *owner_first, int *chunks, int *sag, int *wait_timing)
+{
+    MG_ENTER(g);
+    if (owner_first) *owner_first = g->owner_first ? 1 : 0;
+    if (chunks) *chunks = (int)g->bcast_chunks;
+    if (sag) *sag = g->bcast_sag ? 1 : 0;
+    if (wait_timing) *wait_timing = g->wait_timing ? 1 : 0;
     return GPX_OK;
 }
 

@@ -632,22 +632,36 @@ int64_t panel_res_max()
 // the process and says so on stderr (gpx_debug_leaf_selfcheck: 1 passed, 2 failed -> fallback, 0 not run yet).
 static thread_local int g_leaf_force = 0;                      // the self-check's own launches: 1 / 4 / 5, no check
 static std::mutex g_leaf_mu;
-static int g_leaf_state[RES_MAXDEV] = {};                      // 0 unknown, 1 ok, 2 failed (guarded by g_leaf_mu)
+static int g_leaf_state[RES_MAXDEV] = {};                      // 0 unknown, 1 ok, 2 failed, 3 never verified (guarded by g_leaf_mu)
+static int g_leaf_tries[RES_MAXDEV] = {};                      // attempts that could not run (guarded by g_leaf_mu)
+constexpr int LEAF_CHECK_TRIES = 3;
 static int leaf_selfcheck_run(int dev, hipStream_t st);
+// true: the asm-scheduled leaf may be used on the current device.  While the check has not PASSED the compiler-scheduled
+// leaf is used (round 6: "could not run" used to count as a pass -- under HBM pressure the unverified leaf ran, and every
+// panel launch repeated the attempt, host matrix, allocations and syncs included, on the factorisation's critical path);
+// after LEAF_CHECK_TRIES attempts that could not run (no memory for its ~135 MB, a stream capture open) the device keeps
+// the compiler-scheduled leaf for the rest of the process and says so once.
 static bool leaf_asm_ok(hipStream_t st = nullptr)
 {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return true; }
-    if (dev < 0 || dev >= RES_MAXDEV) return true;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (dev < 0 || dev >= RES_MAXDEV) return false;
     std::lock_guard<std::mutex> lk(g_leaf_mu);
     if (g_leaf_state[dev] == 0) {
+        ++g_prof_mute;
         const int rc = leaf_selfcheck_run(dev, st);
-        if (rc == 1 || rc == 2) g_leaf_state[dev] = rc;         // (anything else: could not run now -- e.g. a capture is open: ask again)
+        --g_prof_mute;
+        if (rc == 1 || rc == 2) g_leaf_state[dev] = rc;
+        else if (++g_leaf_tries[dev] >= LEAF_CHECK_TRIES) g_leaf_state[dev] = 3;
         if (rc == 2)
             fprintf(stderr, "[gpx] WARNING: the asm-scheduled MFMA leaf failed its self-check on device %d: "
                             "falling back to the compiler-scheduled leaf (GPX_LEAF=1)\n", dev);
+        else if (g_leaf_state[dev] == 3)
+            fprintf(stderr, "[gpx] NOTE: the asm-scheduled MFMA leaf could not be verified on device %d (%d attempts: no memory "
+                            "for the check, or a stream capture was open): keeping the compiler-scheduled leaf (GPX_LEAF=1)\n",
+                    dev, LEAF_CHECK_TRIES);
     }
-    return g_leaf_state[dev] != 2;
+    return g_leaf_state[dev] == 1;
 }
 
 template <typename T>
@@ -787,10 +801,17 @@ static int leaf_selfcheck_run(int dev, hipStream_t st)
 {
     (void)dev;
     constexpr int64_t N = RES_MAXSTEPS * IB, LD = N, GM = 4096, GK = 512;
-    // not while any capture is open on this thread's streams (synchronising calls are illegal then)
+    // not while `st` is being captured (synchronising calls are illegal then).  A capture open on ANOTHER stream of this
+    // thread in global or thread-local mode would be invalidated by the check's hipMalloc / hipMemcpy: the thread's capture
+    // mode is relaxed for the duration of the check (its launches go to streams of its own, never into a capture)
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return 0; }
     if (cs != hipStreamCaptureStatusNone) return 0;
+    struct CaptureModeGuard {
+        hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed; bool ok = false;
+        CaptureModeGuard() { ok = hipThreadExchangeStreamCaptureMode(&mode) == hipSuccess; if (!ok) (void)hipGetLastError(); }
+        ~CaptureModeGuard() { if (ok) (void)hipThreadExchangeStreamCaptureMode(&mode); }
+    } capture_mode__;
     // a full-mantissa SPD panel: A = B B^T / 8 + 2 I, B (N x 32) from a fixed linear congruential stream
     constexpr int64_t KB = 32;
     std::vector<double> hA((size_t)N * LD), hB((size_t)N * KB);
@@ -882,8 +903,8 @@ bool panel_res_fold(int64_t rows, int64_t kpre, int64_t kb, size_t es, int64_t l
 
 }  // namespace gpx
 
-// the state of the asm leaf's self-check on the current device: 0 not run yet, 1 passed, 2 failed (the library then uses the
-// compiler-scheduled leaf); run_now != 0 runs it if it has not run
+// the state of the asm leaf's self-check on the current device: 0 not run yet, 1 passed, 2 failed, 3 could not be run in three
+// attempts (2 and 3: the library uses the compiler-scheduled leaf); run_now != 0 runs it if it has not run
 extern "C" int gpx_debug_leaf_selfcheck(int run_now, int *state)
 {
     GPX_TRY(gpx::ensure_device());

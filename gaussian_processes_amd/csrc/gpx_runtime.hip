@@ -118,6 +118,7 @@ namespace gpx {
 // under g_prof_mu, a scope ends the record it began (by index), and the registry is capped so a
 // forgotten gpx_prof_enable(1) cannot grow without bound.
 bool g_prof_on = false;
+thread_local int g_prof_mute = 0;
 struct ProfRec { int cls; double work; hipEvent_t a, b; };
 static std::vector<ProfRec> g_prof;
 static std::mutex g_prof_mu;
@@ -341,6 +342,16 @@ int gpx_free(void *dptr)
 {
     if (!dptr) return GPX_OK;
     GPX_HIP(hipFree(dptr));
+    return GPX_OK;
+}
+
+int gpx_mem_info(size_t *free_bytes, size_t *total_bytes)
+{
+    GPX_TRY(ensure_device());
+    size_t f = 0, t = 0;
+    GPX_HIP(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
     return GPX_OK;
 }
 

@@ -268,8 +268,21 @@ class NativeDistributedGP(object):
         self._check(self.lib.gpx_mg_set_chunks(self.h, int(chunks)))
 
     def set_owner_first(self, on):
-        """The owner of the next panel factors it before it starts its own trailing update (default: world >= 4)."""
+        """The owner of the next panel factors it before it starts its own trailing update (default: on for world >= 2;
+        GPX_MG_OWNER_FIRST=0 / 1 overrides; `schedule_info()` says what is in effect)."""
         self._check(self.lib.gpx_mg_set_owner_first(self.h, 1 if on else 0))
+
+    def set_wait_timing(self, on):
+        """Time the update stream's waits for panels that have not arrived (`timing(extended=True)`: exposed_wait ...).
+        Off by default: two timing-enabled event records per wait on the stream that bounds the step."""
+        self._check(self.lib.gpx_mg_set_wait_timing(self.h, 1 if on else 0))
+
+    def schedule_info(self):
+        """The schedule parameters IN EFFECT for the next fit, read back from the handle."""
+        v = [ctypes.c_int(0) for _ in range(4)]
+        self._check(self.lib.gpx_mg_schedule_info(self.h, *[ctypes.byref(x) for x in v]))
+        return {"owner_first": bool(v[0].value), "chunks": v[1].value,
+                "panel_bcast": "scatter+allgather" if v[2].value else "one collective", "wait_timing": bool(v[3].value)}
 
     def timing(self, extended=False):
         if extended:
@@ -332,11 +345,18 @@ def tune_schedule(candidates, measure, dist=None, budget_s=60.0, clock=time.perf
             dist.all_reduce(v, op=dist.ReduceOp.MAX)
             mine, spent = float(v[0].item()), float(v[1].item())
         row = dict(c)
-        row["fit_s"] = round(mine, 5)
+        if np.isfinite(mine):
+            row["fit_s"] = round(mine, 5)
+        else:                                              # some rank could not set this candidate up: dropped on all
+            row["fit_s"] = None
+            row["skipped"] = "a rank could not set this layout up"
         table.append(row)
         if spent > budget_s:
             break
-    best = min(table, key=lambda r: (r["fit_s"], r["nb"], r["chunks"], r["sag"]))
+    done = [r for r in table if r["fit_s"] is not None]
+    if not done:
+        raise RuntimeError("tune_schedule: no candidate could be measured")
+    best = min(done, key=lambda r: (r["fit_s"], r["nb"], r["chunks"], r["sag"]))
     return {k: best[k] for k in ("nb", "chunks", "sag")}, table
 
 
@@ -377,6 +397,8 @@ def rehearse_rank(N, d, rank, world, X, y, params, s, dtype_id=_lib.F64, nb=None
             mg.set_bcast(sag)
         if owner_first is not None:
             mg.set_owner_first(owner_first)
+        mg.set_wait_timing(True)
+        sched = mg.schedule_info()                      # what is IN EFFECT (the arguments may have been None)
         mg.set_data(X, y)
         runs = []
         p = np.ascontiguousarray(params, dtype=np.float64)
@@ -418,7 +440,8 @@ def rehearse_rank(N, d, rank, world, X, y, params, s, dtype_id=_lib.F64, nb=None
         own = chain[chain > 0]
         return {
             "what": "rehearsal of rank %d of %d on one GPU: measured compute, MODELLED transfer" % (rank, world),
-            "N": N, "d": d, "dtype": dtype, "nb": nbv, "chunks": chunks, "owner_first": owner_first, "panel_bcast": "scatter+allgather" if sag else "one collective (ring)",
+            "N": N, "d": d, "dtype": dtype, "nb": nbv, "chunks": sched["chunks"], "owner_first": sched["owner_first"],
+            "panel_bcast": "scatter+allgather" if sched["panel_bcast"] == "scatter+allgather" else "one collective (ring)",
             "model": {"link_GBps_sustained_assumed": link_GBps, "latency_us_per_collective_assumed": latency_us,
                       "ring_us": "bytes / rate + latency", "scatter_allgather_us": "2 bytes / (P rate) + 2 latency",
                       "remote_owner_chain": "this rank's own measured chain for its nearest owned panel, from the fit before"},
@@ -545,6 +568,7 @@ def bench_distributed(args, X, y, Xo, params, s, dtype_id, residual_check=None):
             if old_gp is not None:
                 old_gp.close()
             g_.set_data(X, y)
+            g_.set_wait_timing(True)                    # the bench reports exposed chain time per rank
             holder["gp"] = g_
             with Watchdog(wd_s, "first fit + predict (N=%d, world %d, nb %d)" % (N, world, g_.nb), rank):
                 llh0 = g_.fit(params, s)
@@ -582,15 +606,29 @@ def bench_distributed(args, X, y, Xo, params, s, dtype_id, residual_check=None):
                 cands = [c for c in cands if c["sag"] == want]
 
             def measure(c):
+                """One untimed-by-the-bench fit of candidate c: seconds, or inf when its layout cannot be set up here (the
+                old handle plus the new layout are in HBM together while the communicator moves: a rank may run out).  The
+                verdict is agreed on by tune_schedule's MAX all-reduce: inf on one rank drops the candidate on all."""
                 if holder["gp"].nb != c["nb"]:
+                    ok = 1
+                    if backend == "rccl":
+                        # can every rank hold the second layout?  agreed BEFORE anybody enters the collective set-up
+                        need = (N + 1) * (-(-(-(-N // c["nb"])) // world)) * c["nb"] * (8 if dtype_id == _lib.F64 else 4) * 1.1
+                        ok = 1 if _lib.mem_free() > need else 0
+                        v = torch.tensor([ok], dtype=torch.int32)
+                        dist.all_reduce(v, op=dist.ReduceOp.MIN)
+                        ok = int(v.item())
+                    if not ok:
+                        return float("inf")
                     make(c["nb"])
                 gp = holder["gp"]
                 gp.set_chunks(c["chunks"])
                 gp.set_bcast(c["sag"])
                 dist.barrier()
-                t0 = time.perf_counter()
-                gp.fit(params, s)
-                return time.perf_counter() - t0
+                with Watchdog(wd_s, "tuning fit (nb %d, chunks %d, sag %d)" % (c["nb"], c["chunks"], c["sag"]), rank):
+                    t0 = time.perf_counter()
+                    gp.fit(params, s)
+                    return time.perf_counter() - t0
 
             budget = float(os.environ.get("GPX_BENCH_TUNE_BUDGET_S", "90"))
             if cands:
@@ -655,7 +693,8 @@ def bench_distributed(args, X, y, Xo, params, s, dtype_id, residual_check=None):
             "rccl_nranks": comm_infos[0]["rccl_nranks"],
             "comm_info_per_rank": comm_infos,
             "schedule_autotune": sched_tune,
-            "bcast_chunks": (sched_tune["chosen"]["chunks"] if sched_tune else int(os.environ.get("GPX_MG_BCAST_CHUNKS", "4"))),
+            "bcast_chunks": gp.schedule_info()["chunks"],
+            "schedule_in_effect": gp.schedule_info(),
             "watchdog_s": wd_s,
             "first_fit_log_lh": first[0],
             "panel_bcast": gp.comm_info()["panel_bcast"],

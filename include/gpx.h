@@ -126,6 +126,8 @@ int gpx_device_info(int device, char *name, size_t name_len, int *cus,
 
 int gpx_malloc(void **dptr, size_t bytes);
 int gpx_free(void *dptr);
+/* free / total HBM of the current device, bytes (hipMemGetInfo) */
+int gpx_mem_info(size_t *free_bytes, size_t *total_bytes);
 int gpx_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream);
 int gpx_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream);
 int gpx_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream);
@@ -491,6 +493,13 @@ int gpx_mg_adopt_comm(gpx_mg_t *mg, gpx_mg_t *from);
 /* on != 0: the owner of the next panel factors it before it starts its own share of the trailing update (the panel is the
  * serial chain of the run; default: on for world >= 2, GPX_MG_OWNER_FIRST=0 / 1 overrides). */
 int gpx_mg_set_owner_first(gpx_mg_t *mg, int on);
+/* on != 0: also time how long the update stream waits in front of panels (chunks) that have not arrived -- values [8] .. [10]
+ * of gpx_mg_timing_ex; costs two timing-enabled event records per wait on the stream that bounds the step, so it is OFF by
+ * default (bench.py and the rehearsal turn it on; with it off those three values read 0). */
+int gpx_mg_set_wait_timing(gpx_mg_t *mg, int on);
+/* the schedule parameters IN EFFECT for the next fit (any pointer may be NULL): owner-first, row chunks per panel
+ * broadcast, scatter + all-gather broadcast form, wait timing */
+int gpx_mg_schedule_info(gpx_mg_t *mg, int *owner_first, int *chunks, int *sag, int *wait_timing);
 /* Row chunks per panel broadcast for the following fits (1 .. 16; collective: the same on every rank). */
 int gpx_mg_set_chunks(gpx_mg_t *mg, int chunks);
 /* REHEARSAL: rank `rank` of a `world`-rank run in ONE process on one GPU, without a communicator.  The rank builds, factors,

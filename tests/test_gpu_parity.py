@@ -466,15 +466,15 @@ def test_syrk_bc_block_cyclic_vs_numpy(n, nb, P, k):
         sync()
         got = dC.to_host()
         ref = C.copy()
+        rows_all = np.arange(row_begin, n)
         for jl, j in enumerate(gblocks):
             if jl < first:
                 continue
-            for cc in range(nb):
-                gc = j * nb + cc
-                if gc >= n:
-                    continue       # padding columns beyond the matrix: rows >= gc do not exist
-                rows = np.arange(max(row_begin, gc), n)
-                ref[rows, jl * nb + cc] -= panel[rows - k0] @ panel[gc - k0]
+            gcols = j * nb + np.arange(nb)
+            gcols = gcols[gcols < n]           # padding columns beyond the matrix: rows >= gc do not exist
+            upd = panel[rows_all - k0] @ panel[gcols - k0].T                    # one product per block column ...
+            upd[rows_all[:, None] < gcols[None, :]] = 0.0                       # ... masked to global row >= global column
+            ref[row_begin:, jl * nb:jl * nb + gcols.size] -= upd
         np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-10)
 
 

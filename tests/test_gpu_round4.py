@@ -602,7 +602,7 @@ def test_bench_four_ranks_line_schema_over_gloo():
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    env.update(GPX_DIST_BACKEND="gloo", GPX_BENCH_SINGLE_DEVICE="1", GPX_BENCH_TUNE_BUDGET_S="20")
+    env.update(GPX_DIST_BACKEND="gloo", GPX_BENCH_SINGLE_DEVICE="1", GPX_BENCH_TUNE_BUDGET_S="5")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--problem-n", "6144",
                         "--problem-d", "4", "--problem-m", "64", "--steps", "1", "--warmup", "1"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
@@ -624,6 +624,10 @@ def test_bench_four_ranks_line_schema_over_gloo():
     best = min(tune["table"], key=lambda r: (r["fit_s"], r["nb"], r["chunks"], r["sag"]))
     assert tune["chosen"] == {k: best[k] for k in ("nb", "chunks", "sag")}
     assert out["panel_bcast"].startswith("scatter") == bool(tune["chosen"]["sag"]) and out["bcast_chunks"] == tune["chosen"]["chunks"]
+    # (round 6) what the handle says is IN EFFECT, read back after the tuning pass
+    eff = out["schedule_in_effect"]
+    assert eff["chunks"] == tune["chosen"]["chunks"] and eff["owner_first"] is True and eff["wait_timing"] is True
+    assert eff["panel_bcast"].startswith("scatter") == bool(tune["chosen"]["sag"])
     assert ("nb=%d" % tune["chosen"]["nb"]) in out["config"]["parallelism"]
     for row in out["stage_and_chain_ms_per_rank"]:
         assert row["exposed_wait"] >= 0 and row["exposed_wait_max"] >= 0 and row["exposed_waits_over_20us"] >= 0

@@ -4,6 +4,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gaussian_processes_amd import _lib
 from gaussian_processes_amd.device import DeviceBuffer, Event, sync
+if len(sys.argv) > 4:
+    _lib.LIB_PATH = os.path.abspath(sys.argv[4])       # another build of the library (A/B of a kernel change)
 lib = _lib.load()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 d = int(sys.argv[2]) if len(sys.argv) > 2 else 32
