@@ -18,7 +18,7 @@ OK = 0
 ERR_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_NOMEM, ERR_UNSUPPORTED, ERR_INTERNAL = -1, -2, -3, -4, -5, -6
 (ROUTE_TRSV_OPS, ROUTE_TRSV_STEPS, ROUTE_PANEL_RES, ROUTE_PANEL_CHAIN, ROUTE_FIT_RIDE, ROUTE_FIT_TWO_SOLVES,
  ROUTE_GEMM_FAST, ROUTE_GEMM_GENERIC, ROUTE_SYRK_EXACT, ROUTE_SYRK_PATCH, ROUTE_MG_BCAST_ONE, ROUTE_MG_BCAST_SAG,
- ROUTE_FIT_OPS_AHEAD, ROUTE_TRSM_OPS) = range(14)
+ ROUTE_FIT_OPS_AHEAD, ROUTE_TRSM_OPS, ROUTE_POTRF_PAIR) = range(15)
 F64, F32 = 0, 1
 KERNEL_GAUSSIAN, KERNEL_PERIODIC = 0, 1
 FULL, LOWER = 0, 1

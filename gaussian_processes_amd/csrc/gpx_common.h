@@ -47,7 +47,7 @@ int  ensure_device();   // GPX_OK when a GPU is usable
 // point of decision.  Tests that force a route through an environment switch assert it here.
 enum Route { RT_TRSV_OPS = 0, RT_TRSV_STEPS = 1, RT_PANEL_RES = 2, RT_PANEL_CHAIN = 3, RT_FIT_RIDE = 4,
              RT_FIT_TWO_SOLVES = 5, RT_GEMM_FAST = 6, RT_GEMM_GENERIC = 7, RT_SYRK_EXACT = 8, RT_SYRK_PATCH = 9,
-             RT_MG_BCAST_ONE = 10, RT_MG_BCAST_SAG = 11, RT_FIT_OPS_AHEAD = 12, RT_TRSM_OPS = 13, RT_COUNT = 14 };
+             RT_MG_BCAST_ONE = 10, RT_MG_BCAST_SAG = 11, RT_FIT_OPS_AHEAD = 12, RT_TRSM_OPS = 13, RT_POTRF_PAIR = 14, RT_COUNT = 15 };
 void route_hit(int route);
 
 // LAPACK-style info of a factorisation as the host sees it: > 0 "not positive definite" (the caller's business),

@@ -418,6 +418,77 @@ int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t
         if (hipStreamIsCapturing(st, &cs) != hipSuccess) (void)hipGetLastError();
         else if (cs != hipStreamCaptureStatusNone) host_paced = false;
     }
+    // ---- PAIR phase (round 6): while many rows are left, the far trailing matrix is updated once per TWO 1024-wide panels
+    // with ONE product of depth K = 2048 -- the operand is simply both block columns of L side by side -- instead of two of
+    // depth 1024: every tile of C is read, accumulated into and written once per 2048 columns, and a tile's prologue /
+    // epilogue is paid once per 2048 (the update kernel alone at M = 32768: 0.929 of the fp64 peak at K = 1024, 0.943 at
+    // K = 3072; fp32, whose tiles take half as long, 0.896 -> 0.928).  Both panels of the NEXT pair are factored on the side
+    // stream while that product runs:
+    //   invariant: panels A = [k0, k0 + 1024) and B = [k0 + 1024, k0 + 2048) are factored / in flight (epA, epB); everything
+    //   before A has been applied everywhere; A has been applied to B's block column only.
+    //     st: U_a  block column C <- (A | B), K = 2048         q: panel C   (after U_a)
+    //     st: U_b  block column D <- (A | B), K = 2048         q: V = D <- C, K = 1024 (after U_b and panel C); panel D
+    //     st: U_c  columns beyond D <- (A | B), K = 2048       (the long one: both panels and V hide under it)
+    // Round 4's "pair phase" at n = 8192 (K = 512, second panel of a pair dispatched onto a chip the update had filled)
+    // lost; here a panel is 2 - 10 ms beside an update of 20 - 120 ms, and the phase ends (A applied to the rest, back to one
+    // panel per update) before the rows that are left make the panels the longer of the two.
+    // MEASURED (profiles/r06_ab_pair_phase.log, r06_timeline_n65536_{pair,nopair}.txt): N = 65536 fp64 1.3248 -> 1.3133 s and
+    // 1.359 -> 1.3405 s on two boxes (-0.9 ... -1.4 %).  Not because the deeper tiles run faster in situ -- per tile the
+    // K = 2048 launches reach 0.916 of peak, the K = 1024 ones 0.921 -- but because a fit has 60 long launches instead of
+    // 81: fewer ramps and tails, fewer cross-stream hand-offs.  fp32 at N = 32768 (three pairs at most) gains nothing
+    // (96.5 vs 96.4 ms): off there (GPX_POTRF_PAIR_ROWS = rows that must be left beyond a pair; 0 = never).
+    const int64_t pair_rows = (bt || nb != 1024 || xrows > 1) ? 0 : tune().pair_rows[dtype == GPX_F64 ? 0 : 1];
+    // (every panel of the phase is 1024 wide: with the taper on, the widths shrink once <= 12288 rows are left)
+    auto pair_ok = [&](int64_t k) { return pair_rows > 0 && n - (k + 4 * 1024) >= pair_rows && nominal(k + 1024) == 1024 &&
+                                           nominal(k + 2048) == 1024 && nominal(k + 3072) == 1024; };
+    if (kb == 1024 && pair_ok(k0)) {
+        // entry: B's block column <- A, then panel B (the only panel of the phase that no update hides)
+        const int64_t rB = k0 + 1024;
+        hipEvent_t epA = ep, epB;
+        GPX_HIP(hipStreamWaitEvent(st, epA, 0));
+        GPX_TRY(syrk_bc(dtype, N, rB, A, lda, rB, rB + 1024, at(k0, k0), lda, k0, 1024, 1024, 1, 0, st, info_dev, nullptr));
+        GPX_TRY(g_la.get(&e));
+        GPX_HIP(hipEventRecord(e, st));
+        GPX_HIP(hipStreamWaitEvent(q, e, 0));
+        GPX_TRY(g_la.get(&epB));
+        GPX_TRY(potrf_panel(dtype, A, lda, N, rB, rB, 1024, info_dev, q, nullptr, 0, epB));
+        if (g_hook) GPX_TRY(g_hook->fn(g_hook->user, rB, epA));
+        route_hit(RT_POTRF_PAIR);
+        while (pair_ok(k0)) {
+            const int64_t rC = k0 + 2048, rD = rC + 1024, rE = rD + 1024;
+            GPX_HIP(hipStreamWaitEvent(st, epB, 0));            // A and B are factored (B follows A on q)
+            GPX_TRY(syrk_bc(dtype, N, rC, A, lda, rC, rD, at(k0, k0), lda, k0, 2048, 1024, 1, 0, st, info_dev, nullptr));   // U_a
+            GPX_TRY(g_la.get(&e));
+            GPX_HIP(hipEventRecord(e, st));
+            GPX_HIP(hipStreamWaitEvent(q, e, 0));
+            hipEvent_t epC, epD;
+            GPX_TRY(g_la.get(&epC));
+            GPX_TRY(potrf_panel(dtype, A, lda, N, rC, rC, 1024, info_dev, q, nullptr, 0, epC));
+            GPX_TRY(syrk_bc(dtype, N, rD, A, lda, rD, rE, at(k0, k0), lda, k0, 2048, 1024, 1, 0, st, info_dev, nullptr));   // U_b
+            GPX_TRY(g_la.get(&e));
+            GPX_HIP(hipEventRecord(e, st));
+            GPX_HIP(hipStreamWaitEvent(q, e, 0));
+            // V: a panel-class product on the panel stream (it is part of the chain to panel D and runs beside U_c)
+            GPX_TRY(gemm_nt(dtype, N - rD, 1024, 1024, at(rD, rC), lda, at(rD, rC), lda, at(rD, rD), lda, -1.0, GPX_LOWER, rD, rD, q));
+            GPX_TRY(g_la.get(&epD));
+            GPX_TRY(potrf_panel(dtype, A, lda, N, rD, rD, 1024, info_dev, q, nullptr, 0, epD));
+            if (rE < n)
+                GPX_TRY(syrk_bc(dtype, N, rE, A, lda, rE, n, at(k0, k0), lda, k0, 2048, 1024, 1, 0, st, info_dev, nullptr)); // U_c
+            if (g_hook) {
+                GPX_TRY(g_hook->fn(g_hook->user, rC, epB));
+                GPX_TRY(g_hook->fn(g_hook->user, rD, epC));
+            }
+            k0 = rC; epA = epC; epB = epD;
+        }
+        // exit: A <- everything beyond B (K = 1024); then the loop below carries on with B as "the panel in flight"
+        const int64_t rB2 = k0 + 1024, rC2 = k0 + 2048;
+        GPX_HIP(hipStreamWaitEvent(st, epA, 0));
+        if (rC2 < n)
+            GPX_TRY(syrk_bc(dtype, N, rC2, A, lda, rC2, n, at(k0, k0), lda, k0, 1024, 1024, 1, 0, st, info_dev, nullptr));
+        GPX_TRY(g_la.get(&e_rest));
+        GPX_HIP(hipEventRecord(e_rest, st));
+        k0 = rB2; kb = 1024; ep = epB;
+    }
     while (true) {
         const int64_t r = k0 + kb;
         GPX_HIP(hipStreamWaitEvent(st, ep, 0));                 // panel k is factored

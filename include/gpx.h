@@ -186,6 +186,7 @@ int gpx_prof_read(int cls, double *launches, double *total_ms, double *total_wor
 #define GPX_ROUTE_MG_BCAST_SAG   11   /* multi-GPU panel broadcast: scatter + all-gather (point to point)     */
 #define GPX_ROUTE_FIT_OPS_AHEAD  12   /* gpx_gp_fit: block operators of the solves built beside the factorisation */
 #define GPX_ROUTE_TRSM_OPS       13   /* X L^-T (posterior covariance, inverse): in-block step as one product with inv(L_kk) */
+#define GPX_ROUTE_POTRF_PAIR     14   /* a factorisation that entered the pair phase: far trailing updates of depth K = 2048, one per two panels */
 int gpx_debug_route_count(int route, int64_t *count);
 /* roctx ranges pushed so far (GPX_ROCTX=1: every gpx_gp_* call and every launch class below it is a nested host range for
  * `rocprofv3 --marker-trace`; libroctx64.so is loaded on first use; 0 while the switch is off) */

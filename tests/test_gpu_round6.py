@@ -182,3 +182,51 @@ def test_mlii_optimize_improves_every_finite_restart():
     # the same answer as the reference's loop would give for the best restart: oracle value at the optimum
     o = orc.OracleGP("gaussian", (res["theta"][b, 0], res["theta"][b, 1]), X, y, res["theta"][b, 2])
     np.testing.assert_allclose(v[b], _raw_llh(o), rtol=1e-10)
+
+
+# --------------------------------------------------------------------------------- the pair phase of the factorisation --
+def _diag_any(g):
+    """diag(L) from the handle's HBM matrix, fp64 or fp32 storage."""
+    st = g._fit_pd()
+    lib = _lib.load()
+    A, lda = ctypes.c_void_p(), ctypes.c_int64()
+    _lib.check(lib.gpx_gp_device_ptrs(st.handle, ctypes.byref(A), ctypes.byref(lda), None, None, None, None))
+    es = 8 if g._dtype == _lib.F64 else 4
+    out = np.empty(g._n, dtype=np.float64 if es == 8 else np.float32)
+    _lib.check(lib.gpx_memcpy2d_d2h(out.ctypes.data_as(ctypes.c_void_p), es, A, (lda.value + 1) * es, es, g._n, None))
+    return out.astype(np.float64)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_pair_phase_k2048_updates_vs_one_panel_per_update(monkeypatch, dtype):
+    """potrf()'s pair phase (far trailing updates of depth K = 2048, one per TWO 1024-wide panels, both panels of the next
+    pair factored on the side stream beside it; default for fp64 while >= 20480 rows lie beyond a pair) forced at
+    N = 13312 + 37 (ragged: the pairs, the exit step, then the tapering single-panel loop) against the default schedule of
+    that size (one panel per update): both against oracle kernel rows (K alpha = y), the log_lh identity from diag(L), and
+    each other (log_lh rtol 1e-12 / 1e-5: the same sums in a different association)."""
+    N, d = 13312 + 37, 6
+    X, y, Xo = orc.synth_inputs(N, d, 8)
+    h, w, s = 1.0, 0.5 * np.sqrt(d), 1.0
+    rows = np.unique(np.array([0, 1023, 1024, 2047, 2048, 4095, 4096, 5000, 8191, 8192, 12287, 12288, N - 2, N - 1]))
+    Krows = _krows(X, rows, h, w, s)
+    f64 = dtype == "float64"
+    out = {}
+    monkeypatch.setenv("GPX_POTRF_NB", "1024")             # (the taper would give 512-wide blocks at this size)
+    monkeypatch.setenv("GPX_FIT_RIDE_MAX", "0")            # (no rider row: the pair phase is for sizes beyond it)
+    for label, pr in (("pair", "2048"), ("single", "0")):
+        monkeypatch.setenv("GPX_POTRF_PAIR_ROWS", pr)
+        _lib.route_reset()
+        g = gp.GP(gp.GaussianKernel(h, w), X, y, s=s, dtype=dtype)
+        alpha = np.array(g.inv_Kxx_y, dtype=np.float64)
+        assert _lib.route_count(_lib.ROUTE_POTRF_PAIR) == (1 if label == "pair" else 0), label
+        np.testing.assert_allclose(Krows @ alpha, y[rows], rtol=1e-9 if f64 else 2e-3, atol=1e-10 if f64 else 2e-3, err_msg=label)
+        dg = _diag_any(g)
+        llh = float(g.log_lh)
+        np.testing.assert_allclose(llh, -0.5 * y @ alpha - np.log(dg).sum() - 0.5 * N * np.log(2 * np.pi),
+                                   rtol=1e-12 if f64 else 1e-5, err_msg=label)
+        out[label] = (llh, alpha, np.array(g.mean(Xo)))
+        del g
+        gc.collect()
+    np.testing.assert_allclose(out["pair"][0], out["single"][0], rtol=1e-12 if f64 else 1e-5)
+    np.testing.assert_allclose(out["pair"][1], out["single"][1], rtol=1e-8 if f64 else 5e-3, atol=1e-11 if f64 else 5e-3)
+    np.testing.assert_allclose(out["pair"][2], out["single"][2], rtol=1e-8 if f64 else 1e-3, atol=1e-11 if f64 else 1e-3)
