@@ -612,7 +612,7 @@ def measure_single(args, lib, _lib, N, d, m, dtid, npdt, steps, warmup, local_ra
         g = prof["gemm_trailing"]
         achieved = g["work"] / (g["ms"] * 1e-3) / 1e12
         roofline = {"bound": "mfma",
-                    "kernel": "gpx::gemm_nt_fast_kernel<%s, 128, 1, 128> (trailing SYRK updates of the factorisation)"
+                    "kernel": "gpx::gemm_nt_fast_kernel<%s, 128, 1, 0> (trailing SYRK updates of the factorisation)"
                               % ("double" if dtype_name == "f64" else "float"),
                     "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": None,

@@ -706,7 +706,7 @@ def bench_distributed(args, X, y, Xo, params, s, dtype_id, residual_check=None):
             # panel (chunk) that had not arrived (a hidden chain shows ~0 there whatever chain_* say)
             "stage_and_chain_ms_per_rank": all_chain,
             "roofline": ({"bound": "mfma",
-                          "kernel": "gpx::gemm_nt_fast_kernel<T, 128, 1, 128> (trailing SYRK updates) on rank 0",
+                          "kernel": "gpx::gemm_nt_fast_kernel<T, 128, 1, 0> (trailing SYRK updates) on rank 0",
                           "achieved": round(rank0_gemm["tflops"], 3), "peak": peak, "unit": "TFLOP/s",
                           "frac": round(rank0_gemm["tflops"] / peak, 4), "traffic": None,
                           "launches_per_step": rank0_gemm["launches_per_step"],

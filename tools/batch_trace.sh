@@ -31,7 +31,7 @@ for r in sub:
     gap = s - prev_end.get(q, s)
     prev_end[q] = e
     k = r["Kernel_Name"]
-    mark = "P" if "panel_res" in k else ("U" if "128, 1, 128" in k else " ")
+    mark = "P" if "panel_res" in k else ("U" if "128, 1, 0>" in k else " ")
     print("%9.1f %8.1f  end %9.1f  gap %6.1f  q=%-3s grid=%-7s y=%-3s %s %s" % (s, e - s, e, gap, q, r["Grid_Size_X"], r.get("Grid_Size_Y"), mark, short(k)))
 PY
 tail -3 $ROOT/gpurun_out/$tag.txt

@@ -15,5 +15,5 @@ for r in sub:
     q = r.get("Queue_Id")
     gap = s - prev_end.get(q, s)
     prev_end[q] = e
-    mark = "P" if "panel_res" in r["Kernel_Name"] else ("U" if "128, 1, 128" in r["Kernel_Name"] or "128,1,128" in r["Kernel_Name"].replace(" ", "") else " ")
+    mark = "P" if "panel_res" in r["Kernel_Name"] else ("U" if "128, 1, 0>" in r["Kernel_Name"] or "128,1,0>" in r["Kernel_Name"].replace(" ", "") else " ")
     print("%9.1f %8.1f  end %9.1f  gap %6.1f  q=%-3s grid=%-6s %s %s" % (s, e - s, e, gap, q, r["Grid_Size_X"], mark, short(r["Kernel_Name"])))

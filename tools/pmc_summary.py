@@ -41,7 +41,7 @@ def schedule(N):
     return out
 
 
-key = [k for k in res["FETCH_SIZE"][0] if "gemm_nt_fast_kernel<double, 128, 1, 128>" in k]
+key = [k for k in res["FETCH_SIZE"][0] if "gemm_nt_fast_kernel<double, 128, 1, 0>" in k]
 if key:
     k = key[0]
     n = res["FETCH_SIZE"][1][k]
@@ -49,39 +49,67 @@ if key:
     write = res["WRITE_SIZE"][0][k] / res["WRITE_SIZE"][1][k] * 1024.0
     N, fits = 65536, 2                                  # the profiled command runs one warm-up and one timed fit
     per_fit = n / float(fits)
-    # algorithmic bytes of one fit's trailing updates: every element of the lower triangle to the right of a panel is
-    # read and written once per panel (8 B each way is counted once: WRITE_SIZE sees the atomic add's write), and the
-    # panel itself is read once; divided by the launches of that kernel per fit
-    # Which launches are this kernel's: every outer step updates the next block column first (rows x w1) and then the rest
-    # of the lower triangle; a launch of at most 2600 tiles of 128 x 128 goes to the 128 x 64 kernel instead
-    # (csrc/gpx_gemm.hip, GPX_SYRK_BN64_TILES) and is not counted here.
-    BN64_TILES = 2600
-    sched = schedule(N)
+    # algorithmic bytes of one fit's trailing updates: every element of C that a launch updates is read and written once
+    # (8 B each way counted once: WRITE_SIZE sees the atomic add's write), and the launch's panel operand is read once;
+    # divided by the launches of that kernel per fit.  The launches are potrf()'s (csrc/gpx_potrf.hip), restated: the pair
+    # phase while >= PAIR_ROWS rows lie beyond a pair (far updates of depth K = 2048: U_a, U_b one block column each, U_c the
+    # rest; V is a panel-class product and not this kernel), then one panel per update with the next block column first.
+    # A launch of at most 2600 tiles of 128 x 128 goes to the 128 x 64 kernel (GPX_SYRK_BN64_TILES) and is not counted here.
+    BN64_TILES, PAIR_ROWS = 2600, 20480
+
+    def width(left):
+        return 256 if left <= 8192 else 512 if left <= 12288 else 1024
+
+    def nominal(k):
+        return min(1024, width(N - k))
+
+    def c_elems(r0, c0, c1):
+        """elements (row >= col) of rows >= r0, columns [c0, c1) of the N x N matrix"""
+        tot = 0.0
+        for c in (c0, ):
+            pass
+        a = max(c0, min(c1, r0))                      # columns [c0, a): full height from r0; [a, c1): from the diagonal
+        tot += (a - c0) * float(N - r0)
+        if c1 > a:
+            tot += (c1 - a) * float(N) - 0.5 * (a + c1 - 1) * (c1 - a)
+        return tot
+
+    launches = []                                      # (row_begin, c0, c1, K)
+
+    def pair_ok(k):
+        return N - (k + 4096) >= PAIR_ROWS and nominal(k + 1024) == 1024 and nominal(k + 2048) == 1024 and nominal(k + 3072) == 1024
+
+    k0, kb = 0, min(nominal(0), N)
+    if kb == 1024 and pair_ok(k0):
+        launches.append((k0 + 1024, k0 + 1024, k0 + 2048, 1024))
+        while pair_ok(k0):
+            rC, rD, rE = k0 + 2048, k0 + 3072, k0 + 4096
+            launches += [(rC, rC, rD, 2048), (rD, rD, rE, 2048), (rE, rE, N, 2048)]
+            k0 = rC
+        launches.append((k0 + 2048, k0 + 2048, N, 1024))
+        k0, kb = k0 + 1024, 1024
+    while k0 + kb < N:
+        r = k0 + kb
+        kb1 = min(nominal(r), N - r)
+        launches.append((r, r, r + kb1, kb))
+        if r + kb1 < N:
+            launches.append((r, r + kb1, N, kb))
+        k0, kb = r, kb1
     c_tot = p_tot = 0.0
     modelled = 0
-    for i, (k0, w) in enumerate(sched):
-        r = k0 + w
-        if r >= N:
-            break
-        w1 = sched[i + 1][1]
-        rows = N - r
-        launches = [(rows, w1, 8.0 * (rows * w1 - w1 * (w1 - 1) / 2.0))]              # next block column (its triangle's upper part is not touched)
-        rest = rows - w1
-        if rest > 0:
-            launches.append((rest, rest, 8.0 * rest * (rest + 1) / 2.0))
-        for m_, n_, cb in launches:
-            tr, tc = -(-rows // 128), -(-n_ // 128)                                     # (both launches start at row r: syrk_bc's M)
-            if min(tr * (tr + 1) // 2, tr * tc) <= BN64_TILES:
-                continue
-            c_tot += cb
-            p_tot += 8.0 * m_ * w                                                       # the panel rows this launch reads once
-            modelled += 1
+    for (r0, c0, c1, K) in launches:
+        tr, tc = -(-(N - r0) // 128), -(-(c1 - c0) // 128)
+        if min(tr * (tr + 1) // 2, tr * tc) <= BN64_TILES:
+            continue
+        c_tot += 8.0 * c_elems(r0, c0, c1)
+        p_tot += 8.0 * (N - min(r0, c0)) * K           # the panel rows this launch reads once (A and B operand rows coincide)
+        modelled += 1
     c_bytes, p_bytes = c_tot / max(1, modelled), p_tot / max(1, modelled)
     src = open(os.path.join(root, "gaussian_processes_amd", "csrc", "gpx_gemm.hip"), "rb").read()
     json.dump({
         "command": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE> --output-format csv -- python3 bench.py --steps 1 "
                    "--warmup 1 --no-cpu-baseline --no-secondary --no-prof  (two separate passes)",
-        "workload": "N=65536 d=32 f64, 1 GPU", "kernel": "gpx::gemm_nt_fast_kernel<double, 128, 1, 128>",
+        "workload": "N=65536 d=32 f64, 1 GPU", "kernel": "gpx::gemm_nt_fast_kernel<double, 128, 1, 0>",
         "dispatches_profiled": n, "launches_per_step": per_fit, "launches_per_step_modelled": modelled,
         "fetch_bytes_per_launch_corrected": fetch, "write_bytes_per_launch": write,
         "traffic_bytes_per_launch": fetch + write,
