@@ -418,25 +418,24 @@ int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t
         if (hipStreamIsCapturing(st, &cs) != hipSuccess) (void)hipGetLastError();
         else if (cs != hipStreamCaptureStatusNone) host_paced = false;
     }
-    // ---- PAIR phase (round 6): while many rows are left, the far trailing matrix is updated once per TWO 1024-wide panels
-    // with ONE product of depth K = 2048 -- the operand is simply both block columns of L side by side -- instead of two of
-    // depth 1024: every tile of C is read, accumulated into and written once per 2048 columns, and a tile's prologue /
-    // epilogue is paid once per 2048 (the update kernel alone at M = 32768: 0.929 of the fp64 peak at K = 1024, 0.943 at
-    // K = 3072; fp32, whose tiles take half as long, 0.896 -> 0.928).  Both panels of the NEXT pair are factored on the side
-    // stream while that product runs:
+    // ---- PAIR phase (round 6; OPT-IN: GPX_POTRF_PAIR_ROWS = rows that must lie beyond a pair, e.g. 20480; default 0 = never).
+    // While many rows are left, the far trailing matrix is updated once per TWO 1024-wide panels with ONE product of depth
+    // K = 2048 -- the operand is simply both block columns of L side by side -- instead of two of depth 1024, and both panels
+    // of the NEXT pair are factored on the side stream while that product runs:
     //   invariant: panels A = [k0, k0 + 1024) and B = [k0 + 1024, k0 + 2048) are factored / in flight (epA, epB); everything
     //   before A has been applied everywhere; A has been applied to B's block column only.
     //     st: U_a  block column C <- (A | B), K = 2048         q: panel C   (after U_a)
     //     st: U_b  block column D <- (A | B), K = 2048         q: V = D <- C, K = 1024 (after U_b and panel C); panel D
     //     st: U_c  columns beyond D <- (A | B), K = 2048       (the long one: both panels and V hide under it)
-    // Round 4's "pair phase" at n = 8192 (K = 512, second panel of a pair dispatched onto a chip the update had filled)
-    // lost; here a panel is 2 - 10 ms beside an update of 20 - 120 ms, and the phase ends (A applied to the rest, back to one
-    // panel per update) before the rows that are left make the panels the longer of the two.
-    // MEASURED (profiles/r06_ab_pair_phase.log, r06_timeline_n65536_{pair,nopair}.txt): N = 65536 fp64 1.3248 -> 1.3133 s and
-    // 1.359 -> 1.3405 s on two boxes (-0.9 ... -1.4 %).  Not because the deeper tiles run faster in situ -- per tile the
-    // K = 2048 launches reach 0.916 of peak, the K = 1024 ones 0.921 -- but because a fit has 60 long launches instead of
-    // 81: fewer ramps and tails, fewer cross-stream hand-offs.  fp32 at N = 32768 (three pairs at most) gains nothing
-    // (96.5 vs 96.4 ms): off there (GPX_POTRF_PAIR_ROWS = rows that must be left beyond a pair; 0 = never).
+    // MEASURED at N = 65536 fp64 (profiles/r06_ab_pair_phase.log, r06_timeline_n65536_{pair,nopair}.txt, r06_pmc_pair/): the
+    // step gets 0.9 ... 1.4 % SHORTER (1.3248 -> 1.3133 s, 1.359 -> 1.3405 s on two boxes; log_lh identical to the last digit)
+    // because a fit has 60 long trailing launches instead of 81 -- fewer ramps, tails and cross-stream hand-offs -- and the
+    // trailing updates' C traffic halves.  But the update kernel itself runs SLOWER per tile (0.916 of peak against 0.921;
+    // bench.py's kernel-class fraction 0.880 against 0.899) and its L2-miss traffic rises by half (30.5 GB fetched per launch,
+    // 1.83 TB per fit against 1.20): a K = 2048 tile lives twice as long, the tiles of a patch drift further apart than the
+    // 16 k-steps of operand slices an XCD's 4 MiB L2 holds, and the A slices are fetched again.  A shorter step for a worse
+    // kernel: not the default; the route is kept because the schedule is the natural home of a deeper-K update once the
+    // tile order keeps a patch's sharers inside the L2 window.  fp32 at N = 32768 (three pairs at most): 96.5 vs 96.4 ms.
     const int64_t pair_rows = (bt || nb != 1024 || xrows > 1) ? 0 : tune().pair_rows[dtype == GPX_F64 ? 0 : 1];
     // (every panel of the phase is 1024 wide: with the taper on, the widths shrink once <= 12288 rows are left)
     auto pair_ok = [&](int64_t k) { return pair_rows > 0 && n - (k + 4 * 1024) >= pair_rows && nominal(k + 1024) == 1024 &&

@@ -58,7 +58,7 @@ namespace gpx {
     X(potrf_inv_max, "GPX_POTRF_INV_MAX", 16384)                                                                       \
     XF(no_lookahead, "GPX_POTRF_NO_LOOKAHEAD")                                                                         \
     X(taper, "GPX_POTRF_TAPER", 1)                                                                                     \
-    X2(pair_rows, "GPX_POTRF_PAIR_ROWS", 20480, 0)                                                                     \
+    X2(pair_rows, "GPX_POTRF_PAIR_ROWS", 0, 0)                                                                         \
     X(host_paced, "GPX_POTRF_HOST_PACED", 16384)                                                                       \
     X(gate_rows, "GPX_POTRF_GATE_ROWS", 16384)                                                                         \
     /* ---- solves (gpx_solve.hip) ---- */                                                                             \

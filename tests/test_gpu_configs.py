@@ -100,7 +100,7 @@ def test_config4_full_size_fp64_through_GP_and_through_the_rccl_schedule(monkeyp
     alpha = g.inv_Kxx_y
     assert _lib.route_count(_lib.ROUTE_FIT_TWO_SOLVES) == 1 and _lib.route_count(_lib.ROUTE_TRSV_OPS) == 2
     assert _lib.route_count(_lib.ROUTE_SYRK_EXACT) > 0 and _lib.route_count(_lib.ROUTE_PANEL_CHAIN) == 0
-    assert _lib.route_count(_lib.ROUTE_POTRF_PAIR) == 1            # (round 6) the pair phase: K = 2048 far updates
+    assert _lib.route_count(_lib.ROUTE_POTRF_PAIR) == 0            # (round 6) the pair phase is opt-in (GPX_POTRF_PAIR_ROWS)
     np.testing.assert_allclose(Krows @ alpha, y[rows], rtol=1e-9, atol=1e-10)
     dg = _device_diag(g)
     assert (dg > 0).all()

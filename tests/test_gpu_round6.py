@@ -200,7 +200,8 @@ def _diag_any(g):
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_pair_phase_k2048_updates_vs_one_panel_per_update(monkeypatch, dtype):
     """potrf()'s pair phase (far trailing updates of depth K = 2048, one per TWO 1024-wide panels, both panels of the next
-    pair factored on the side stream beside it; default for fp64 while >= 20480 rows lie beyond a pair) forced at
+    pair factored on the side stream beside it; opt-in, GPX_POTRF_PAIR_ROWS: a shorter step at N = 65536 for a slower
+    update kernel) forced at
     N = 13312 + 37 (ragged: the pairs, the exit step, then the tapering single-panel loop) against the default schedule of
     that size (one panel per update): both against oracle kernel rows (K alpha = y), the log_lh identity from diag(L), and
     each other (log_lh rtol 1e-12 / 1e-5: the same sums in a different association)."""

@@ -55,7 +55,8 @@ if key:
     # phase while >= PAIR_ROWS rows lie beyond a pair (far updates of depth K = 2048: U_a, U_b one block column each, U_c the
     # rest; V is a panel-class product and not this kernel), then one panel per update with the next block column first.
     # A launch of at most 2600 tiles of 128 x 128 goes to the 128 x 64 kernel (GPX_SYRK_BN64_TILES) and is not counted here.
-    BN64_TILES, PAIR_ROWS = 2600, 20480
+    BN64_TILES = 2600
+    PAIR_ROWS = int(os.environ.get("GPX_POTRF_PAIR_ROWS", "0")) or (1 << 60)      # (the library's default: no pair phase)
 
     def width(left):
         return 256 if left <= 8192 else 512 if left <= 12288 else 1024
