@@ -177,24 +177,37 @@ __device__ __forceinline__ void store_wave_tile_atomic(typename M::acc_t (&acc)[
         }
 }
 
-// The same for a wave tile that lies wholly inside the matrix and wholly at or below the diagonal (all but the
-// edge and diagonal tiles of a trailing update): no bounds or triangle tests, one lane pointer, the row part of the
-// offset wave-uniform and the column part an immediate -- two vector instructions per atomic instead of seventeen
-// (the general form's 64-bit index arithmetic and exec masking ran on the SIMD whose other wave is in its k-loop).
+// The same for a wave tile that lies wholly inside the matrix (every tile of an aligned update but those on its ragged
+// edges): no bounds tests, one lane pointer, the row part of the offset wave-uniform and the column part an immediate, the
+// triangle as ONE 32-bit compare of a per-lane constant against a wave-uniform threshold per element -- a handful of
+// instructions per atomic instead of seventeen (the general form's 64-bit index arithmetic and exec masking ran on the
+// SIMD whose other wave is in its k-loop: in situ the difference is 1.8 % of the N = 65536 step).
+// The instruction stream is THE SAME for tiles below the diagonal and tiles on it (those only execute fewer lanes): a first
+// version that skipped the compare for interior tiles made their epilogue shorter than the diagonal tiles' general one,
+// the workgroups of an XCD fell out of the lock-step in which they share operand slices in L2, and the kernel fetched
+// 25 % more alone and 80 % more in situ (FETCH_SIZE 6.56 -> 8.1 GB raw per launch at M = 32768;
+// profiles/r06_fetch_probe.log).  Equal work per tile keeps the convoy together.
 template <typename T, typename M, int NTJ>
 __device__ __forceinline__ void store_wave_tile_atomic_inner(typename M::acc_t (&acc)[64 / (M::NR == 4 ? 16 : 32)][NTJ],
                                                              T *__restrict__ C, int64_t ldc, int64_t r_base,
-                                                             int64_t c_base, int lane, T alpha)
+                                                             int64_t c_base, int lane, T alpha, int tri,
+                                                             int64_t row0, int64_t col0)
 {
     constexpr int TM = M::NR == 4 ? 16 : 32, NR = M::NR, TI = 64 / TM;
     T *p = C + (r_base + M::row(lane, 0)) * ldc + c_base + (lane & (TM - 1));
+    // element (i, r, j) of this lane is at or below the diagonal iff  delta + lane_d + rowoff - coloff >= 0
+    const int64_t delta64 = (row0 + r_base) - (col0 + c_base);
+    const int delta = tri == GPX_LOWER ? (int)max((int64_t)-4096, min((int64_t)4096, delta64)) : 4096;   // wave-uniform; clamped: |offsets| < 128
+    const int lane_d = M::row(lane, 0) - (lane & (TM - 1));
 #pragma unroll
     for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-            T *pr = p + (int64_t)(i * TM + M::row(0, r)) * ldc;
+            const int rowoff = i * TM + M::row(0, r);
+            T *pr = p + (int64_t)rowoff * ldc;
 #pragma unroll
-            for (int j = 0; j < NTJ; ++j) atomic_add_nr(pr + j * TM, alpha * acc[i][j][r]);
+            for (int j = 0; j < NTJ; ++j)
+                if (lane_d >= j * TM - rowoff - delta) atomic_add_nr(pr + j * TM, alpha * acc[i][j][r]);
         }
 }
 
@@ -820,9 +833,8 @@ __global__ __launch_bounds__(F_BM * 2, 2) void gemm_nt_fast_kernel(int64_t M, in
                 for (int r = 0; r < MM::NR; ++r) sum += acc[i][j][r];
         if (sum == (T)123.456) C[0] = sum;
     } else
-    if (fm.atomic_c && !beta0 && bm0 + F_BM <= M && bn0 + BN <= N &&
-        (tri != GPX_LOWER || row0 + bm0 >= col0 + bn0 + BN - 1))
-        store_wave_tile_atomic_inner<T, MM, TJ>(acc, C, ldc, bm0 + wr * 64, bn0 + wc * (BN / 2), lane, alpha);
+    if (!(ABL & 16) && fm.atomic_c && !beta0 && bm0 + F_BM <= M && bn0 + BN <= N)
+        store_wave_tile_atomic_inner<T, MM, TJ>(acc, C, ldc, bm0 + wr * 64, bn0 + wc * (BN / 2), lane, alpha, tri, row0, col0);
     else if (fm.atomic_c && !beta0)
         store_wave_tile_atomic<T, NTW, MM, TJ>(acc, C, ldc, M, N, bm0 + wr * 64, bn0 + wc * (BN / 2), lane, alpha, tri, row0,
                                        col0);
@@ -1090,7 +1102,7 @@ int syrk_bc(int dtype, int64_t n, int64_t row_begin, void *Cloc, int64_t ldc, in
 #define GPX_ABL_CASE(V)                                                                                            \
     case V: return launch_gemm_nt_fast<double, 128, 1, V>(M, Ncols, kb, A, ldp, Pb, ldp, C, ldc, -1.0, GPX_LOWER, \
                                                                row_begin, cl0 + (int64_t)rank * nb, st, &fm, work, 0, 0, bt)
-            switch ((int)tune().gemm_ablate) { GPX_ABL_CASE(1); GPX_ABL_CASE(2); GPX_ABL_CASE(4); GPX_ABL_CASE(7); GPX_ABL_CASE(8); GPX_ABL_CASE(15); default: break; }
+            switch ((int)tune().gemm_ablate) { GPX_ABL_CASE(1); GPX_ABL_CASE(2); GPX_ABL_CASE(4); GPX_ABL_CASE(7); GPX_ABL_CASE(8); GPX_ABL_CASE(15); GPX_ABL_CASE(16); default: break; }
 #undef GPX_ABL_CASE
         }
         if (dtype == GPX_F64)

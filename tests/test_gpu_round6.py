@@ -231,3 +231,33 @@ def test_pair_phase_k2048_updates_vs_one_panel_per_update(monkeypatch, dtype):
     np.testing.assert_allclose(out["pair"][0], out["single"][0], rtol=1e-12 if f64 else 1e-5)
     np.testing.assert_allclose(out["pair"][1], out["single"][1], rtol=1e-8 if f64 else 5e-3, atol=1e-11 if f64 else 5e-3)
     np.testing.assert_allclose(out["pair"][2], out["single"][2], rtol=1e-8 if f64 else 1e-3, atol=1e-11 if f64 else 1e-3)
+
+
+def test_fit_batch_grad_chunked_equals_one_chunk_and_leaves_the_handle_alone(monkeypatch):
+    """The table is processed in chunks of what fits in HBM (GPX_BATCH_MAX caps a chunk): chunks of 3 give the same values and
+    gradients as one chunk of 8, bit for bit; the handle's own fitted state (a fit made before the sweep) is untouched, as
+    gpx_gp_fit_batch promises; the value-only entry after a gradient sweep still agrees."""
+    from gaussian_processes_amd import mlii
+    N, d = 1280, 5
+    X, y, _ = orc.synth_inputs(N, d, 4)
+    th = _draws(d, 8)
+    with mlii.BatchEvaluator(X, y) as ev:
+        lib = _lib.load()
+        p0 = np.array([1.1, 0.9 * np.sqrt(d)])
+        _lib.check(lib.gpx_gp_set_params(ev.h, _lib.dptr(p0), 0.8))
+        _lib.check(lib.gpx_gp_fit(ev.h, None))
+        v_own = ctypes.c_double(0.0)
+        _lib.check(lib.gpx_gp_log_lh(ev.h, ctypes.byref(v_own)))
+        monkeypatch.setenv("GPX_BATCH_MAX", "3")               # (first: an existing larger workspace would be reused whole)
+        v3, g3 = ev.value_and_grad(th, clamp=False)
+        monkeypatch.delenv("GPX_BATCH_MAX", raising=False)
+        v1, g1 = ev.value_and_grad(th, clamp=False)
+        np.testing.assert_array_equal(v1, v3)
+        np.testing.assert_array_equal(g1, g3)
+        monkeypatch.delenv("GPX_BATCH_MAX", raising=False)
+        v_again = ctypes.c_double(0.0)
+        _lib.check(lib.gpx_gp_log_lh(ev.h, ctypes.byref(v_again)))
+        assert v_again.value == v_own.value
+        o = orc.OracleGP("gaussian", (1.1, 0.9 * np.sqrt(d)), X, y, 0.8)
+        np.testing.assert_allclose(v_own.value, float(o.log_lh), rtol=1e-10)
+        np.testing.assert_allclose(ev(th), np.where(np.isfinite(ev(th)), v1, -np.inf))
