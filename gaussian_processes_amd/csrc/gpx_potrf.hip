@@ -427,15 +427,13 @@ int potrf(int dtype, void *A, int64_t n, int64_t lda, int *info_dev, hipStream_t
     //     st: U_a  block column C <- (A | B), K = 2048         q: panel C   (after U_a)
     //     st: U_b  block column D <- (A | B), K = 2048         q: V = D <- C, K = 1024 (after U_b and panel C); panel D
     //     st: U_c  columns beyond D <- (A | B), K = 2048       (the long one: both panels and V hide under it)
-    // MEASURED at N = 65536 fp64 (profiles/r06_ab_pair_phase.log, r06_timeline_n65536_{pair,nopair}.txt, r06_pmc_pair/): the
-    // step gets 0.9 ... 1.4 % SHORTER (1.3248 -> 1.3133 s, 1.359 -> 1.3405 s on two boxes; log_lh identical to the last digit)
-    // because a fit has 60 long trailing launches instead of 81 -- fewer ramps, tails and cross-stream hand-offs -- and the
-    // trailing updates' C traffic halves.  But the update kernel itself runs SLOWER per tile (0.916 of peak against 0.921;
-    // bench.py's kernel-class fraction 0.880 against 0.899) and its L2-miss traffic rises by half (30.5 GB fetched per launch,
-    // 1.83 TB per fit against 1.20): a K = 2048 tile lives twice as long, the tiles of a patch drift further apart than the
-    // 16 k-steps of operand slices an XCD's 4 MiB L2 holds, and the A slices are fetched again.  A shorter step for a worse
-    // kernel: not the default; the route is kept because the schedule is the natural home of a deeper-K update once the
-    // tile order keeps a patch's sharers inside the L2 window.  fp32 at N = 32768 (three pairs at most): 96.5 vs 96.4 ms.
+    // MEASURED at N = 65536 fp64 (profiles/r06_ab_pair_phase.log, r06_timeline_n65536_{pair,nopair}.txt): the step gets 0.2 ... 0.6 %
+    // SHORTER on the final build (1.334 -> 1.326 - 1.331 s; 0.9 ... 1.4 % on the round's earlier build; log_lh identical to the
+    // last digit) because a fit has 60 long trailing launches instead of 81 -- fewer ramps, tails and cross-stream hand-offs --
+    // and the trailing updates' C traffic halves.  But the update kernel's own figure gets worse (class fraction 0.88 against
+    // 0.893; per tile 0.916 of peak against 0.921): the panel stream works two panels and V back to back beside ONE launch.
+    // A slightly shorter step for a lower roofline fraction of the kernel this project is measured by: not the default; the
+    // route is kept, tested, for larger N.  fp32 at N = 32768 (three pairs at most): 96.5 vs 96.4 ms.
     const int64_t pair_rows = (bt || nb != 1024 || xrows > 1) ? 0 : tune().pair_rows[dtype == GPX_F64 ? 0 : 1];
     // (every panel of the phase is 1024 wide: with the taper on, the widths shrink once <= 12288 rows are left)
     auto pair_ok = [&](int64_t k) { return pair_rows > 0 && n - (k + 4 * 1024) >= pair_rows && nominal(k + 1024) == 1024 &&
