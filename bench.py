@@ -51,6 +51,8 @@ def parse_args():
     ap.add_argument("--cpu-sample-n2", type=int, default=16384)   # a second, cheap sample (~12 s): two sizes fit the two-term model
                                                                   # t(N) = a N^3 + b N^2 of the O(N^3) stages (see cpu_baseline)
     ap.add_argument("--cpu-sample-n3", type=int, default=0)
+    ap.add_argument("--cpu-budget-s", type=float, default=170.0,
+                    help="host seconds the CPU samples may take together; a size predicted to overrun is skipped")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip per-launch HIP-event profiling")
     ap.add_argument("--no-secondary", action="store_true",
@@ -120,7 +122,7 @@ def _blas_info():
     return info
 
 
-def cpu_baseline(N, d, m, sample_ns):
+def cpu_baseline(N, d, m, sample_ns, budget_s=170.0):
     """Oracle stage sequence (the reference's own: C kernel loop, scipy cholesky / cho_solve, numpy slogdet LU, dot)
     on the host cores, on bounded samples (`sample_ns`, increasing), scaled stage by stage to N.
 
@@ -135,7 +137,18 @@ def cpu_baseline(N, d, m, sample_ns):
     ns_list = sorted(set(min(int(v), N) for v in sample_ns if v))
     _cpu_sample(orc, min(768, N), d, 8)                     # untimed: library loading / thread-pool start-up
     samples, llh = [], None
+    skipped = []
+    t_begin = time.perf_counter()
     for ns in ns_list:
+        # a bounded sample (the contract: the default run finishes within a few minutes whatever the host): the next size is
+        # predicted from the one before (measured on this pool's host: the N = 32768 sequence takes 3.6 x the N = 16384 one --
+        # N^3 work at a rising BLAS rate; budgeted as (ratio of sizes)^3 / 2) and skipped when it would overrun
+        if samples:
+            n_prev, t_prev = samples[-1]
+            predicted = sum(t_prev.values()) * (ns / float(n_prev)) ** 3 / 2.0
+            if (time.perf_counter() - t_begin) + predicted > budget_s:
+                skipped.append({"N": ns, "predicted_seconds": round(predicted, 1)})
+                continue
         t, llh_s = _cpu_sample(orc, ns, d, m)
         if llh is None:
             llh = llh_s
@@ -195,6 +208,7 @@ def cpu_baseline(N, d, m, sample_ns):
                    "meaning": "high = the largest sample scaled at nominal exponents (its rate held); low = exponents fitted from "
                               "the two largest samples (a power law: the rate keeps rising); value = the two-term model between them"},
         "two_term_model": model,
+        "sample_budget_s": budget_s, "samples_skipped_over_budget": skipped,
         "os_cpu_count": os.cpu_count(), "cpu_model": cpu_model, "blas": blas,
         "sample_seconds": round(sum(sum(t.values()) for _, t in samples), 3),
         "fair_value": round(fair, 3),
@@ -389,7 +403,8 @@ def main():
     if not args.no_secondary and (N, d) != (8192, 8):
         result["secondary"] = secondary_measurements(args, lib, _lib, local_rank, result)
     if not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(N, d, m, (args.cpu_sample_n, args.cpu_sample_n2, args.cpu_sample_n3))
+        result["cpu_baseline"] = cpu_baseline(N, d, m, (args.cpu_sample_n, args.cpu_sample_n2, args.cpu_sample_n3),
+                                              budget_s=args.cpu_budget_s)
     print(json.dumps(result))
 
 
