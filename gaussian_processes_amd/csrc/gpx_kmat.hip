@@ -66,7 +66,8 @@ int make_kparams(int kernel, int member, const double *params, double diag_add, 
 struct KP32 { float c[6]; };
 
 constexpr int KM_ROWS = 64;        // tile rows
-constexpr int KM_RB = 4;           // rows register-blocked per lane
+constexpr int KM_RB = 8;           // rows register-blocked per lane (round 6: 4 -> 8: half the LDS reads and loop overhead per entry,
+                                   // N = 65536 d = 32: 7.65 -> 7.3 ms)
 
 // MODE 0..2: gaussian FORM 0..2 ; MODE 3: periodic K, any d ; MODE 4: periodic member, d == 1
 template <typename T, int MODE>
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256) void kmat_kernel(const T *__restrict__ x1, int
 #pragma unroll
             for (int r = 0; r < KM_RB; ++r)
                 arow[r] = x1 + min(row0 + wave_u * 16 + rb + r, n - 1) * d;
-#pragma unroll 8
+#pragma unroll 4
             for (int k = 0; k < d; ++k) {
                 T b[VEC];
 #pragma unroll
