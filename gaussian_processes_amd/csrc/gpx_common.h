@@ -198,6 +198,8 @@ int trsv_lower(int dtype, const void *L, int64_t n, int64_t ldl, void *b, void *
                TrsvOps *ops = nullptr);
 int trsm_right_lt(int dtype, const void *L, int64_t n, int64_t ldl, void *X, int64_t m, int64_t ldx,
                   hipStream_t st, int x_upper = 0, TrsvOps *ops = nullptr);   // ops: this factor's block operators (completed here if need be): in-block substitution = one product with inv(L_kk)
+int trsm_right_lt_batch(int dtype, const void *L, int64_t sL, int64_t n, int64_t ldl, void *X, int64_t sX, int64_t m, int64_t ldx,
+                        hipStream_t st, int x_upper, const void *ops_base, int64_t sO, int count);   // `count` systems in lock-step (operator route)
 int logdet_chol(int dtype, const void *L, int64_t n, int64_t ldl, double *out_dev, hipStream_t st, int count = 1,
                 int64_t sL = 0, int64_t so = 0);
 int dot(int dtype, const void *a, const void *b, int64_t n, double *out_dev, hipStream_t st, int count = 1,

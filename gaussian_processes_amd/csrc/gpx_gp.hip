@@ -581,6 +581,24 @@ int gpx_gp_get_inv_Kxx(gpx_gp_t *g, double *out, int64_t ld)
     return download_f64(g->dtype, out, ld, C.p, lda, n, n, 0, g->st);
 }
 
+// the reduction half of the gradient: W = K^-1 (lower triangle, n x ldw) is in HBM; one fused pass of (alpha alpha^T - W)
+// against the kernel derivatives evaluated on the fly (gp_c.pyx:34-49).  Synchronises g->st.
+static int grad_reduce(gpx_gp *g, const void *alpha, const double *params, double s_noise, const void *W, int64_t ldw, double *part,
+                       double *out)
+{
+    const int64_t n = g->n;
+    double *aa = part + 1024 * 4;
+    GPX_TRY(dot(g->dtype, alpha, alpha, n, aa, g->st));
+    double p4[4];
+    GPX_TRY(dloglh_reduce(g->dtype, g->kernel, g->x, n, g->d, params, alpha, W, ldw, part, p4, g->st));
+    double ata = 0.0;
+    GPX_HIP(hipMemcpyAsync(&ata, aa, sizeof(double), hipMemcpyDeviceToHost, g->st));
+    GPX_HIP(hipStreamSynchronize(g->st));
+    for (int i = 0; i < g->nparams; ++i) out[i] = 0.5 * p4[i];
+    out[g->nparams] = s_noise * (ata - p4[3]);         // dK/ds = 2 s I  (gp_c.pyx:46)
+    return GPX_OK;
+}
+
 // d log_lh / d(kernel params..., s) from a factor L (n x n, lower, in HBM) and alpha = K^-1 y: X = L^-T by the blocked
 // right-looking TRSM, W = K^-1 = X X^T (lower triangle, triangular k-loop) on the MFMA kernel, then ONE fused pass
 // reduces (alpha alpha^T - W) against the kernel derivatives evaluated on the fly.  X, W: n x lda scratch; part:
@@ -597,16 +615,7 @@ static int grad_from_factor(gpx_gp *g, const void *L, int64_t lda, const void *a
     GPX_HIP(hipMemsetAsync(W, 0, (size_t)n * lda * es, g->st));
     GPX_TRY(trsm_right_lt(g->dtype, L, n, lda, X, n, lda, g->st, 1, ops));
     GPX_TRY(gemm_nt(g->dtype, n, n, n, X, lda, X, lda, W, lda, 1.0, GPX_LOWER, 0, 0, g->st, 0, 1));
-    double *aa = part + 1024 * 4;
-    GPX_TRY(dot(g->dtype, alpha, alpha, n, aa, g->st));
-    double p4[4];
-    GPX_TRY(dloglh_reduce(g->dtype, g->kernel, g->x, n, g->d, params, alpha, W, lda, part, p4, g->st));
-    double ata = 0.0;
-    GPX_HIP(hipMemcpyAsync(&ata, aa, sizeof(double), hipMemcpyDeviceToHost, g->st));
-    GPX_HIP(hipStreamSynchronize(g->st));
-    for (int i = 0; i < g->nparams; ++i) out[i] = 0.5 * p4[i];
-    out[g->nparams] = s_noise * (ata - p4[3]);         // dK/ds = 2 s I  (gp_c.pyx:46)
-    return GPX_OK;
+    return grad_reduce(g, alpha, params, s_noise, W, lda, part, out);
 }
 
 // Gradient of the log marginal likelihood w.r.t. (kernel params..., s), RW06 eq. 5.9
@@ -651,13 +660,23 @@ static int fit_batch_impl(gpx_gp_t *g, const double *thetas, int64_t B, double *
     if (B == 0) return GPX_OK;
     if (dloglh) {
         if (g->kernel == GPX_KERNEL_PERIODIC && g->d != 1) { set_error("periodic gradient needs d == 1"); return GPX_ERR_UNSUPPORTED; }
-        // gradient scratch BEFORE the chunk size is taken from what is free: X = L^-T and W = K^-1 of ONE matrix at a time
-        const size_t gneed = 2 * (size_t)g->n * g->lda * esize(g->dtype) + (size_t)(1024 * 4 + 8) * sizeof(double);
+        // gradient scratch BEFORE the chunk size is taken from what is free: X = L^-T and W = K^-1 of a GROUP of up to 8 rows
+        // at a time (the group's TRSM and SYRK run in lock-step: at n = 8192 one system's far update is 1 - 2 rounds of
+        // tiles), as many as a sixth of free HBM holds, + their block operators
+        const size_t nl = (size_t)g->n * g->lda * esize(g->dtype);
+        const bool group_ok = trsv_ops_ahead_ok(g->dtype, g->A, g->n, g->lda) && tune().trsm_ops != 0;
+        size_t freeg = 0, totalg = 0;
+        GPX_HIP(hipMemGetInfo(&freeg, &totalg));
+        const size_t per_row = 2 * nl + (group_ok ? trsv_ops_bytes(g->dtype, g->n) : 0);
+        int G = group_ok ? (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(8, B), (int64_t)((double)(freeg + g->gw_bytes) / 6.0 / (double)per_row))) : 1;
+        if (g->gw_cap >= G && g->gw) G = g->gw_cap;
+        const size_t gneed = (size_t)G * per_row + (size_t)(1024 * 4 + 8) * sizeof(double) + 256;
         if (g->gw_bytes < gneed) {
-            if (g->gw) { GPX_HIP(hipStreamSynchronize(g->st)); (void)hipFree(g->gw); g->gw = nullptr; g->gw_bytes = 0; }
+            if (g->gw) { GPX_HIP(hipStreamSynchronize(g->st)); (void)hipFree(g->gw); g->gw = nullptr; g->gw_bytes = 0; g->gw_cap = 0; }
             GPX_HIP(hipMalloc(&g->gw, gneed));
             g->gw_bytes = gneed;
         }
+        g->gw_cap = G;
     }
     if (!g->x_finite || !g->y_finite) { set_error("%s (%s)", NONFINITE_MSG, g->x_finite ? "y" : "x"); return GPX_ERR_ARG; }
     const int64_t n = g->n, lda = g->lda;
@@ -743,15 +762,47 @@ static int fit_batch_impl(gpx_gp_t *g, const double *thetas, int64_t B, double *
             // computes the gradient whenever the factorisation succeeds (no logdet < MIN test there); NaN for a row that
             // is not positive definite (gp/gp.py:424-428) or that the reference would have refused (ValueError).
             const size_t nl = (size_t)n * lda * es;
-            char *Xs = (char *)g->gw, *Ws = Xs + nl;
-            double *part = (double *)(Ws + nl);
-            for (int i = 0; i < cnt; ++i) {
-                double *o = dloglh + (b0 + i) * (np + 1);
-                if (!valid[i] || hi[i] != 0) { for (int k = 0; k <= np; ++k) o[k] = NAN; continue; }
-                const double *th = thetas + (b0 + i) * (np + 1);
-                g->bops.invalidate();
-                GPX_TRY(grad_from_factor(g, (char *)Ab.p + (size_t)i * per, lda, (char *)al.p + (size_t)i * vec, th, th[np],
-                                         Xs, Ws, part, &g->bops, o));
+            const int G = (int)g->gw_cap;
+            char *Xs = (char *)g->gw, *Ws = Xs + (size_t)G * nl;
+            const size_t obytes = G > 1 ? trsv_ops_bytes(g->dtype, n) : 0;
+            char *Os = Ws + (size_t)G * nl;
+            double *part = (double *)(((uintptr_t)(Os + (size_t)G * obytes) + 255) / 256 * 256);
+            for (int i0 = 0; i0 < cnt; i0 += G) {
+                const int gc = std::min(G, cnt - i0);
+                bool any = false;
+                for (int i = i0; i < i0 + gc; ++i) any = any || (valid[i] && hi[i] == 0);
+                const bool lock_step = G > 1 && gc > 1 && any;
+                if (lock_step) {
+                    // the group's K^-1 in lock-step: X = L^-T (operators of every row built first), W = X X^T lower.  Rows that are
+                    // invalid or not positive definite take part (their factor is garbage; nothing of theirs is read back).
+                    const char *L0 = (const char *)Ab.p + (size_t)i0 * per;
+                    dim3 grid((unsigned)cdiv(lda, 256), (unsigned)std::min<int64_t>(n, 32768)), block(256);
+                    for (int i = 0; i < gc; ++i) {
+                        if (g->dtype == GPX_F64) hipLaunchKernelGGL((eye_kernel<double>), grid, block, 0, st, (double *)(Xs + (size_t)i * nl), n, lda);
+                        else hipLaunchKernelGGL((eye_kernel<float>), grid, block, 0, st, (float *)(Xs + (size_t)i * nl), n, lda);
+                        GPX_LAUNCH_CHECK();
+                        TrsvOps o;                                   // (a view into the group's operator block: not owned, not freed)
+                        o.buf = Os + (size_t)i * obytes; o.bytes = obytes;
+                        GPX_TRY(trsv_ops_build_upto(g->dtype, L0 + (size_t)i * per, n, lda, &o, n / 512, st));
+                    }
+                    GPX_HIP(hipMemsetAsync(Ws, 0, (size_t)gc * nl, st));
+                    GPX_TRY(trsm_right_lt_batch(g->dtype, L0, (int64_t)(per / es), n, lda, Xs, (int64_t)(nl / es), n, lda, st, 1, Os,
+                                                (int64_t)(obytes / es), gc));
+                    Batch bw; bw.count = gc; bw.sA = bw.sB = bw.sC = (int64_t)(nl / es);
+                    GPX_TRY(gemm_nt(g->dtype, n, n, n, Xs, lda, Xs, lda, Ws, lda, 1.0, GPX_LOWER, 0, 0, st, 0, 1, &bw));
+                }
+                for (int i = i0; i < i0 + gc; ++i) {
+                    double *o = dloglh + (b0 + i) * (np + 1);
+                    if (!valid[i] || hi[i] != 0) { for (int k = 0; k <= np; ++k) o[k] = NAN; continue; }
+                    const double *th = thetas + (b0 + i) * (np + 1);
+                    const void *alpha_i = (char *)al.p + (size_t)i * vec;
+                    if (lock_step) {
+                        GPX_TRY(grad_reduce(g, alpha_i, th, th[np], Ws + (size_t)(i - i0) * nl, lda, part, o));
+                    } else {
+                        g->bops.invalidate();
+                        GPX_TRY(grad_from_factor(g, (char *)Ab.p + (size_t)i * per, lda, alpha_i, th, th[np], Xs, Ws, part, &g->bops, o));
+                    }
+                }
             }
         }
     }

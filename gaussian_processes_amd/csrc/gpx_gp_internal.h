@@ -21,7 +21,7 @@ struct gpx_gp {
     gpx::TrsvOps ops;
     // fit_batch_grad: X = L^-T and W = K^-1 of one matrix at a time + the reduction's partial sums (grow-only), and
     // the block operators of the row being differentiated
-    void *gw; size_t gw_bytes;
+    void *gw; size_t gw_bytes; int64_t gw_cap;   // gw_cap: rows per lock-step gradient group the block holds
     gpx::TrsvOps bops;
     hipStream_t st_ops;   // lazily created: where gpx_gp_fit builds `ops` while the factorisation is still running
     hipEvent_t ev_ops;

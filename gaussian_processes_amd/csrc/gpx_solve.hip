@@ -965,6 +965,38 @@ int trsm_right_lt(int dtype, const void *L, int64_t n, int64_t ldl, void *X, int
     return GPX_OK;
 }
 
+// X <- X L^-T for `count` systems in LOCK-STEP (operator route only: n a multiple of 512, every system's block operators
+// complete in ops_base + i * sO): every launch covers all systems -- at n = 8192 a single system's far update is 1 - 2 rounds
+// of tiles (32 x 32 at most), eight of them fill the chip.  L, X, the operators and the scratch block are sL / sX / sO / (m * 512)
+// elements apart.  Same products, same order per system as trsm_right_lt.
+int trsm_right_lt_batch(int dtype, const void *L, int64_t sL, int64_t n, int64_t ldl, void *X, int64_t sX, int64_t m, int64_t ldx,
+                        hipStream_t st, int x_upper, const void *ops_base, int64_t sO, int count)
+{
+    if (n <= 0 || m <= 0 || count <= 0) return GPX_OK;
+    const size_t es = esize(dtype);
+    if (n % OB != 0 || !trsv_ops_ahead_ok(dtype, L, n, ldl)) { set_error("trsm_right_lt_batch: n must be a multiple of %d", OB); return GPX_ERR_ARG; }
+    route_hit(RT_TRSM_OPS);
+    const int64_t nfull = n / OB, BS = (int64_t)OB * OB, sS = m * OB;
+    void *scr = nullptr;
+    GPX_TRY(trsm_scratch((size_t)count * sS * es, &scr));
+    for (int64_t k = 0; k < nfull; ++k) {
+        const int64_t k0 = k * OB, r = k0 + OB;
+        const int64_t me = x_upper ? std::min(m, r) : m;
+        char *Xk = (char *)X + k0 * es;
+        Batch b1; b1.count = count; b1.sA = sX; b1.sB = sO; b1.sC = sS;
+        GPX_TRY(gemm_nt(dtype, me, OB, OB, Xk, ldx, (const char *)ops_base + (size_t)k * BS * es, OB, scr, OB, 1.0, GPX_FULL, 0, 0, st, 1, 0, &b1));
+        for (int i = 0; i < count; ++i)
+            GPX_HIP(hipMemcpy2DAsync(Xk + (size_t)i * sX * es, (size_t)ldx * es, (const char *)scr + (size_t)i * sS * es, (size_t)OB * es,
+                                     (size_t)OB * es, (size_t)me, hipMemcpyDeviceToDevice, st));
+        if (r < n) {
+            Batch b2; b2.count = count; b2.sA = sX; b2.sB = sL; b2.sC = sX;
+            GPX_TRY(gemm_nt(dtype, me, n - r, OB, Xk, ldx, (const char *)L + (r * ldl + k0) * es, ldl, (char *)X + r * es, ldx,
+                            -1.0, GPX_FULL, 0, 0, st, 0, 0, &b2));
+        }
+    }
+    return GPX_OK;
+}
+
 // ---- reductions (single workgroup, fixed order => deterministic) ----------
 template <typename T, int MODE>   // MODE 0: sum a[i]*b[i]   1: 2*sum log a[i*stride]
 __global__ __launch_bounds__(1024) void reduce_kernel(const T *__restrict__ a, const T *__restrict__ b,

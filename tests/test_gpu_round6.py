@@ -238,7 +238,7 @@ def test_fit_batch_grad_chunked_equals_one_chunk_and_leaves_the_handle_alone(mon
     gradients as one chunk of 8, bit for bit; the handle's own fitted state (a fit made before the sweep) is untouched, as
     gpx_gp_fit_batch promises; the value-only entry after a gradient sweep still agrees."""
     from gaussian_processes_amd import mlii
-    N, d = 1280, 5
+    N, d = 1536, 5                                         # (a multiple of 512: the gradient's lock-step group route)
     X, y, _ = orc.synth_inputs(N, d, 4)
     th = _draws(d, 8)
     with mlii.BatchEvaluator(X, y) as ev:
