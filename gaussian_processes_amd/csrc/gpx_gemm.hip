@@ -515,6 +515,22 @@ static unsigned long long *g_gemm_stamps = nullptr;
 typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
 #define GPX_DSR(dst, addr, off) \
     asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
+// The wait that belongs to those reads.  The compiler takes an asm's output for written when the statement has executed; a
+// ds_read's destination is written when the data RETURNS.  Every fragment register therefore passes through the wait as an
+// in/out operand: nothing can read, copy or -- once the fragments are dead, after the k-loop -- REUSE such a register
+// before the wait.  (Round 6, found by the soak test beside a neighbour: the plain wait after the loop came behind the
+// compiler's copies of the accumulators for the epilogue, one of which went to a register of the last, unused fragment
+// read; about one fp32 fit in a thousand at n = 8192 got the late LDS data in the last accumulator of a wave instead --
+// rows 59 / 63 of a 64-row wave tile.  tools/r6_soak_probe.py, profiles/r06_soak_probe_*.log.)
+#define GPX_FRAG_WAIT(CNT, RA, RB, NB4)                                                                        \
+    do {                                                                                                       \
+        if (NB4)                                                                                               \
+            asm volatile("s_waitcnt " CNT : "+v"(RA[0]), "+v"(RA[1]), "+v"(RA[2]), "+v"(RA[3]), "+v"(RB[0]), "+v"(RB[1]), \
+                                            "+v"(RB[2]), "+v"(RB[3]) : : "memory");                             \
+        else                                                                                                   \
+            asm volatile("s_waitcnt " CNT : "+v"(RA[0]), "+v"(RA[1]), "+v"(RA[2]), "+v"(RA[3]), "+v"(RB[0]), "+v"(RB[1]) \
+                         : : "memory");                                                                        \
+    } while (0)
 
 // TAG only changes the symbol name: 1 = the block-cyclic trailing update of the
 // factorisation (gpx_d_syrk_bc), so that profilers list the dominant kernel separately
@@ -696,6 +712,7 @@ __global__ __launch_bounds__(F_BM * 2, 2) void gemm_nt_fast_kernel(int64_t M, in
     //           { MFMA group(R1) ; DMA piece g of stage kt+NST -> buffer kt % NST ; ds_read R0(kt+1)[g] }
     constexpr int H = SUB / 2;
     u4_t r0a[4], r0b[4], r1a[4], r1b[4];
+    constexpr bool NB4 = TM == 16 ? TJ > 2 : TJ > 1;          // the B fragments a half reads: four (else two, GPX_SLOT_READ)
     // one piece of the next un-fetched k-slice.  Issued unconditionally: past the last slice
     // the increment is 0, so the tail re-fetches the final slice into a buffer nobody reads
     // any more (no branch in the k-loop, always the same vmcnt bookkeeping).
@@ -760,7 +777,7 @@ __global__ __launch_bounds__(F_BM * 2, 2) void gemm_nt_fast_kernel(int64_t M, in
         }
         const int inc = (kt + F_NST + 1 < nk) ? G_ROWB : 0;   // slice kt+NST is fetched now; is there one more?
 
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // R0 of this stage is in
+        GPX_FRAG_WAIT("lgkmcnt(0)", r0a, r0b, NB4);             // R0 of this stage is in
         __builtin_amdgcn_sched_barrier(0);
         {
             T ha[TI][H], hb[TJ][H];
@@ -787,7 +804,7 @@ __global__ __launch_bounds__(F_BM * 2, 2) void gemm_nt_fast_kernel(int64_t M, in
                     __builtin_amdgcn_sched_barrier(0);
                 }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // R1 in: this wave is done reading the stage
+        GPX_FRAG_WAIT("lgkmcnt(0)", r1a, r1b, NB4);             // R1 in: this wave is done reading the stage
         if (!(ABL & 1)) {
             WaitVm<(F_NST - 2) * PW>::go();          // slice kt+1 landed (this wave's pieces), then everybody's
             __builtin_amdgcn_s_barrier();
@@ -820,7 +837,8 @@ __global__ __launch_bounds__(F_BM * 2, 2) void gemm_nt_fast_kernel(int64_t M, in
         stage = nstage;
     }
 #undef GPX_SLOT_READ
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // tail DMA / reads must not outlive the tile
+    // tail DMA / reads must not outlive the tile -- nor land in a register the epilogue has been given meanwhile
+    GPX_FRAG_WAIT("vmcnt(0) lgkmcnt(0)", r0a, r0b, NB4);
 
     if (fm.stamps) { __builtin_amdgcn_s_barrier(); st2 = __builtin_amdgcn_s_memtime(); }   // all waves done
     if (ABL & 8) {                             // timing only: no epilogue (one element keeps the accumulators alive)
