@@ -444,7 +444,7 @@ def secondary_measurements(args, lib, _lib, local_rank, headline):
     rag = {"name": "ragged_sizes", "unit": "s",
            "config": "handle path, fp64: N=65000 d=32 m=1000 (beside N=65536) and N=8191 d=8 m=1024 (beside N=8192)"}
     aligned = {65000: (headline["stages_ms"]["potrf"], headline["config"]["N"]), 8191: (out[0]["stages_ms"]["potrf"], 8192)}
-    for n_r, d_r, m_r, st_r, wu_r in ((65000, 32, 1000, 2, 1), (8191, 8, 1024, 10, 2)):
+    for n_r, d_r, m_r, st_r, wu_r in ((8191, 8, 1024, 10, 2), (65000, 32, 1000, 2, 1)):    # (the small one first: not right behind the release of 35 GB)
         if n_r == 65000 and headline["config"]["N"] != 65536:
             continue
         r_ = measure_single(args, lib, _lib, n_r, d_r, m_r, _lib.F64, np.float64, st_r, wu_r, local_rank, prof_on=False)

@@ -261,3 +261,54 @@ def test_fit_batch_grad_chunked_equals_one_chunk_and_leaves_the_handle_alone(mon
         o = orc.OracleGP("gaussian", (1.1, 0.9 * np.sqrt(d)), X, y, 0.8)
         np.testing.assert_allclose(v_own.value, float(o.log_lh), rtol=1e-10)
         np.testing.assert_allclose(ev(th), np.where(np.isfinite(ev(th)), v1, -np.inf))
+
+
+# ------------------------------------------------------------- the fragment-register hazard of round 6, as a long soak --
+@pytest.mark.parametrize("dtype,fold", [("float32", True), ("float32", False), ("float64", True)])
+def test_long_soak_beside_a_neighbour(monkeypatch, dtype, fold):
+    """1500 fits of n = 8192 (fp64: 600) beside a second host thread that factors n = 3000 in a loop, every log_lh and alpha
+    equal to the first fit's bit for bit -- the folded route (the panel applies its predecessor itself) and the one with a
+    block-column update per step.  An in-flight LDS read of the GEMM's k-loop used to land in a register its epilogue had
+    been given about once in a thousand such fp32 fits ("The waits carry the fragment registers"; the 50
+    neighbour fits of the round-4 soak caught it once in five suite runs)."""
+    import threading
+    from test_gpu_round4 import _Fit
+    if not fold:
+        monkeypatch.setenv("GPX_POTRF_FOLD_ROWS", "0")
+    n, d = 8192, 3
+    reps = 1500 if dtype == "float32" else 600
+    X, y, _ = orc.synth_inputs(n, d, 4)
+    params, s = np.array([1.0, 0.5 * np.sqrt(d)]), 0.9
+    fit = _Fit(X, y, dtype)
+    llh0, a0 = fit(params, s)
+    stop, err = threading.Event(), []
+
+    def neighbour():
+        try:
+            Xn, yn, _ = orc.synth_inputs(3000, d, 4, seed=5)
+            other = _Fit(Xn, yn, dtype)
+            l0, c0 = other(params, 1.1)
+            while not stop.is_set():
+                l1, c1 = other(params, 1.1)
+                if l1 != l0 or not np.array_equal(c1, c0):
+                    err.append("the neighbour's own fit changed: %r vs %r" % (l1, l0))
+                    break
+            other.close()
+        except Exception as exc:       # noqa: BLE001
+            err.append(repr(exc))
+
+    t = threading.Thread(target=neighbour)
+    t.start()
+    try:
+        for rep in range(reps):
+            llh, a = fit(params, s)
+            assert llh == llh0, "fit %d beside a neighbour: log_lh %r vs %r" % (rep, llh, llh0)
+            assert np.array_equal(a, a0), "fit %d beside a neighbour: alpha differs in %d entries" % (rep, int((a != a0).sum()))
+    finally:
+        stop.set()
+        t.join(120)
+        fit.close()
+    assert not err, err
+    rows = [0, 1, n // 2, n - 2, n - 1, 777, 4097]
+    from test_gpu_round4 import _residual
+    assert _residual(X, y, a0, 1.0, 0.5 * np.sqrt(d), s, rows) < (1e-9 if dtype == "float64" else 2e-3)
